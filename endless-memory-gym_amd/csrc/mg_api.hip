@@ -1,0 +1,157 @@
+// mg_api.hip -- the C ABI of include/memgym.h on top of the per-family implementations.
+#include <map>
+#include <mutex>
+
+#include "mg_family.hpp"
+
+namespace mg {
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace mg
+
+struct mg_env {
+    mg::Family* fam = nullptr;
+    int device = 0;
+    int num_envs = 0;
+    std::string id;
+};
+
+namespace {
+template <typename F>
+int guarded(mg_env* env, F&& f) {
+    try {
+        if (!env || !env->fam) {
+            mg::set_error("null handle");
+            return -1;
+        }
+        MG_HIP(hipSetDevice(env->device));
+        f();
+        return 0;
+    } catch (const mg::OptionError& e) {
+        mg::set_error(e.msg);
+        return e.code;
+    } catch (const std::exception& e) {
+        mg::set_error(e.what());
+        return -1;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* mg_last_error(void) { return mg::g_last_error.c_str(); }
+
+int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
+    try {
+        if (!env_id || !out || num_envs < 1) {
+            mg::set_error("mg_create: bad arguments");
+            return -1;
+        }
+        MG_HIP(hipSetDevice(device));
+        std::string id(env_id);
+        mg::Family* fam = nullptr;
+        if (id == "MortarMayhem-Grid-v0") fam = mg::make_mortar(0, num_envs);
+        else if (id == "MortarMayhem-v0") fam = mg::make_mortar(1, num_envs);
+        else if (id == "Endless-MortarMayhem-v0") fam = mg::make_mortar(2, num_envs);
+        else {
+            mg::set_error("mg_create: environment id not available in this build: " + id);
+            return -5;
+        }
+        mg_env* e = new mg_env();
+        e->fam = fam;
+        e->device = device;
+        e->num_envs = num_envs;
+        e->id = id;
+        *out = e;
+        return 0;
+    } catch (const std::exception& e) {
+        mg::set_error(e.what());
+        return -1;
+    }
+}
+
+void mg_destroy(mg_env* env) {
+    if (!env) return;
+    (void)hipSetDevice(env->device);
+    delete env->fam;
+    delete env;
+}
+
+int32_t mg_num_envs(const mg_env* env) { return env ? env->num_envs : 0; }
+int32_t mg_action_dim(const mg_env* env) { return env ? env->fam->action_dim() : 0; }
+int32_t mg_gt_dim(const mg_env* env) { return env ? env->fam->gt_dim() : 0; }
+const char* mg_info_name(const mg_env* env, int k) { return env ? env->fam->info_name(k) : nullptr; }
+
+int mg_set_option(mg_env* env, const char* key, const double* values, int n) {
+    return guarded(env, [&] {
+        if (!key || !values || n < 1) throw mg::OptionError{-3, "mg_set_option: bad arguments"};
+        env->fam->set_option(key, values, n);
+    });
+}
+
+int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, uint8_t* obs_dev, float* gt_dev, void* stream) {
+    return guarded(env, [&] {
+        if (!obs_dev) throw std::runtime_error("mg_reset: obs_dev is NULL");
+        env->fam->reset(seeds_dev, mask_dev, obs_dev, gt_dev, (hipStream_t)stream);
+    });
+}
+
+int mg_step(mg_env* env, const int32_t* actions_dev, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, float* gt_dev,
+            const mg_info_buffers* info, int autoreset, void* stream) {
+    return guarded(env, [&] {
+        if (!actions_dev || !obs_dev || !reward_dev || !done_dev) throw std::runtime_error("mg_step: NULL buffer");
+        env->fam->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, info, autoreset, (hipStream_t)stream);
+    });
+}
+
+size_t mg_state_size(const mg_env* env) {
+    if (!env) return 0;
+    size_t t = 0;
+    for (auto& b : env->fam->state_blobs()) t += b.second;
+    return t;
+}
+
+int mg_get_state(mg_env* env, void* host_buf, size_t size) {
+    return guarded(env, [&] {
+        if (size < mg_state_size(env)) throw std::runtime_error("mg_get_state: buffer too small");
+        MG_HIP(hipDeviceSynchronize());
+        char* p = (char*)host_buf;
+        for (auto& b : env->fam->state_blobs()) {
+            MG_HIP(hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost));
+            p += b.second;
+        }
+    });
+}
+
+int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
+    return guarded(env, [&] {
+        if (size < mg_state_size(env)) throw std::runtime_error("mg_set_state: buffer too small");
+        MG_HIP(hipDeviceSynchronize());
+        const char* p = (const char*)host_buf;
+        for (auto& b : env->fam->state_blobs()) {
+            MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
+            p += b.second;
+        }
+    });
+}
+
+int mg_set_profiling(mg_env* env, int on) {
+    return guarded(env, [&] { env->fam->prof.on = on != 0; });
+}
+
+int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches) {
+    return guarded(env, [&] {
+        if (kind < 0 || kind > 1 || !total_ms || !launches) throw std::runtime_error("mg_get_profile: bad arguments");
+        env->fam->prof.collect(kind, total_ms, launches);
+    });
+}
+
+int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
+    return guarded(env, [&] {
+        if (i < 0 || i >= env->num_envs) throw std::runtime_error("mg_debug_rng: index out of range");
+        MG_HIP(hipDeviceSynchronize());
+        env->fam->debug_rng(i, out);
+    });
+}
+
+}  // extern "C"

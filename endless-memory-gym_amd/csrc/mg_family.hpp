@@ -1,0 +1,114 @@
+// mg_family.hpp -- host-side interface every environment family implements behind the C ABI (include/memgym.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/memgym.h"
+
+namespace mg {
+
+void set_error(const std::string& msg);
+
+#define MG_HIP(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(e_));      \
+    } while (0)
+
+// RAII device array
+template <typename T>
+struct DevArray {
+    T* p = nullptr;
+    size_t n = 0;
+    DevArray() {}
+    DevArray(const DevArray&) = delete;
+    DevArray& operator=(const DevArray&) = delete;
+    ~DevArray() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count, bool zero = true) {
+        release();
+        n = count;
+        MG_HIP(hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)));
+        if (zero) MG_HIP(hipMemset(p, 0, sizeof(T) * (count ? count : 1)));
+    }
+    void upload(const std::vector<T>& v) {
+        alloc(v.size(), false);
+        MG_HIP(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    }
+    size_t bytes() const { return sizeof(T) * n; }
+};
+
+struct OptionError {
+    int code;  // -2 unknown key, -3 unsupported value
+    std::string msg;
+};
+
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+struct KernelProfile {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // 0 = logic kernel, 1 = raster kernel
+    void begin(int kind, hipStream_t s) {
+        if (!on) return;
+        hipEvent_t a, b;
+        MG_HIP(hipEventCreate(&a));
+        MG_HIP(hipEventCreate(&b));
+        MG_HIP(hipEventRecord(a, s));
+        ev[kind].push_back({a, b});
+    }
+    void end(int kind, hipStream_t s) {
+        if (!on) return;
+        MG_HIP(hipEventRecord(ev[kind].back().second, s));
+    }
+    // sum of elapsed ms and launch count for `kind`; synchronises and clears
+    void collect(int kind, double* ms, int64_t* launches) {
+        double t = 0;
+        for (auto& p : ev[kind]) {
+            MG_HIP(hipEventSynchronize(p.second));
+            float f = 0;
+            MG_HIP(hipEventElapsedTime(&f, p.first, p.second));
+            t += f;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        *ms = t;
+        *launches = (int64_t)ev[kind].size();
+        ev[kind].clear();
+    }
+};
+
+class Family {
+   public:
+    KernelProfile prof;
+    virtual ~Family() {}
+    virtual int action_dim() const = 0;
+    virtual int gt_dim() const = 0;
+    virtual const char* info_name(int k) const = 0;
+    virtual void set_option(const std::string& key, const double* v, int n) = 0;  // throws OptionError
+    virtual void reset(const int64_t* seeds, const uint8_t* mask, uint8_t* obs, float* gt, hipStream_t s) = 0;
+    virtual void step(const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, float* gt,
+                      const mg_info_buffers* info, int autoreset, hipStream_t s) = 0;
+    // checkpoint: list of (device pointer, bytes) making up the state
+    virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;
+    virtual void debug_rng(int i, uint64_t out[6]) = 0;
+};
+
+Family* make_mortar(int variant, int num_envs);
+
+inline int to_int_checked(double v, const char* key) {
+    int i = (int)v;
+    if ((double)i != v) throw OptionError{-3, std::string("option ") + key + " must be integral"};
+    return i;
+}
+
+}  // namespace mg

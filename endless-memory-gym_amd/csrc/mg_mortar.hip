@@ -1,0 +1,672 @@
+// mg_mortar.hip -- Mortar Mayhem family on gfx950: MortarMayhem-Grid-v0, MortarMayhem-v0, Endless-MortarMayhem-v0.
+//
+// Reference behaviour reproduced (bit-exact observations, rewards, dones, RNG consumption):
+//   memory_gym/mortar_mayhem_grid.py     reset :213-278  step :280-375
+//   memory_gym/mortar_mayhem.py          reset :206-272  step :274-369
+//   memory_gym/endless_mortar_mayhem.py  reset :194-259  step :261-373
+//   memory_gym/character_controller.py   free :89-146  grid :177-210  screen-wrap :226-283
+//   memory_gym/pygame_assets.py          Command :241-304  MortarTile/MortarArena :306-418
+//
+// Two kernels per step:
+//   mortar_logic  : one LANE per environment instance.  Episode state machine, RNG, reward/done/info; emits a
+//                   16-byte draw descriptor per instance.  State is small fixed-size records in HBM, read and
+//                   written fully coalesced (lane i <-> record i).
+//   mortar_raster : one WORKGROUP (4 waves) per instance.  The 21,168-byte frame is composed in LDS -- the
+//                   arena comes from an L2-resident template selected by (tiles on?, target tile), the agent
+//                   sprite and the command glyph are stamped from palette-indexed atlases -- and streamed to HBM
+//                   as 1,323 coalesced 16-byte stores.  Write-bound: 21,168 B of algorithmic traffic per env-step.
+#include "mg_device.hpp"
+#include "mg_family.hpp"
+#include "mg_stamps.hpp"
+
+namespace mg {
+
+enum { V_GRID = 0, V_FREE = 1, V_ENDLESS = 2 };
+
+struct MortarParams {
+    int variant, N, allowed, visual_feedback, max_steps, initial_count;
+    int cmd_cap;                 // per-instance command list capacity
+    int arena_x0, tile;          // arena top-left (x == y) and tile size in px
+    int radius, sprite_dim;      // agent radius, sprite box
+    int v_axis_i, v_diag_i;      // free controller: int(speed), int(speed/sqrt2)
+    int off_lo, off_hi;          // endless: spawn offset = integers(off_lo, off_hi)
+    double v_axis, v_diag;       // screen-wrap controller: un-truncated velocities
+    OptList command_count, show_dur, show_delay, expl_dur, expl_delay;
+    double r_fail, r_succ, r_ep_succ, r_new;
+};
+
+// 64-byte per-instance record
+struct __attribute__((aligned(16))) MortarState {
+    int16_t ax, ay;          // agent rect centre
+    int16_t disp_x, disp_y;  // centre of the rect the frame shows (differs from ax/ay only through the Endless stale-sprite quirk)
+    uint8_t rot8;            // agent.rotation / 45
+    uint8_t disp_sprite;     // sprite index the frame shows, 0xFF = none yet
+    uint8_t disp_is_agent;   // rotated_agent_rect is the live agent's rect
+    uint8_t tiles_on;
+    int8_t tx, ty;           // target tile
+    int8_t nx, ny;           // normalized agent position
+    uint16_t num_cmds, cur_cmd;
+    uint16_t vis_pos, vis_len, vis_base;  // display schedule: next entry, length, first command it covers
+    uint16_t cmd_steps, verify_step;
+    uint8_t show_dur, show_delay, expl_dur, expl_delay;
+    uint8_t gx, gy;          // grid controller position
+    int32_t ep_len, t, total_completed;
+    uint32_t pad0;
+    double ep_sum;
+};
+static_assert(sizeof(MortarState) == 64, "MortarState must be 64 bytes");
+
+struct __attribute__((aligned(16))) MortarDesc {
+    int16_t sx, sy;    // sprite top-left on screen
+    uint16_t tmpl;     // background template index, 0xFFFF = leave the frame untouched
+    uint8_t sprite;    // 0..7, 0xFF none
+    uint8_t glyph;     // 0..9, 0xFF none
+    uint32_t pad[2];
+};
+static_assert(sizeof(MortarDesc) == 16, "MortarDesc must be 16 bytes");
+
+__constant__ int8_t kCmdDx[9] = {1, 0, -1, 0, 0, 1, 1, -1, -1};
+__constant__ int8_t kCmdDy[9] = {0, 1, 0, -1, 0, 1, -1, 1, -1};
+
+__device__ __forceinline__ int floordiv(int a, int b) {  // b > 0
+    int q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+__device__ __forceinline__ int mod6(int a) { return ((a % 6) + 6) % 6; }
+__device__ __forceinline__ int round_haz(double v) { return v >= 0 ? (int)floor(v + 0.5) : -(int)floor(-v + 0.5); }
+
+// Env.reset body (RNG draw order: spawn tile, [offset x2], [command_count], commands, show dur/delay, explosion dur/delay)
+__device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint8_t* cmds, MortarDesc& d, float* gt) {
+    // the frame keeps showing the previous agent's rect until the first execution step (Endless only can observe it)
+    if (s.disp_sprite != 0xFF && s.disp_is_agent) {
+        s.disp_x = s.ax;
+        s.disp_y = s.ay;
+        s.disp_is_agent = 0;
+    }
+    int half = P.tile / 2;
+    int tile_id = g.integers(0, P.N * P.N);
+    int cx = P.arena_x0 + P.tile * (tile_id / P.N) + half;
+    int cy = P.arena_x0 + P.tile * (tile_id % P.N) + half;
+    if (P.variant == V_ENDLESS) {
+        cx += g.integers(P.off_lo, P.off_hi);
+        cy += g.integers(P.off_lo, P.off_hi);
+    }
+    s.ax = (int16_t)cx;
+    s.ay = (int16_t)cy;
+    s.rot8 = 0;
+    int nx = floordiv(cx - P.arena_x0, P.tile), ny = floordiv(cy - P.arena_x0, P.tile);
+    s.nx = (int8_t)nx;
+    s.ny = (int8_t)ny;
+    s.gx = (uint8_t)nx;
+    s.gy = (uint8_t)ny;
+
+    int n;
+    if (P.variant == V_ENDLESS) {
+        n = P.initial_count;
+        for (int i = 0; i < n; ++i) cmds[i] = (uint8_t)g.integers(0, P.allowed);
+    } else {
+        n = choice(g, P.command_count);
+        int px = nx, py = ny;
+        for (int i = 0; i < n; ++i) {
+            int valid[9], nv = 0;
+            for (int c = 0; c < P.allowed; ++c) {
+                int qx = px + kCmdDx[c], qy = py + kCmdDy[c];
+                if (qx >= 0 && qx < P.N && qy >= 0 && qy < P.N) valid[nv++] = c;
+            }
+            int pick = g.integers(0, nv), c = valid[0];
+            for (int k = 1; k < 9; ++k) c = (k == pick) ? valid[k] : c;  // register-resident select
+            cmds[i] = (uint8_t)c;
+            px += kCmdDx[c];
+            py += kCmdDy[c];
+        }
+    }
+    s.num_cmds = (uint16_t)n;
+    s.show_dur = (uint8_t)choice(g, P.show_dur);
+    s.show_delay = (uint8_t)choice(g, P.show_delay);
+    s.vis_len = (uint16_t)(n * (s.show_dur + s.show_delay));
+    s.vis_base = 0;
+    s.vis_pos = 1;  // reset pops the first entry for its own frame
+    int first = cmds[0];
+    uint8_t glyph = s.show_dur > 0 ? (uint8_t)first : (uint8_t)9;
+    if (P.variant == V_ENDLESS) {
+        s.tx = (int8_t)mod6(nx + kCmdDx[first]);
+        s.ty = (int8_t)mod6(ny + kCmdDy[first]);
+    } else {
+        s.tx = (int8_t)(nx + kCmdDx[first]);
+        s.ty = (int8_t)(ny + kCmdDy[first]);
+    }
+    s.cur_cmd = 0;
+    s.cmd_steps = 0;
+    s.verify_step = 0;
+    s.total_completed = 0;
+    s.tiles_on = 0;
+    s.t = 0;
+    s.ep_len = 0;
+    s.ep_sum = 0.0;
+    s.expl_dur = (uint8_t)choice(g, P.expl_dur);
+    s.expl_delay = (uint8_t)choice(g, P.expl_delay);
+
+    // reset frame: blue arena, sprite 0 at the NEW agent position, first glyph
+    d.tmpl = 0;
+    d.sprite = 0;
+    d.sx = (int16_t)(cx - P.sprite_dim / 2);
+    d.sy = (int16_t)(cy - P.sprite_dim / 2);
+    d.glyph = glyph;
+    if (gt) {
+        gt[0] = (float)(s.tx / 5.0);
+        gt[1] = (float)(s.ty / 5.0);
+    }
+}
+
+struct MortarIO {
+    MortarState* state;
+    uint8_t* cmds;
+    RngSoA rng;
+    MortarDesc* desc;
+};
+
+__global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P, int n, MortarIO io, const int64_t* seeds,
+                                                           const uint8_t* mask, float* gt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    MortarDesc d;
+    d.pad[0] = d.pad[1] = 0;
+    if (mask && !mask[i]) {
+        d.sx = d.sy = 0;
+        d.tmpl = 0xFFFF;
+        d.sprite = d.glyph = 0xFF;
+        io.desc[i] = d;
+        return;
+    }
+    Pcg g;
+    if (seeds) g.seed((uint64_t)seeds[i]);
+    else g.load(io.rng, i);
+    MortarState s = io.state[i];
+    mortar_reset(P, s, g, io.cmds + (size_t)i * P.cmd_cap, d, gt ? gt + 2 * i : nullptr);
+    io.state[i] = s;
+    g.store(io.rng, i);
+    io.desc[i] = d;
+}
+
+__global__ __launch_bounds__(256) void mortar_init_kernel(int n, MortarState* state) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    MortarState s;
+    memset(&s, 0, sizeof(s));
+    s.disp_sprite = 0xFF;
+    state[i] = s;
+}
+
+__global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n, MortarIO io, const int32_t* actions,
+                                                          float* reward_out, uint8_t* done_out, float* gt,
+                                                          mg_info_buffers info, int autoreset) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    MortarState s = io.state[i];
+    uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
+    double reward = 0.0;
+    bool done = false;
+    int success = 0;
+    uint8_t glyph = 0xFF;
+    Pcg g;
+    bool rng_loaded = false;
+
+    if (s.vis_pos < s.vis_len) {
+        // display phase: pop the next schedule entry, agent frozen
+        int period = s.show_dur + s.show_delay;
+        int k = s.vis_pos / period, w = s.vis_pos % period;
+        glyph = (w < s.show_dur) ? cmds[s.vis_base + k] : (uint8_t)9;
+        s.vis_pos++;
+        if (P.variant != V_ENDLESS || s.disp_sprite == 0xFF) {
+            s.disp_sprite = 0;  // get_rotated_sprite(0) with the live agent's rect
+            s.disp_is_agent = 1;
+        }
+    } else {
+        int ax = s.ax, ay = s.ay;
+        if (P.variant == V_GRID) {
+            int a = actions[i];
+            int rot = s.rot8 * 45;
+            if (a == 1) rot = (rot + 90) % 360;
+            if (a == 2) rot = (rot + 270) % 360;
+            int gx = s.gx, gy = s.gy;
+            if (a == 3) {
+                int face = rot / 90;  // 0 N, 1 W, 2 S, 3 E
+                if (face == 0) { if (gy > 0) gy--; }
+                else if (face == 3) { if (gx < P.N - 1) gx++; }
+                else if (face == 2) { if (gy < P.N - 1) gy++; }
+                else { if (gx > 0) gx--; }
+                ax = P.arena_x0 + P.tile * gx + P.tile / 2;
+                ay = P.arena_x0 + P.tile * gy + P.tile / 2;
+            }
+            s.gx = (uint8_t)gx;
+            s.gy = (uint8_t)gy;
+            s.rot8 = (uint8_t)(rot / 45);
+        } else {
+            int a0 = actions[2 * i], a1 = actions[2 * i + 1];
+            int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
+            int rot = s.rot8 * 45;
+            if (a0 == 1) rot = 90;
+            if (a0 == 2) rot = 270;
+            if (a1 == 1) rot = 0;
+            if (a1 == 2) rot = 180;
+            if (dxs < 0 && dys < 0) rot = 45;
+            if (dxs < 0 && dys > 0) rot = 135;
+            if (dxs > 0 && dys < 0) rot = 315;
+            if (dxs > 0 && dys > 0) rot = 225;
+            s.rot8 = (uint8_t)(rot / 45);
+            bool diag = dxs != 0 && dys != 0;
+            if (P.variant == V_FREE) {
+                int v = diag ? P.v_diag_i : P.v_axis_i;
+                ax += dxs * v;
+                ay += dys * v;
+                int lo = P.arena_x0 + P.radius, hi = P.arena_x0 + P.tile * P.N - P.radius;
+                ax = ax > hi ? hi : ax;
+                ax = ax < lo ? lo : ax;
+                ay = ay > hi ? hi : ay;
+                ay = ay < lo ? lo : ay;
+            } else {
+                double v = diag ? P.v_diag : P.v_axis;
+                ax = round_haz((double)ax + dxs * v);
+                ay = round_haz((double)ay + dys * v);
+                // wrap once the centre passes the arena edge by radius * 0.5 (character_controller.py:269-281)
+                double left = P.arena_x0, right = P.arena_x0 + P.tile * P.N, off = P.radius * 0.5;
+                double x = ax, y = ay;
+                if (x > right + off) x = left - off;
+                if (x < left - off) x = right + off;
+                if (y > right + off) y = left - off;
+                if (y < left - off) y = right + off;
+                ax = round_haz(x);
+                ay = round_haz(y);
+            }
+        }
+        s.ax = (int16_t)ax;
+        s.ay = (int16_t)ay;
+        s.disp_sprite = s.rot8;
+        s.disp_is_agent = 1;
+        int nx = floordiv(ax - P.arena_x0, P.tile), ny = floordiv(ay - P.arena_x0, P.tile);
+        s.nx = (int8_t)nx;
+        s.ny = (int8_t)ny;
+        bool on_target = (nx == s.tx) && (ny == s.ty);
+
+        bool verify = (s.cmd_steps % s.expl_delay == 0) && s.cmd_steps > 0;
+        if (verify && !s.tiles_on) {
+            if (s.cur_cmd < s.num_cmds) {
+                s.cur_cmd++;
+                s.tiles_on = 1;
+                if (on_target) {
+                    reward += P.r_succ;
+                    if (P.variant == V_ENDLESS) {
+                        s.total_completed++;
+                        if (s.cur_cmd == s.num_cmds) reward += P.r_new;
+                    }
+                } else {
+                    done = true;
+                    reward += P.r_fail;
+                }
+            }
+            if (s.cur_cmd >= s.num_cmds) {
+                if (P.variant == V_ENDLESS) {
+                    g.load(io.rng, i);
+                    rng_loaded = true;
+                    int nc = g.integers(0, P.allowed);
+                    if (s.num_cmds < P.cmd_cap) {
+                        cmds[s.num_cmds] = (uint8_t)nc;
+                        s.vis_base = s.num_cmds;
+                        s.num_cmds++;
+                    } else {  // capacity reached (not reachable by any realistic policy): end the episode
+                        done = true;
+                        s.vis_base = (uint16_t)(s.num_cmds - 1);
+                    }
+                    s.cur_cmd = 0;
+                    s.verify_step = 0;
+                    s.vis_pos = 0;
+                    s.vis_len = (uint16_t)(s.show_dur + s.show_delay);
+                } else {
+                    done = true;
+                    success = 1;
+                    reward += P.r_ep_succ;
+                }
+            }
+            s.cmd_steps = 1;
+        }
+        if (s.tiles_on) {
+            if (s.verify_step % s.expl_dur == 0 && s.verify_step > 0) {
+                s.tiles_on = 0;
+                s.verify_step = 0;
+                if (s.cur_cmd < s.num_cmds) {
+                    int c = cmds[s.cur_cmd];
+                    if (P.variant == V_ENDLESS) {
+                        s.tx = (int8_t)mod6(s.tx + kCmdDx[c]);
+                        s.ty = (int8_t)mod6(s.ty + kCmdDy[c]);
+                    } else {
+                        s.tx = (int8_t)(s.tx + kCmdDx[c]);
+                        s.ty = (int8_t)(s.ty + kCmdDy[c]);
+                    }
+                }
+            } else {
+                if (!on_target) {
+                    done = true;
+                    reward = P.r_fail;  // overwrite (mortar_mayhem_grid.py:348)
+                }
+                s.verify_step++;
+            }
+        } else {
+            s.cmd_steps++;
+        }
+    }
+
+    if (P.variant == V_ENDLESS) {
+        s.t++;
+        if (s.t == P.max_steps) done = true;
+    }
+    s.ep_sum += reward;
+    s.ep_len++;
+
+    if (done) {
+        if (info.ep_reward_dev) info.ep_reward_dev[i] = s.ep_sum;
+        if (info.ep_length_dev) info.ep_length_dev[i] = s.ep_len;
+        if (P.variant == V_ENDLESS) {
+            if (info.aux_dev[0]) info.aux_dev[0][i] = (float)s.total_completed;
+            if (info.aux_dev[1]) info.aux_dev[1][i] = (float)(s.num_cmds > 1 ? s.num_cmds - 1 : 0);
+        } else {
+            if (info.aux_dev[0]) info.aux_dev[0][i] = (float)success;
+            if (info.aux_dev[1]) info.aux_dev[1][i] = (float)((double)((int)s.cur_cmd - 1 + success) / (double)s.num_cmds);
+        }
+    }
+    reward_out[i] = (float)reward;
+    done_out[i] = done ? 1 : 0;
+
+    MortarDesc d;
+    d.pad[0] = d.pad[1] = 0;
+    if (done && autoreset) {
+        if (!rng_loaded) g.load(io.rng, i);
+        rng_loaded = true;
+        mortar_reset(P, s, g, cmds, d, (gt && P.variant == V_ENDLESS) ? gt + 2 * i : nullptr);
+    } else {
+        int cx = s.disp_is_agent ? s.ax : s.disp_x, cy = s.disp_is_agent ? s.ay : s.disp_y;
+        d.sx = (int16_t)(cx - P.sprite_dim / 2);
+        d.sy = (int16_t)(cy - P.sprite_dim / 2);
+        d.sprite = s.disp_sprite;
+        d.glyph = glyph;
+        d.tmpl = (uint16_t)((s.tiles_on && P.visual_feedback) ? 1 + s.tx * P.N + s.ty : 0);
+        if (gt && P.variant == V_ENDLESS) {
+            gt[2 * i] = (float)(s.tx / 5.0);
+            gt[2 * i + 1] = (float)(s.ty / 5.0);
+        }
+    }
+    if (rng_loaded) g.store(io.rng, i);
+    io.state[i] = s;
+    io.desc[i] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Raster: one workgroup per instance; LDS-composed frame, 16-byte coalesced stores.
+// ---------------------------------------------------------------------------------------------------------
+struct MortarAtlas {
+    const uint8_t* templates;   // [(1+N*N)][84][84][3]
+    const uint8_t* sprites;     // [8][dim][dim] palette indices, stored [x][y] (column-major like the frame)
+    const uint8_t* glyphs;      // [10][gdim][gdim] stored [x][y], 0/1
+    int sprite_dim, glyph_box;  // glyph_box = allocated square per glyph
+    int glyph_dim[10];          // actual side of each glyph (22 or 31)
+    int glyph_x0;               // blit position (== y)
+    uint32_t palette[PAL_COUNT];  // 0x00BBGGRR byte order r,g,b in the low three bytes
+};
+
+__device__ __forceinline__ void put_px(uint8_t* frame, int x, int y, uint32_t rgb) {
+    uint8_t* p = frame + (x * SCREEN + y) * 3;
+    p[0] = (uint8_t)rgb;
+    p[1] = (uint8_t)(rgb >> 8);
+    p[2] = (uint8_t)(rgb >> 16);
+}
+
+__global__ __launch_bounds__(256) void mortar_raster_kernel(const MortarDesc* __restrict__ descs, MortarAtlas A,
+                                                            uint8_t* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t frame[];
+    const int env = blockIdx.x, tid = threadIdx.x;
+    const MortarDesc d = descs[env];
+    if (d.tmpl == 0xFFFF) return;
+
+    const uint4* src = reinterpret_cast<const uint4*>(A.templates + (size_t)d.tmpl * FRAME_BYTES);
+    uint4* lds = reinterpret_cast<uint4*>(frame);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int c = tid + k * 256;
+        if (c < FRAME_VEC16) lds[c] = src[c];
+    }
+    __syncthreads();
+
+    if (d.sprite != 0xFF) {
+        const int D = A.sprite_dim;
+        const uint8_t* sp = A.sprites + (int)d.sprite * D * D;
+        for (int p = tid; p < D * D; p += 256) {
+            int px = p / D, py = p - px * D;
+            uint8_t idx = sp[p];
+            int X = d.sx + px, Y = d.sy + py;
+            if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_px(frame, X, Y, A.palette[idx]);
+        }
+    }
+    if (d.glyph < 9) {  // 9 = blank glyph, 0xFF = none: nothing to draw
+        __syncthreads();
+        const int G = A.glyph_dim[d.glyph], B = A.glyph_box;
+        const uint8_t* gp = A.glyphs + (int)d.glyph * B * B;
+        for (int p = tid; p < G * G; p += 256) {
+            int px = p / G, py = p - px * G;
+            if (gp[px * B + py]) put_px(frame, A.glyph_x0 + px, A.glyph_x0 + py, 0x00FFFFFFu);
+        }
+    }
+    __syncthreads();
+
+    uint4* dst = reinterpret_cast<uint4*>(obs + (size_t)env * FRAME_BYTES);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int c = tid + k * 256;
+        if (c < FRAME_VEC16) dst[c] = lds[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------------------
+static const double SCALE = 0.25;  // the reference's module constant (e.g. mortar_mayhem_grid.py:13)
+
+class MortarFamily : public Family {
+   public:
+    MortarFamily(int variant, int n) : n_(n) {
+        memset(&P_, 0, sizeof(P_));
+        P_.variant = variant;
+        agent_scale_ = 1.0 * SCALE;
+        agent_speed_ = 12.0 * SCALE;
+        P_.N = variant == V_ENDLESS ? 6 : 5;
+        P_.allowed = variant == V_GRID ? 5 : 9;
+        P_.visual_feedback = 1;
+        P_.max_steps = -1;
+        P_.initial_count = 1;
+        P_.cmd_cap = variant == V_ENDLESS ? 512 : 32;
+        set_list(P_.command_count, {10});
+        set_list(P_.show_dur, {3});
+        set_list(P_.show_delay, {1});
+        set_list(P_.expl_dur, {variant == V_GRID ? 2 : 6});
+        set_list(P_.expl_delay, {variant == V_GRID ? 6 : 18});
+        P_.r_fail = 0.0;
+        P_.r_succ = 0.1;
+        P_.r_ep_succ = 0.0;
+        P_.r_new = 0.0;
+        state_.alloc(n);
+        cmds_.alloc((size_t)n * P_.cmd_cap);
+        desc_.alloc(n);
+        rng_s_hi_.alloc(n); rng_s_lo_.alloc(n); rng_i_hi_.alloc(n); rng_i_lo_.alloc(n); rng_buf_.alloc(n);
+        hipLaunchKernelGGL(mortar_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, state_.p);
+        MG_HIP(hipDeviceSynchronize());
+        rebuild();
+    }
+
+    int action_dim() const override { return P_.variant == V_GRID ? 1 : 2; }
+    int gt_dim() const override { return P_.variant == V_ENDLESS ? 2 : 0; }
+    const char* info_name(int k) const override {
+        if (P_.variant == V_ENDLESS) return k == 0 ? "commands_completed" : (k == 1 ? "max_command_sequence" : nullptr);
+        return k == 0 ? "success" : (k == 1 ? "commands_completed" : nullptr);
+    }
+
+    void set_option(const std::string& key, const double* v, int n) override {
+        const bool endless = P_.variant == V_ENDLESS;
+        auto scalar_i = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
+        auto list = [&](OptList& l, int lo, int hi) {
+            if (n < 1 || n > 8) throw OptionError{-3, "option " + key + ": lists of 1..8 values are supported"};
+            l.n = n;
+            for (int i = 0; i < n; ++i) {
+                l.v[i] = to_int_checked(v[i], key.c_str());
+                if (l.v[i] < lo || l.v[i] > hi)
+                    throw OptionError{-3, "option " + key + ": value out of the supported range"};
+            }
+        };
+        if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
+        else if (key == "allowed_commands") {
+            int a = to_int_checked(v[0], key.c_str());
+            if (a < 4 || a > 9) throw OptionError{-4, "assert 4 <= allowed_commands <= 9"};
+            P_.allowed = a;
+        }
+        else if (key == "command_show_duration") list(P_.show_dur, 1, 100);
+        else if (key == "command_show_delay") list(P_.show_delay, 0, 100);
+        else if (key == "explosion_duration") list(P_.expl_dur, 1, 200);
+        else if (key == "explosion_delay") list(P_.expl_delay, 1, 200);
+        else if (key == "visual_feedback") P_.visual_feedback = v[0] != 0.0;
+        else if (key == "reward_command_failure") P_.r_fail = v[0];
+        else if (key == "reward_command_success") P_.r_succ = v[0];
+        else if (endless && key == "max_steps") scalar_i(P_.max_steps);
+        else if (endless && key == "initial_command_count") {
+            int c = to_int_checked(v[0], key.c_str());
+            if (c < 1 || c > P_.cmd_cap / 2) throw OptionError{-3, "initial_command_count out of the supported range"};
+            P_.initial_count = c;
+        }
+        else if (endless && key == "reward_new_command_success") P_.r_new = v[0];
+        else if (!endless && key == "arena_size") {
+            int a = to_int_checked(v[0], key.c_str());
+            if (a < 2 || a > 6) throw OptionError{-4, "assert 2 <= arena_size <= 6"};
+            P_.N = a;
+            dirty_ = true;
+        }
+        else if (!endless && key == "command_count") list(P_.command_count, 1, P_.cmd_cap);
+        else if (!endless && key == "reward_episode_success") P_.r_ep_succ = v[0];
+        else if (P_.variant != V_GRID && key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
+        else throw OptionError{-2, "unknown reset parameter " + key};
+    }
+
+    void reset(const int64_t* seeds, const uint8_t* mask, uint8_t* obs, float* gt, hipStream_t s) override {
+        if (dirty_) rebuild();
+        if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
+        if (seeds) seeded_ = true;  // with a mask the caller is responsible for having seeded the other instances
+        hipLaunchKernelGGL(mortar_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), seeds, mask,
+                           gt_dim() ? gt : nullptr);
+        raster(obs, s);
+    }
+
+    void step(const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,
+              int autoreset, hipStream_t s) override {
+        if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next step");
+        mg_info_buffers ib;
+        memset(&ib, 0, sizeof(ib));
+        if (info) ib = *info;
+        prof.begin(0, s);
+        hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), actions, reward, done,
+                           gt_dim() ? gt : nullptr, ib, autoreset);
+        prof.end(0, s);
+        prof.begin(1, s);
+        raster(obs, s);
+        prof.end(1, s);
+    }
+
+    std::vector<std::pair<void*, size_t>> state_blobs() override {
+        return {{state_.p, state_.bytes()}, {cmds_.p, cmds_.bytes()},       {rng_s_hi_.p, rng_s_hi_.bytes()},
+                {rng_s_lo_.p, rng_s_lo_.bytes()}, {rng_i_hi_.p, rng_i_hi_.bytes()}, {rng_i_lo_.p, rng_i_lo_.bytes()},
+                {rng_buf_.p, rng_buf_.bytes()}};
+    }
+
+    void debug_rng(int i, uint64_t out[6]) override {
+        uint64_t b;
+        MG_HIP(hipMemcpy(&out[0], rng_s_hi_.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&out[1], rng_s_lo_.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&out[2], rng_i_hi_.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&out[3], rng_i_lo_.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&b, rng_buf_.p + i, 8, hipMemcpyDeviceToHost));
+        out[4] = (b >> 32) & 1;
+        out[5] = b & 0xFFFFFFFFull;
+    }
+
+   private:
+    static void set_list(OptList& l, std::initializer_list<int> v) {
+        l.n = 0;
+        for (int x : v) l.v[l.n++] = x;
+    }
+    MortarIO io() {
+        MortarIO o;
+        o.state = state_.p;
+        o.cmds = cmds_.p;
+        o.rng = RngSoA{rng_s_hi_.p, rng_s_lo_.p, rng_i_hi_.p, rng_i_lo_.p, rng_buf_.p};
+        o.desc = desc_.p;
+        return o;
+    }
+
+    // (re)build geometry-dependent constants, atlases and templates
+    void rebuild() {
+        int radius = 0;
+        std::vector<Stamp> sprites = build_agent_sprites(agent_scale_, &radius);
+        std::vector<Stamp> glyphs = build_glyphs(SCALE);
+        P_.tile = (int)(56 * SCALE);
+        P_.arena_x0 = SCREEN / 2 - ((P_.tile * P_.N) >> 1);
+        P_.radius = radius;
+        P_.sprite_dim = sprites[0].w;
+        double inv = 1.0 / std::sqrt(2.0);
+        P_.v_axis = (1.0 / 1.0) * agent_speed_;
+        P_.v_diag = inv * agent_speed_;
+        P_.v_axis_i = (int)P_.v_axis;
+        P_.v_diag_i = (int)P_.v_diag;
+        P_.off_lo = (int)(-8 * SCALE);
+        P_.off_hi = (int)(8 * SCALE);
+
+        int D = P_.sprite_dim;
+        std::vector<uint8_t> sp((size_t)8 * D * D);
+        for (int k = 0; k < 8; ++k)
+            for (int x = 0; x < D; ++x)
+                for (int y = 0; y < D; ++y) sp[(size_t)k * D * D + x * D + y] = sprites[k].get(x, y);
+        int B = 0;
+        for (auto& g : glyphs) B = std::max(B, std::max(g.w, g.h));
+        std::vector<uint8_t> gl((size_t)10 * B * B, 0);
+        for (int k = 0; k < 10; ++k) {
+            A_.glyph_dim[k] = glyphs[k].w;
+            for (int x = 0; x < glyphs[k].w; ++x)
+                for (int y = 0; y < glyphs[k].h; ++y) gl[(size_t)k * B * B + x * B + y] = glyphs[k].get(x, y) ? 1 : 0;
+        }
+        sprites_dev_.upload(sp);
+        glyphs_dev_.upload(gl);
+        templates_dev_.upload(build_mortar_templates(P_.N, SCALE, SCREEN));
+        A_.templates = templates_dev_.p;
+        A_.sprites = sprites_dev_.p;
+        A_.glyphs = glyphs_dev_.p;
+        A_.sprite_dim = D;
+        A_.glyph_box = B;
+        A_.glyph_x0 = (int)((SCREEN / 2) - std::floor(88 * SCALE / 2));
+        for (int k = 0; k < PAL_COUNT; ++k)
+            A_.palette[k] = (uint32_t)PALETTE_RGB[k][0] | ((uint32_t)PALETTE_RGB[k][1] << 8) | ((uint32_t)PALETTE_RGB[k][2] << 16);
+        dirty_ = false;
+    }
+
+    void raster(uint8_t* obs, hipStream_t s) {
+        hipLaunchKernelGGL(mortar_raster_kernel, dim3(n_), dim3(256), FRAME_BYTES, s, desc_.p, A_, obs);
+        MG_HIP(hipGetLastError());
+    }
+
+    int n_;
+    MortarParams P_;
+    MortarAtlas A_;
+    double agent_scale_, agent_speed_;
+    bool dirty_ = true, seeded_ = false;
+    DevArray<MortarState> state_;
+    DevArray<uint8_t> cmds_;
+    DevArray<MortarDesc> desc_;
+    DevArray<uint64_t> rng_s_hi_, rng_s_lo_, rng_i_hi_, rng_i_lo_, rng_buf_;
+    DevArray<uint8_t> sprites_dev_, glyphs_dev_, templates_dev_;
+};
+
+Family* make_mortar(int variant, int num_envs) { return new MortarFamily(variant, num_envs); }
+
+}  // namespace mg

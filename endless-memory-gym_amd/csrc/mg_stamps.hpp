@@ -1,0 +1,274 @@
+// mg_stamps.hpp -- host-side builder of the palette-indexed stamp atlases and background templates
+// that the raster kernels sample.  Runs once in mg_create(); nothing here is on the per-step path.
+//
+// What is produced (all geometry at the reference's module constant SCALE = 0.25, 84x84 screen):
+//   * agent sprites: 8 rotations (character_controller.py:29-75 create_character_sprites)
+//   * command glyphs: 9 commands + blank (pygame_assets.py:254-304 Command)
+//   * mortar arena templates (pygame_assets.py:306-418 MortarTile/MortarArena) as full frames in the
+//     observation layout [x][y][c]
+// The integer rasterisation rules (even-diameter discs, one-axis thick lines, 16.16 fixed-point rotation)
+// are those of pygame 2.4 / SDL2 which the reference renders with; parity is enforced by the tests
+// against the CPU oracle and, through it, against the reference's GIF recordings.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+namespace mg {
+
+// A small indexed image; 0 = transparent (colour key).
+struct Stamp {
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;
+    Stamp() {}
+    Stamp(int w_, int h_) : w(w_), h(h_), px((size_t)w_ * h_, 0) {}
+    uint8_t& at(int x, int y) { return px[(size_t)y * w + x]; }
+    uint8_t get(int x, int y) const { return px[(size_t)y * w + x]; }
+    void span(int xa, int y, int xb, uint8_t v) {  // inclusive, clipped, order-free
+        if (y < 0 || y >= h) return;
+        if (xb < xa) std::swap(xa, xb);
+        if (xa < 0) xa = 0;
+        if (xb > w - 1) xb = w - 1;
+        for (int x = xa; x <= xb; ++x) at(x, y) = v;
+    }
+    void vspan(int ya, int x, int yb, uint8_t v) {
+        if (x < 0 || x >= w) return;
+        if (ya < 0) ya = 0;
+        if (yb > h - 1) yb = h - 1;
+        for (int y = ya; y <= yb; ++y) at(x, y) = v;
+    }
+};
+
+// Filled disc with pygame's even-diameter midpoint rule: covers columns x0-r .. x0+r-1.
+inline void disc(Stamp& s, int x0, int y0, int r, uint8_t v) {
+    if (r < 1) return;
+    int f = 1 - r, ddx = 0, ddy = -2 * r, x = 0, y = r;
+    while (x < y) {
+        if (f >= 0) { --y; ddy += 2; f += ddy; }
+        ++x; ddx += 2; f += ddx + 1;
+        if (f >= 0) {
+            s.span(x0 - x, y0 + y - 1, x0 + x - 1, v);
+            s.span(x0 - x, y0 - y, x0 + x - 1, v);
+        }
+        s.span(x0 - y, y0 + x - 1, x0 + y - 1, v);
+        s.span(x0 - y, y0 - x, x0 + y - 1, v);
+    }
+}
+
+// Ring of thickness t (1 < t < r): outer and inner midpoint ellipses walked together.
+inline void ring(Stamp& s, int x0, int y0, int r, int t, uint8_t v) {
+    using ll = long long;
+    ll x = 0, y = r, r2 = (ll)r * r, D = 2 * r2, dx = 0, dy = D * y;
+    double d1 = r2 * (1.25 - r);
+    bool solid = true;
+    ll ri = r - t + 1, xi = 0, yi = ri, ri2 = ri * ri, Di = 2 * ri2, dxi = 0, dyi = Di * yi;
+    double d1i = ri2 * (1.25 - ri), d2i = 0;
+    auto emit = [&]() {
+        if (solid) {
+            s.span(x0 - (int)x, y0 - (int)y, x0 + (int)x - 1, v);
+            s.span(x0 - (int)x, y0 + (int)y - 1, x0 + (int)x - 1, v);
+        } else {
+            s.span(x0 - (int)x, y0 - (int)y, x0 - (int)xi, v);
+            s.span(x0 - (int)x, y0 + (int)y - 1, x0 - (int)xi, v);
+            s.span(x0 + (int)xi - 1, y0 - (int)y, x0 + (int)x - 1, v);
+            s.span(x0 + (int)xi - 1, y0 + (int)y - 1, x0 + (int)x - 1, v);
+        }
+    };
+    auto inner_region1 = [&]() {
+        while (d1i < 0) { ++xi; dxi += Di; d1i += dxi + ri2; }
+        ++xi; --yi; dxi += Di; dyi -= Di; d1i += dxi - dyi + ri2;
+    };
+    while (dx < dy) {
+        while (d1 < 0) { ++x; dx += D; d1 += dx + r2; }
+        emit();
+        ++x; --y; dx += D; dy -= D; d1 += dx - dy + r2;
+        if (solid && y < ri) solid = false;
+        if (!solid) inner_region1();
+    }
+    d1 = r2 * ((x + 0.5) * (x + 0.5) + (y - 1) * (y - 1) - r2);
+    while (y >= 0) {
+        emit();
+        if (d1 > 0) { --y; dy -= D; d1 += r2 - dy; }
+        else { --y; ++x; dx += D; dy -= D; d1 += dx - dy + r2; }
+        if (solid && y < ri) solid = false;
+        if (!solid) {
+            if (dxi < dyi) inner_region1();
+            else {
+                if (!d2i) d2i = ri2 * ((xi + 0.5) * (xi + 0.5) + (yi - 1) * (yi - 1) - ri2);
+                if (d2i > 0) { --yi; dyi -= Di; d2i += ri2 - dyi; }
+                else { --yi; ++xi; dxi += Di; dyi -= Di; d2i += dxi - dyi + ri2; }
+            }
+        }
+    }
+}
+
+inline void circle(Stamp& s, int x0, int y0, int r, int width, uint8_t v) {
+    if (r < 1 || width < 0) return;
+    if (width > r) width = r;
+    if (width == 0 || width == r) disc(s, x0, y0, r, v);
+    else ring(s, x0, y0, r, width, v);
+}
+
+// Thick line (width >= 2; the hot path never draws 1-px lines): Bresenham centre line, thickness grown
+// along the minor axis only, flat ends.
+inline void thick_line(Stamp& s, int x1, int y1, int x2, int y2, int width, uint8_t v) {
+    if (width < 1) return;
+    int extra = 1 - (width % 2), half = width / 2;
+    bool grow_x = std::abs(x1 - x2) <= std::abs(y1 - y2);
+    int dx = std::abs(x2 - x1), sx = x1 < x2 ? 1 : -1, dy = std::abs(y2 - y1), sy = y1 < y2 ? 1 : -1;
+    int err = (dx > dy ? dx : -dy) / 2;
+    auto advance = [&]() {
+        int e2 = err;
+        if (e2 > -dx) { err -= dy; x1 += sx; }
+        if (e2 < dy) { err += dx; y1 += sy; }
+    };
+    if (grow_x) {
+        while (y1 != y2 + sy) {
+            int a = x1 - half + extra, b = x1 + half;
+            if (a <= b && y1 >= 0 && y1 < s.h) s.span(std::max(a, 0), y1, std::min(b, s.w - 1), v);
+            advance();
+        }
+    } else {
+        while (x1 != x2 + sx) {
+            int a = y1 - half + extra, b = y1 + half;
+            if (a <= b && x1 >= 0 && x1 < s.w) s.vspan(a, x1, b, v);
+            advance();
+        }
+    }
+}
+
+// Counter-clockwise rotation: exact quarter turns, otherwise inverse nearest-neighbour in 16.16 fixed point.
+inline Stamp rotate_ccw(const Stamp& src, int angle) {
+    if (angle % 90 == 0) {
+        int k = ((angle / 90) % 4 + 4) % 4;
+        Stamp d(k % 2 ? src.h : src.w, k % 2 ? src.w : src.h);
+        for (int y = 0; y < d.h; ++y)
+            for (int x = 0; x < d.w; ++x) {
+                int sx, sy;
+                if (k == 0) { sx = x; sy = y; }
+                else if (k == 1) { sx = src.w - 1 - y; sy = x; }
+                else if (k == 2) { sx = src.w - 1 - x; sy = src.h - 1 - y; }
+                else { sx = y; sy = src.h - 1 - x; }
+                d.at(x, y) = src.get(sx, sy);
+            }
+        return d;
+    }
+    double rad = angle * .01745329251994329, sa = std::sin(rad), ca = std::cos(rad);
+    double cx = ca * src.w, cy = ca * src.h, sx = sa * src.w, sy = sa * src.h;
+    int nx = (int)std::fmax(std::fmax(std::fmax(std::fabs(cx + sy), std::fabs(cx - sy)), std::fabs(-cx + sy)), std::fabs(-cx - sy));
+    int ny = (int)std::fmax(std::fmax(std::fmax(std::fabs(sx + cy), std::fabs(sx - cy)), std::fabs(-sx + cy)), std::fabs(-sx - cy));
+    Stamp d(nx, ny);
+    int mid = ny / 2, xd = (src.w - nx) << 15, yd = (src.h - ny) << 15;
+    int isin = (int)(sa * 65536), icos = (int)(ca * 65536);
+    int ax = (nx << 15) - (int)(ca * ((nx - 1) << 15));
+    int ay = (ny << 15) - (int)(sa * ((nx - 1) << 15));
+    int xmax = (src.w << 16) - 1, ymax = (src.h << 16) - 1;
+    for (int y = 0; y < ny; ++y) {
+        int fx = ax + isin * (mid - y) + xd, fy = ay - icos * (mid - y) + yd;
+        for (int x = 0; x < nx; ++x, fx += icos, fy += isin)
+            d.at(x, y) = (fx < 0 || fy < 0 || fx > xmax || fy > ymax) ? 0 : src.get(fx >> 16, fy >> 16);
+    }
+    return d;
+}
+
+// pygame Vector2.rotate: multiples of 90 degrees are exact, else plain cos/sin in double.
+inline void rotate_vec(double x, double y, double deg, double& ox, double& oy) {
+    const double eps = 1e-6;
+    deg = std::fmod(deg, 360.0);
+    if (deg < 0) deg += 360.0;
+    if (std::fmod(deg + eps, 90.0) < 2 * eps) {
+        switch ((int)((deg + eps) / 90.0)) {
+            case 1: ox = -y; oy = x; break;
+            case 2: ox = -x; oy = -y; break;
+            case 3: ox = y; oy = -x; break;
+            default: ox = x; oy = y; break;
+        }
+    } else {
+        double rad = deg * M_PI / 180.0, s = std::sin(rad), c = std::cos(rad);
+        ox = c * x - s * y;
+        oy = s * x + c * y;
+    }
+}
+
+enum : uint8_t { PAL_KEY = 0, PAL_BODY = 1, PAL_HAND = 2, PAL_OUTLINE = 3, PAL_WHITE = 4, PAL_RED = 5, PAL_COUNT = 8 };
+static const uint8_t PALETTE_RGB[PAL_COUNT][3] = {
+    {0, 0, 0}, {250, 204, 153}, {250, 250, 250}, {50, 50, 50}, {255, 255, 255}, {255, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+
+// 8 agent sprites; sprite k shows rotation 45k degrees (the hands are rotated by 360-45k about the centre).
+inline std::vector<Stamp> build_agent_sprites(double agent_scale, int* radius_out) {
+    int radius = (int)(25 * agent_scale);
+    int hands_x = (int)(18 * agent_scale), hand_y = (int)(12 * agent_scale);
+    int hand_r = (int)(10 * agent_scale), outline = (int)(3 * agent_scale);
+    const int extension = 14;
+    int dim = radius * 2 + hand_r + extension, c = dim / 2;
+    std::vector<Stamp> out;
+    for (int k = 0; k < 8; ++k) {
+        Stamp s(dim, dim);
+        disc(s, c, c, radius, PAL_BODY);
+        double lx, ly, rx, ry;
+        rotate_vec(-hands_x, hand_y + extension / 2 - c, 360 - 45 * k, lx, ly);
+        rotate_vec(hands_x, hand_y + extension / 2 - c, 360 - 45 * k, rx, ry);
+        int lxi = (int)(lx + c), lyi = (int)(ly + c), rxi = (int)(rx + c), ryi = (int)(ry + c);
+        circle(s, lxi, lyi, hand_r, 0, PAL_HAND);
+        circle(s, rxi, ryi, hand_r, 0, PAL_HAND);
+        circle(s, lxi, lyi, hand_r, outline, PAL_OUTLINE);
+        circle(s, rxi, ryi, hand_r, outline, PAL_OUTLINE);
+        out.push_back(s);
+    }
+    if (radius_out) *radius_out = radius;
+    return out;
+}
+
+// 10 glyphs: Command.COMMANDS order right, down, left, up, stay, right_down, right_up, left_down, left_up; 9 = blank.
+inline std::vector<Stamp> build_glyphs(double scale) {
+    static const int ANGLE[9] = {0, 270, 180, 90, 0, 315, 45, 225, 135};
+    double rect_dim = 88 * scale;
+    int dim = (int)rect_dim, lw = (int)(8 * scale);
+    std::vector<Stamp> out;
+    for (int g = 0; g < 10; ++g) {
+        Stamp s(dim, dim);
+        if (g == 4) {
+            double radius = std::floor(rect_dim / 2) - 4 * scale;
+            double x = rect_dim - 12 * scale, y = std::floor(rect_dim / 2) - 8 * scale;
+            circle(s, (int)radius, (int)radius, (int)radius, lw, PAL_WHITE);
+            thick_line(s, 0, (int)y, (int)x, (int)y, lw, PAL_WHITE);
+        } else if (g < 9) {
+            int x1 = (int)(2 * scale), x2 = (int)(80 * scale), y1 = (int)(40 * scale);
+            thick_line(s, x1, y1, x2, y1, lw, PAL_WHITE);
+            thick_line(s, x2, y1, y1, 0, lw, PAL_WHITE);
+            thick_line(s, x2, y1, y1, x2, lw, PAL_WHITE);
+            s = rotate_ccw(s, ANGLE[g]);
+        }
+        out.push_back(s);
+    }
+    return out;
+}
+
+// Mortar arena frame templates in observation layout [x][y][c]; template 0 = all tiles blue,
+// template 1 + tx*N + ty = every tile red except (tx,ty).  Returns (1+N*N) * 84*84*3 bytes.
+inline std::vector<uint8_t> build_mortar_templates(int N, double scale, int screen) {
+    const uint8_t BLUE[3] = {21, 43, 77}, LBLUE[3] = {29, 60, 107}, RED[3] = {81, 18, 26}, LRED[3] = {112, 24, 36};
+    int tile = (int)(56 * scale), border = (int)(4 * scale), arena = tile * N;
+    int x0 = screen / 2 - (arena >> 1), y0 = x0;
+    size_t frame = (size_t)screen * screen * 3;
+    std::vector<uint8_t> out((size_t)(1 + N * N) * frame, 0);
+    for (int t = 0; t < 1 + N * N; ++t) {
+        int tx = t == 0 ? -1 : (t - 1) / N, ty = t == 0 ? -1 : (t - 1) % N;
+        uint8_t* f = out.data() + (size_t)t * frame;
+        for (int x = 0; x < screen; ++x)
+            for (int y = 0; y < screen; ++y) {
+                int ax = x - x0, ay = y - y0;
+                if (ax < 0 || ay < 0 || ax >= arena || ay >= arena) continue;
+                int i = ax / tile, j = ay / tile, u = ax % tile, v = ay % tile;
+                bool edge = (border * 2 < tile) ? (u < border || v < border || u >= tile - border || v >= tile - border) : true;
+                bool red = t != 0 && !(i == tx && j == ty);
+                const uint8_t* c = red ? (edge ? LRED : RED) : (edge ? LBLUE : BLUE);
+                uint8_t* p = f + ((size_t)x * screen + y) * 3;
+                p[0] = c[0]; p[1] = c[1]; p[2] = c[2];
+            }
+    }
+    return out;
+}
+
+}  // namespace mg

@@ -1,0 +1,39 @@
+"""memory_gym_amd -- MI355X-native batched Memory Gym (hot path of MarcoMeter/endless-memory-gym).
+
+Same environment ids and reset-options dictionaries as the reference (memory_gym/__init__.py:13-61):
+
+    import memory_gym_amd as memory_gym
+    env = memory_gym.make("MortarMayhem-Grid-v0", num_envs=65536)     # batched, tensors on the GPU
+    env = memory_gym.make("MortarMayhem-Grid-v0")                      # num_envs=1: reference-shaped numpy API
+
+If gymnasium is installed on the host the ids are also registered there (gymnasium.make(id) returns the
+single-instance adapter), mirroring the reference's registration side effect on import.
+"""
+from .reset_params import DEFAULTS, process_reset_params  # noqa: F401
+from .vec_env import ENV_IDS, MemoryGymEnv, VecMemoryGym  # noqa: F401
+
+NOT_IN_SCOPE = ["MysteryPath-Grid-v0", "MortarMayhemB-v0", "MortarMayhemB-Grid-v0"]
+
+
+def make(env_id, num_envs=None, device=None, render_mode=None):
+    if env_id in NOT_IN_SCOPE:
+        raise NotImplementedError(env_id + " is outside the accelerated hot path (see DESIGN.md)")
+    if num_envs is None:
+        return MemoryGymEnv(env_id, device=device, render_mode=render_mode)
+    return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode)
+
+
+def _register_with_gymnasium():
+    try:
+        from gymnasium.envs.registration import register
+    except Exception:
+        return
+    for env_id in ENV_IDS:
+        try:
+            register(id=env_id, entry_point=lambda _id=env_id, **kw: MemoryGymEnv(_id, **kw), disable_env_checker=True,
+                     order_enforce=False)
+        except Exception:
+            pass
+
+
+_register_with_gymnasium()

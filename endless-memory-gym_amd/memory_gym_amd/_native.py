@@ -1,0 +1,61 @@
+"""ctypes binding of libmemgym_hip.so (C ABI: include/memgym.h).
+
+The HIP library is the product: there is NO CPU or PyTorch fallback -- if the shared object is missing or does
+not load, importing this module raises.  `import torch` happens first on purpose: torch ships its own
+libamdhip64.so.7 and the dynamic loader must resolve our DT_NEEDED entry to that already-loaded runtime so that
+device pointers and streams are shared with torch tensors.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before the native library, see above)
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("MEMGYM_HIP_LIB", os.path.join(PKG_ROOT, "lib", "libmemgym_hip.so"))
+
+MG_INFO_SLOTS = 8
+
+
+class InfoBuffers(C.Structure):
+    _fields_ = [("ep_reward_dev", C.c_void_p), ("ep_length_dev", C.c_void_p), ("aux_dev", C.c_void_p * MG_INFO_SLOTS)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "memory_gym_amd: native library %s not found. Build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.mg_last_error.restype = C.c_char_p
+    L.mg_create.argtypes = [C.c_char_p, C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
+    L.mg_destroy.argtypes = [C.c_void_p]
+    L.mg_destroy.restype = None
+    for f in ("mg_num_envs", "mg_action_dim", "mg_gt_dim"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_int32
+    L.mg_info_name.argtypes = [C.c_void_p, C.c_int]
+    L.mg_info_name.restype = C.c_char_p
+    L.mg_set_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]
+    L.mg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
+                          C.c_int, C.c_void_p]
+    L.mg_state_size.argtypes = [C.c_void_p]
+    L.mg_state_size.restype = C.c_size_t
+    L.mg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mg_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.mg_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    return L
+
+
+LIB = _load()
+
+
+def last_error():
+    return (LIB.mg_last_error() or b"").decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))

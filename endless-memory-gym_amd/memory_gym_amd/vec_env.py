@@ -1,0 +1,247 @@
+"""Batched, device-resident Memory Gym environments behind the reference's env ids and reset-options dict.
+
+`VecMemoryGym(env_id, num_envs, device)` holds `num_envs` independent instances of one of the reference's
+environments (memory_gym/__init__.py:13-61) on one MI355X.  reset()/step() enqueue HIP kernels on torch's current
+stream and return torch tensors that alias the kernels' output buffers (no copies, no host synchronisation):
+
+    obs      uint8  [N, 84, 84, 3]  indexed [env][x][y][c], exactly the reference's array3d layout
+    reward   float32 [N]
+    done     bool   [N]             (`truncation` is always False in the reference)
+    info     dict of tensors: "done_mask", end-of-episode records ("reward", "length", "success", ...) that are valid
+             where done_mask is set, and "ground_truth" [N, G] for the endless envs.
+
+`MemoryGymEnv` is the num_envs == 1 adapter with the reference's exact single-instance signature
+(numpy obs, Python float reward, bool done, False, dict info).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from .reset_params import DEFAULTS, calc_max_episode_steps, process_reset_params
+
+ENV_IDS = list(DEFAULTS.keys())
+
+
+class _Space:
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+    def __repr__(self):
+        return "%s(%s)" % (self.kind, ", ".join("%s=%r" % kv for kv in self.__dict__.items() if kv[0] != "kind"))
+
+
+def _spaces(action_dim, gt_dim):
+    try:  # use real gymnasium spaces when the host has them
+        from gymnasium import spaces
+        act = spaces.Discrete(4) if action_dim == 1 else spaces.MultiDiscrete([3, 3])
+        obs = spaces.Box(low=0, high=255, shape=[84, 84, 3], dtype=np.uint8)
+        gt = None if gt_dim == 0 else spaces.Box(low=np.zeros(gt_dim, np.float32), high=np.ones(gt_dim, np.float32),
+                                                  shape=(gt_dim,), dtype=np.float32)
+    except Exception:
+        act = _Space("Discrete", n=4) if action_dim == 1 else _Space("MultiDiscrete", nvec=[3, 3])
+        obs = _Space("Box", low=0, high=255, shape=[84, 84, 3], dtype=np.uint8)
+        gt = None if gt_dim == 0 else _Space("Box", low=0.0, high=1.0, shape=(gt_dim,), dtype=np.float32)
+    return act, obs, gt
+
+
+class VecMemoryGym:
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
+
+    def __init__(self, env_id, num_envs=1, device=None, render_mode=None):
+        if env_id not in DEFAULTS:
+            raise ValueError("unknown env id %r" % (env_id,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("memory_gym_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
+        self.env_id = env_id
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   (device if isinstance(device, int) else torch.device(device).index or 0))
+        self.render_mode = render_mode
+        h = C.c_void_p()
+        _native.check(_native.LIB.mg_create(env_id.encode(), self.num_envs, self.device.index, C.byref(h)), "mg_create")
+        self._h = h
+        self.action_dim = _native.LIB.mg_action_dim(h)
+        self.gt_dim = _native.LIB.mg_gt_dim(h)
+        self.has_ground_truth_info = self.gt_dim > 0
+        self.action_space, self.observation_space, self.ground_truth_space = _spaces(self.action_dim, self.gt_dim)
+        N, dev = self.num_envs, self.device
+        self.obs = torch.empty((N, 84, 84, 3), dtype=torch.uint8, device=dev)
+        self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.done_u8 = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.gt = torch.zeros((N, max(self.gt_dim, 1)), dtype=torch.float32, device=dev)
+        self.ep_reward = torch.zeros(N, dtype=torch.float64, device=dev)
+        self.ep_length = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.info_names = []
+        for k in range(_native.MG_INFO_SLOTS):
+            nm = _native.LIB.mg_info_name(h, k)
+            if nm is None:
+                break
+            self.info_names.append(nm.decode())
+        self.aux = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in self.info_names]
+        self._info = _native.InfoBuffers()
+        self._info.ep_reward_dev = self.ep_reward.data_ptr()
+        self._info.ep_length_dev = self.ep_length.data_ptr()
+        for k, t in enumerate(self.aux):
+            self._info.aux_dev[k] = t.data_ptr()
+        self.reset_params = process_reset_params(env_id, None)
+        self._applied = dict(DEFAULTS[env_id])
+        self.max_episode_steps = None
+        self.autoreset = True
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _apply_options(self, options):
+        params = process_reset_params(self.env_id, options)
+        for k, v in params.items():
+            if self._applied.get(k, None) == v and k in self._applied:
+                continue
+            vals = [float(x) for x in v] if isinstance(v, (list, tuple, np.ndarray)) else [float(v)]
+            arr = (C.c_double * len(vals))(*vals)
+            rc = _native.LIB.mg_set_option(self._h, k.encode(), arr, len(vals))
+            if rc == -2:
+                raise AssertionError("Provided reset parameter (" + str(k) + ") is not valid. Check spelling.")
+            if rc == -4:
+                raise AssertionError(_native.last_error())
+            if rc != 0:
+                raise NotImplementedError("reset parameter %s=%r: %s" % (k, v, _native.last_error()))
+            self._applied[k] = v
+        self.reset_params = params
+        if self.env_id in ("MortarMayhem-Grid-v0", "MortarMayhem-v0"):
+            self.max_episode_steps = calc_max_episode_steps(
+                max(params["command_count"]), max(params["command_show_duration"]), max(params["command_show_delay"]),
+                max(params["explosion_delay"]), max(params["explosion_duration"]))
+        else:
+            self.max_episode_steps = params.get("max_steps", None)
+
+    def _seed_tensor(self, seed):
+        if seed is None:
+            return None
+        if isinstance(seed, torch.Tensor):
+            s = seed.to(device=self.device, dtype=torch.int64)
+        elif np.isscalar(seed):
+            # one integer seeds instance i with seed + i (instance 0 == the reference's reset(seed=seed))
+            s = torch.arange(self.num_envs, device=self.device, dtype=torch.int64) + int(seed)
+        else:
+            s = torch.as_tensor(np.asarray(seed, dtype=np.int64), device=self.device)
+        assert s.numel() == self.num_envs
+        return s.contiguous()
+
+    # ------------------------------------------------------------------ API
+    def reset(self, seed=None, return_info=True, options=None, mask=None):
+        """Env.reset(seed, options) for all instances (or those selected by the bool/uint8 tensor `mask`)."""
+        with torch.cuda.device(self.device):
+            self._apply_options(options)
+            s = self._seed_tensor(seed)
+            m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            _native.check(_native.LIB.mg_reset(self._h, None if s is None else s.data_ptr(),
+                                               None if m is None else m.data_ptr(), self.obs.data_ptr(),
+                                               self.gt.data_ptr() if self.gt_dim else None, self._stream()), "mg_reset")
+        info = {"ground_truth": self.gt} if self.gt_dim else {}
+        return self.obs, info
+
+    def step(self, actions):
+        with torch.cuda.device(self.device):
+            a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+            assert a.numel() == self.num_envs * self.action_dim, "actions must have shape [N] or [N, 2]"
+            _native.check(_native.LIB.mg_step(self._h, a.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                              self.done_u8.data_ptr(), self.gt.data_ptr() if self.gt_dim else None,
+                                              C.byref(self._info), int(self.autoreset), self._stream()), "mg_step")
+        done = self.done_u8.view(torch.bool)
+        info = {"done_mask": done, "reward": self.ep_reward, "length": self.ep_length}
+        for nm, t in zip(self.info_names, self.aux):
+            info[nm] = t
+        if self.gt_dim:
+            info["ground_truth"] = self.gt
+        return self.obs, self.reward, done, torch.zeros_like(done), info
+
+    def render(self):
+        """rgb_array mode of the reference: fliplr(rot90(obs, 3)) == transpose to [y][x][c] (mortar_mayhem_grid.py:401-402)."""
+        return self.obs.permute(0, 2, 1, 3)
+
+    def state_dict(self):
+        n = _native.LIB.mg_state_size(self._h)
+        buf = np.empty(n, np.uint8)
+        _native.check(_native.LIB.mg_get_state(self._h, buf.ctypes.data, n), "mg_get_state")
+        return {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf}
+
+    def load_state_dict(self, sd):
+        assert sd["env_id"] == self.env_id and sd["num_envs"] == self.num_envs
+        buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
+        _native.check(_native.LIB.mg_set_state(self._h, buf.ctypes.data, buf.size), "mg_set_state")
+
+    def set_profiling(self, on):
+        _native.check(_native.LIB.mg_set_profiling(self._h, int(bool(on))), "mg_set_profiling")
+
+    def get_profile(self, kind):
+        """(total_ms, launches) of the logic (kind 0) or raster (kind 1) kernel since the last call."""
+        ms, n = C.c_double(), C.c_int64()
+        _native.check(_native.LIB.mg_get_profile(self._h, kind, C.byref(ms), C.byref(n)), "mg_get_profile")
+        return ms.value, n.value
+
+    def rng_words(self, i):
+        w = np.zeros(6, np.uint64)
+        _native.check(_native.LIB.mg_debug_rng(self._h, int(i), w.ctypes.data), "mg_debug_rng")
+        return w
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _native.LIB.mg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MemoryGymEnv:
+    """Single-instance adapter with the reference's exact signatures (reset -> (obs, info); step -> 5-tuple)."""
+
+    def __init__(self, env_id, device=None, render_mode=None):
+        self.vec = VecMemoryGym(env_id, 1, device, render_mode)
+        self.vec.autoreset = False
+        self.action_space = self.vec.action_space
+        self.observation_space = self.vec.observation_space
+        self.has_ground_truth_info = self.vec.has_ground_truth_info
+        if self.has_ground_truth_info:
+            self.ground_truth_space = self.vec.ground_truth_space
+        self.metadata = self.vec.metadata
+        self.render_mode = render_mode
+
+    @property
+    def max_episode_steps(self):
+        return self.vec.max_episode_steps
+
+    def reset(self, seed=None, return_info=True, options=None):
+        obs, info = self.vec.reset(seed=seed, options=options)
+        out = {}
+        if "ground_truth" in info:
+            out["ground_truth"] = info["ground_truth"][0].double().cpu().numpy()
+        return obs[0].cpu().numpy(), out
+
+    def step(self, action):
+        a = np.atleast_1d(np.asarray(action)).reshape(1, -1)
+        obs, reward, done, _, info = self.vec.step(a)
+        d = bool(done[0].item())
+        out = {}
+        if d:
+            out["reward"] = float(info["reward"][0].item())
+            out["length"] = int(info["length"][0].item())
+            for nm in self.vec.info_names:
+                out[nm] = float(info[nm][0].item())
+        if "ground_truth" in info:
+            out["ground_truth"] = info["ground_truth"][0].double().cpu().numpy()
+        return obs[0].cpu().numpy(), float(reward[0].item()), d, False, out
+
+    def render(self):
+        return self.vec.render()[0].cpu().numpy()
+
+    def close(self):
+        self.vec.close()

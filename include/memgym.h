@@ -1,0 +1,104 @@
+/* include/memgym.h -- C ABI of libmemgym_hip.so (MI355X / gfx950 batched Memory Gym hot path).
+ *
+ * The reference (MarcoMeter/endless-memory-gym) has no FFI: the boundary trainers program against is
+ * the Gymnasium Env protocol of its Python classes.  Each entry point below replaces the per-instance
+ * Python method named next to it, batched over `num_envs` independent environment instances whose
+ * state lives in HBM.  All `*_dev` pointers are device pointers owned by the caller (e.g. torch
+ * tensors); `stream` is a hipStream_t (void* so that this header needs no HIP include); every call
+ * only enqueues work on that stream (no host synchronisation) unless stated otherwise.
+ *
+ * Return value: 0 on success, negative on error (`mg_last_error()` holds the message).
+ * A handle binds one device; it is not thread-safe, distinct handles are independent.
+ *
+ * Observation layout (identical to pygame.surfarray.array3d in the reference, e.g.
+ * memory_gym/mortar_mayhem_grid.py:276,373): uint8 [num_envs][84 (x)][84 (y)][3 (rgb)].
+ */
+#ifndef MEMGYM_H
+#define MEMGYM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg_env mg_env;
+
+#define MG_OBS_DIM 84
+#define MG_OBS_BYTES (84 * 84 * 3) /* 21,168 */
+#define MG_INFO_SLOTS 8
+
+/* Per-env end-of-episode record, written by mg_step when an env reports done (the reference's
+ * `info` dict returned on the terminal step, e.g. mortar_mayhem_grid.py:356-362).  Device SoA,
+ * all arrays [num_envs]; any pointer may be NULL.  `aux[k]` meaning per env id: see mg_info_name(). */
+typedef struct mg_info_buffers {
+    double* ep_reward_dev;         /* "reward": Python sum() of the step rewards, in double        */
+    int32_t* ep_length_dev;        /* "length"                                                      */
+    float* aux_dev[MG_INFO_SLOTS]; /* "success", "commands_completed", "num_fails", ... per env id */
+} mg_info_buffers;
+
+/* gymnasium.make(id) + Env.__init__  (memory_gym/__init__.py:13-61; e.g. mortar_mayhem_grid.py:55-90).
+ * env_id: one of the reference's registered ids.  Allocates the SoA state for num_envs instances on
+ * `device` and builds the stamp atlases / background templates.  Synchronous. */
+int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out);
+void mg_destroy(mg_env* env);
+const char* mg_last_error(void);
+
+/* Static properties (action_space / observation_space / ground_truth_space of the reference classes):
+ * mg_action_dim: 1 = Discrete(4) (mortar_mayhem_grid.py:82, endless_mystery_path.py:83),
+ *                2 = MultiDiscrete([3,3]) (e.g. mortar_mayhem.py:83).
+ * mg_gt_dim:     0, or the size of info["ground_truth"] (endless_mortar_mayhem.py:91-96 -> 2,
+ *                endless_mystery_path.py:92-97 -> 3, endless_searing_spotlights.py:112-117 -> 4). */
+int32_t mg_num_envs(const mg_env* env);
+int32_t mg_action_dim(const mg_env* env);
+int32_t mg_gt_dim(const mg_env* env);
+/* name of aux slot k of mg_info_buffers for this env id, or NULL */
+const char* mg_info_name(const mg_env* env, int k);
+
+/* One key of the reference's reset `options` dict (process_reset_params, e.g.
+ * mortar_mayhem_grid.py:36-53).  `values`/`n`: scalars are n == 1, "sample one per episode" lists
+ * have n >= 1.  Unknown key -> error -2 (the Python layer turns it into the reference's
+ * AssertionError text); unsupported value -> error -3.  Takes effect at the next reset (also
+ * auto-resets), for every instance of the handle. */
+int mg_set_option(mg_env* env, const char* key, const double* values, int n);
+
+/* Env.reset(seed, options) (e.g. mortar_mayhem_grid.py:213-278) for all instances, or for those with
+ * mask_dev[i] != 0.  seeds_dev: int64 [num_envs] -> instance i is re-seeded exactly like
+ * gymnasium's reset(seed=s): Generator(PCG64(SeedSequence(s))); NULL -> keep each instance's stream
+ * (reset(seed=None)).  Writes the first observation of every reset instance to obs_dev (others are
+ * left untouched) and, if gt_dev != NULL and mg_gt_dim() > 0, info["ground_truth"] as float32
+ * [num_envs][gt_dim]. */
+int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, uint8_t* obs_dev, float* gt_dev,
+             void* stream);
+
+/* Env.step(action) (e.g. mortar_mayhem_grid.py:280-375) for all instances.
+ * actions_dev: int32 [num_envs] (Discrete) or [num_envs][2] (MultiDiscrete).
+ * reward_dev: float32 [num_envs] (the reference's Python float, rounded once to float32);
+ * done_dev: uint8 [num_envs] (`truncation` is always False in the reference).
+ * autoreset != 0: an instance that reports done is reset in the same call with seed=None (its RNG
+ * stream continues, exactly what `env.reset()` right after a terminal step does) and obs_dev/gt_dev
+ * hold the first observation of the new episode; the finished episode's info is in `info`. */
+int mg_step(mg_env* env, const int32_t* actions_dev, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
+            float* gt_dev, const mg_info_buffers* info, int autoreset, void* stream);
+
+/* Checkpoint hooks (the reference cannot serialise an env; SoA state makes it free).  Synchronous.
+ * mg_state_size: bytes needed.  Layout is private to one library build. */
+size_t mg_state_size(const mg_env* env);
+int mg_get_state(mg_env* env, void* host_buf, size_t size);
+int mg_set_state(mg_env* env, const void* host_buf, size_t size);
+
+/* Measurement hooks (bench.py's roofline leg): when profiling is on, every mg_step brackets its kernels with
+ * hipEvents recorded on the launch stream.  mg_get_profile(kind) synchronises, returns the summed elapsed
+ * milliseconds and the number of launches since the last call, and clears.  kind 0 = logic kernel
+ * (one lane per instance), kind 1 = raster kernel (the HBM-write-bound one). */
+int mg_set_profiling(mg_env* env, int on);
+int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
+
+/* Test hook: copy the numpy-compatible PCG64 words of instance i to host:
+ * out[6] = {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}.  Synchronous. */
+int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,200 @@
+"""GPU parity (-m gpu): the HIP path, called through the C ABI (memory_gym_amd -> libmemgym_hip.so), against the
+CPU oracle on the same seeds / options / actions.  Bar: bit-exact uint8 observations, dones, RNG words; rewards
+equal after float64 -> float32; end-of-episode info equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MORTAR = ["MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0"]
+
+OPTION_SETS = {
+    "MortarMayhem-Grid-v0": [
+        None,
+        dict(arena_size=6, allowed_commands=9, command_count=[3, 5, 10], command_show_duration=[1, 2, 3],
+             command_show_delay=[0, 1, 2], explosion_duration=[2, 3], explosion_delay=[4, 6, 8],
+             reward_command_failure=-0.1, reward_episode_success=1.0),
+        dict(arena_size=2, allowed_commands=4, command_count=[4], visual_feedback=False),
+    ],
+    "MortarMayhem-v0": [
+        None,
+        dict(arena_size=6, allowed_commands=5, command_count=[3, 6], explosion_duration=[4, 6],
+             explosion_delay=[12, 18], reward_command_failure=-0.5, reward_episode_success=2.0),
+        dict(arena_size=3, command_count=[5], command_show_duration=[2], command_show_delay=[0]),
+    ],
+    "Endless-MortarMayhem-v0": [
+        None,
+        dict(max_steps=200, initial_command_count=3, allowed_commands=5, command_show_duration=[2, 3],
+             command_show_delay=[0, 1], explosion_duration=[4, 6], explosion_delay=[12, 18],
+             reward_new_command_success=0.5, reward_command_failure=-0.25),
+        dict(initial_command_count=2, visual_feedback=False),
+    ],
+}
+
+
+def _toward(d):
+    return 0 if d == 0 else (1 if d < 0 else 2)
+
+
+def run_parity(env_id, options, n, steps, skill_envs=0, check_every=1):
+    import memory_gym_amd
+    import oracle_lib
+
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    ref = oracle_lib.OracleBatch(env_id, n, options=options)
+    disc = env.action_dim == 1
+    seeds = np.arange(n, dtype=np.int64) * 7 + 3
+    obs, info = env.reset(seed=seeds, options=options)
+    assert np.array_equal(obs.cpu().numpy(), ref.reset(seeds)), "reset frames differ"
+    if env.gt_dim:
+        gt_ref = np.stack([e.gt() for e in ref.envs]).astype(np.float32)
+        assert np.array_equal(info["ground_truth"].cpu().numpy(), gt_ref)
+    prng = np.random.Generator(np.random.PCG64(99))
+    arena_n = (options or {}).get("arena_size", 5)
+    n_done = 0
+    for t in range(steps):
+        a = prng.integers(0, 4, (n, 1)) if disc else prng.integers(0, 3, (n, 2))
+        a = a.astype(np.int32)
+        for i in range(skill_envs):
+            act = expert_action_n(env_id, ref.envs[i], prng, 0.97, arena_n)
+            a[i, :len(act[:a.shape[1]])] = act[:a.shape[1]]
+        obs, rew, done, trunc, info = env.step(a if not disc else a[:, 0])
+        o2, r2, d2 = ref.step(a if not disc else a[:, 0], autoreset=True, want_obs=(t % check_every == 0))
+        d = done.cpu().numpy()
+        assert np.array_equal(d, d2.astype(bool)), "done differs at step %d" % t
+        assert np.array_equal(rew.cpu().numpy(), r2.astype(np.float32)), "reward differs at step %d" % t
+        assert not trunc.any()
+        if t % check_every == 0:
+            got = obs.cpu().numpy()
+            if not np.array_equal(got, o2):
+                bad = np.nonzero((got != o2).reshape(n, -1).any(1))[0]
+                raise AssertionError("%s: frame differs at step %d for envs %s" % (env_id, t, bad[:8]))
+        n_done += int(d.sum())
+        if env.gt_dim:
+            gt_ref = np.stack([e.gt() for e in ref.envs]).astype(np.float32)
+            assert np.array_equal(info["ground_truth"].cpu().numpy(), gt_ref), "ground_truth differs at step %d" % t
+    for i in (0, 1, n // 2, n - 1):
+        assert np.array_equal(env.rng_words(i), ref.envs[i].rng_words()), "RNG stream of env %d diverged" % i
+    env.close()
+    ref.close()
+    return n_done
+
+
+def expert_action_n(env_id, e, prng, skill, arena_n):
+    disc = env_id == "MortarMayhem-Grid-v0"
+    if prng.random() > skill:
+        return [int(prng.integers(0, 4)), 0] if disc else [int(prng.integers(0, 3)), int(prng.integers(0, 3))]
+    if e.get("vis_len") > 0 or e.get("tiles_on") > 0:
+        return [0, 0]
+    tx, ty = e.get("tx"), e.get("ty")
+    if disc:
+        nx, ny, rot = e.get("nx"), e.get("ny"), e.get("arot")
+        if (nx, ny) == (tx, ty):
+            return [0, 0]
+        want = 270 if tx > nx else (90 if tx < nx else (0 if ty < ny else 180))
+        if rot == want:
+            return [3, 0]
+        return [1 if (want - rot) % 360 in (90, 180) else 2, 0]
+    endless = env_id.startswith("Endless")
+    n = 6 if endless else arena_n
+    x0 = 42 - (14 * n) // 2
+    cx, cy = x0 + tx * 14 + 7, x0 + ty * 14 + 7
+    dx, dy = cx - e.get("ax"), cy - e.get("ay")
+    if endless:
+        dx = (dx + 42) % 84 - 42
+        dy = (dy + 42) % 84 - 42
+    dx = 0 if abs(dx) < 3 else dx
+    dy = 0 if abs(dy) < 3 else dy
+    return [_toward(dx), _toward(dy)]
+
+
+@pytest.mark.parametrize("env_id", MORTAR)
+@pytest.mark.parametrize("opt_idx", [0, 1, 2])
+def test_parity_with_oracle(env_id, opt_idx):
+    n_done = run_parity(env_id, OPTION_SETS[env_id][opt_idx], n=192, steps=260, skill_envs=48)
+    assert n_done > 0
+
+
+def test_terminal_info_matches_oracle():
+    """End-of-episode info (reward sum in double, length, success, commands_completed) vs single-instance oracles."""
+    import memory_gym_amd
+    import oracle_lib
+
+    for env_id in MORTAR:
+        n = 64
+        env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+        refs = [oracle_lib.OracleEnv(env_id) for _ in range(n)]
+        seeds = np.arange(n, dtype=np.int64) + 1000
+        env.reset(seed=seeds)
+        for i, r in enumerate(refs):
+            r.reset(int(seeds[i]), want_obs=False)
+        prng = np.random.Generator(np.random.PCG64(5))
+        disc = env.action_dim == 1
+        checked = 0
+        for t in range(150):
+            a = (prng.integers(0, 4, (n, 1)) if disc else prng.integers(0, 3, (n, 2))).astype(np.int32)
+            _, _, done, _, info = env.step(a[:, 0] if disc else a)
+            done = done.cpu().numpy()
+            for i, r in enumerate(refs):
+                _, _, d = r.step(a[i], want_obs=False)
+                assert d == done[i]
+                if d:
+                    assert info["reward"][i].item() == r.get("info_reward")
+                    assert info["length"][i].item() == r.get("info_length")
+                    for nm in env.info_names:
+                        assert info[nm][i].item() == np.float32(r.get("info_" + nm)), (env_id, nm)
+                    checked += 1
+                    r.reset(None, want_obs=False)
+        assert checked > 0
+        env.close()
+
+
+def test_full_size_properties():
+    """BASELINE config C2 size (65,536 instances): size-independent properties instead of a full oracle replay.
+    * instance i seeded i matches a single-instance oracle on a sample of indices (sharding invariance);
+    * every frame is one of a closed set: pixel values only from the palette."""
+    import memory_gym_amd
+    import oracle_lib
+    import torch
+
+    n = 65536
+    env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=n, device=0)
+    obs, _ = env.reset(seed=0)
+    sample = [0, 1, 255, 256, 4095, 32768, 65535]
+    refs = {i: oracle_lib.OracleEnv("MortarMayhem-Grid-v0") for i in sample}
+    first = obs[sample].cpu().numpy()
+    for k, i in enumerate(sample):
+        assert np.array_equal(first[k], refs[i].reset(i))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    palette = {(0, 0, 0), (21, 43, 77), (29, 60, 107), (81, 18, 26), (112, 24, 36), (250, 204, 153), (50, 50, 50), (255, 255, 255)}
+    for t in range(50):
+        a = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32)
+        obs, rew, done, _, _ = env.step(a)
+        ac = a[sample].cpu().numpy()
+        got = obs[sample].cpu().numpy()
+        for k, i in enumerate(sample):
+            o, r, d = refs[i].step([int(ac[k]), 0])
+            if d:
+                o = refs[i].reset(None)
+            assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t)
+    colours = torch.unique(obs.reshape(-1, 3)[:: 97], dim=0).cpu().numpy()
+    assert {tuple(c) for c in colours.tolist()} <= palette
+    env.close()
+
+
+def test_checkpoint_roundtrip():
+    import memory_gym_amd
+
+    env = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=256, device=0)
+    env.reset(seed=11)
+    prng = np.random.Generator(np.random.PCG64(3))
+    for _ in range(30):
+        env.step(prng.integers(0, 3, (256, 2)).astype(np.int32))
+    sd = env.state_dict()
+    acts = [prng.integers(0, 3, (256, 2)).astype(np.int32) for _ in range(40)]
+    out1 = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts]
+    env.load_state_dict(sd)
+    out2 = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts]
+    for (o1, r1, d1), (o2, r2, d2) in zip(out1, out2):
+        assert (o1 == o2).all() and (r1 == r2).all() and (d1 == d2).all()
+    env.close()
