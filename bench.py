@@ -42,8 +42,8 @@ def cpu_baseline(env_id, budget_s=15.0):
 
     import oracle_lib
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     n = 64 * cores
     b = oracle_lib.OracleBatch(env_id, n)
     disc = b.discrete

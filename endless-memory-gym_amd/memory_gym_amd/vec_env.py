@@ -90,6 +90,7 @@ class VecMemoryGym:
         self._applied = dict(DEFAULTS[env_id])
         self.max_episode_steps = None
         self.autoreset = True
+        self._truncated = torch.zeros(N, dtype=torch.bool, device=dev)  # `truncation` is always False in the reference
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -158,7 +159,7 @@ class VecMemoryGym:
             info[nm] = t
         if self.gt_dim:
             info["ground_truth"] = self.gt
-        return self.obs, self.reward, done, torch.zeros_like(done), info
+        return self.obs, self.reward, done, self._truncated, info
 
     def render(self):
         """rgb_array mode of the reference: fliplr(rot90(obs, 3)) == transpose to [y][x][c] (mortar_mayhem_grid.py:401-402)."""
