@@ -29,6 +29,13 @@ static inline void mgo_rect_set_center(mgo_rect* r, double cx, double cy) {
     r->y += mgo_round_haz(cy) - (r->y + (r->h >> 1));
 }
 
+/* sin() and cos() evaluated by SEPARATE libm calls.  gcc would otherwise merge them into one sincos(), whose results
+ * differ from sin()/cos() by 1 ulp for 6 of the 720 integer-degree angles with this glibc.  The golden fixtures were
+ * produced through CPython's math.sin / math.cos (two calls), so that is the definition used here; what the real
+ * pygame binary does depends on its compiler and the host libm (sub-ulp ambiguity of the reference itself). */
+static __attribute__((noinline)) double mgo_sin(double x) { volatile double v = x; return sin(v); }
+static __attribute__((noinline)) double mgo_cos(double x) { volatile double v = x; return cos(v); }
+
 /* ---- pygame.math.Vector2.rotate (src_c/math.c:_vector2_rotate_helper) ----------------------- */
 static inline void mgo_vec_rotate(double x, double y, double angle, double* ox, double* oy) {
     const double eps = 1e-6;
@@ -43,7 +50,7 @@ static inline void mgo_vec_rotate(double x, double y, double angle, double* ox, 
             default: *ox = y; *oy = -x; break;
         }
     } else {
-        double rad = angle * M_PI / 180.0, s = sin(rad), c = cos(rad);
+        double rad = angle * M_PI / 180.0, s = mgo_sin(rad), c = mgo_cos(rad);
         *ox = c * x - s * y;
         *oy = s * x + c * y;
     }
