@@ -9,14 +9,16 @@
 //
 // Two kernels per step:
 //   mortar_logic  : one LANE per environment instance.  Episode state machine, RNG, reward/done/info; emits a
-//                   16-byte draw descriptor per instance.  State is small fixed-size records in HBM, read and
+//                   16-byte frame descriptor per instance.  State is small fixed-size records in HBM, read and
 //                   written fully coalesced (lane i <-> record i).
-//   mortar_raster : one WORKGROUP (4 waves) per instance.  The 21,168-byte frame is composed in LDS -- the
-//                   arena comes from an L2-resident template selected by (tiles on?, target tile), the agent
-//                   sprite and the command glyph are stamped from palette-indexed atlases -- and streamed to HBM
-//                   as 1,323 coalesced 16-byte stores.  Write-bound: 21,168 B of algorithmic traffic per env-step.
+//   raster_kernel<MortarComposer> : (mg_raster.hpp) persistent workgroups, one frame at a time in LDS: arena
+//                   template (selected by tiles-on / target tile) -> agent sprite stamp -> command glyph stamp.
+#include <memory>
+
+#include "mg_atlas.hpp"
 #include "mg_device.hpp"
 #include "mg_family.hpp"
+#include "mg_raster.hpp"
 #include "mg_stamps.hpp"
 
 namespace mg {
@@ -28,6 +30,7 @@ struct MortarParams {
     int cmd_cap;                 // per-instance command list capacity
     int arena_x0, tile;          // arena top-left (x == y) and tile size in px
     int radius, sprite_dim;      // agent radius, sprite box
+    int glyph_x0;                // blit position of the command glyph (x == y)
     int v_axis_i, v_diag_i;      // free controller: int(speed), int(speed/sqrt2)
     int off_lo, off_hi;          // endless: spawn offset = integers(off_lo, off_hi)
     double v_axis, v_diag;       // screen-wrap controller: un-truncated velocities
@@ -56,14 +59,31 @@ struct __attribute__((aligned(16))) MortarState {
 };
 static_assert(sizeof(MortarState) == 64, "MortarState must be 64 bytes");
 
+// per-instance frame descriptor: what the raster kernel composes (template -> agent sprite -> command glyph)
 struct __attribute__((aligned(16))) MortarDesc {
     int16_t sx, sy;    // sprite top-left on screen
-    uint16_t tmpl;     // background template index, 0xFFFF = leave the frame untouched
+    uint16_t tmpl;     // background template index, 0xFFFF = leave the frame untouched (masked reset)
     uint8_t sprite;    // 0..7, 0xFF none
-    uint8_t glyph;     // 0..9, 0xFF none
-    uint32_t pad[2];
+    uint8_t glyph;     // 0..9 (9 = blank), 0xFF none
+    int16_t glyph_x0;  // blit position of the glyph (x == y)
+    uint16_t pad[3];
 };
 static_assert(sizeof(MortarDesc) == 16, "MortarDesc must be 16 bytes");
+constexpr int STAMP_SPRITE0 = 0, STAMP_GLYPH0 = 8;
+
+struct MortarComposer {
+    typedef MortarDesc Desc;
+    static __device__ __forceinline__ bool skip(const Desc& d) { return d.tmpl == 0xFFFF; }
+    static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
+        fill_template(R, d.tmpl);
+        __syncthreads();
+        if (d.sprite != 0xFF) stamp(R, STAMP_SPRITE0 + d.sprite, d.sx, d.sy);
+        if (d.glyph < 9) {
+            __syncthreads();
+            stamp(R, STAMP_GLYPH0 + d.glyph, d.glyph_x0, d.glyph_x0);
+        }
+    }
+};
 
 __constant__ int8_t kCmdDx[9] = {1, 0, -1, 0, 0, 1, 1, -1, -1};
 __constant__ int8_t kCmdDy[9] = {0, 1, 0, -1, 0, 1, -1, 1, -1};
@@ -170,11 +190,10 @@ __global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P, int n
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     MortarDesc d;
-    d.pad[0] = d.pad[1] = 0;
+    memset(&d, 0, sizeof(d));
+    d.glyph_x0 = (int16_t)P.glyph_x0;
     if (mask && !mask[i]) {
-        d.sx = d.sy = 0;
         d.tmpl = 0xFFFF;
-        d.sprite = d.glyph = 0xFF;
         io.desc[i] = d;
         return;
     }
@@ -377,7 +396,8 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     done_out[i] = done ? 1 : 0;
 
     MortarDesc d;
-    d.pad[0] = d.pad[1] = 0;
+    memset(&d, 0, sizeof(d));
+    d.glyph_x0 = (int16_t)P.glyph_x0;
     if (done && autoreset) {
         if (!rng_loaded) g.load(io.rng, i);
         rng_loaded = true;
@@ -397,71 +417,6 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     if (rng_loaded) g.store(io.rng, i);
     io.state[i] = s;
     io.desc[i] = d;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Raster: one workgroup per instance; LDS-composed frame, 16-byte coalesced stores.
-// ---------------------------------------------------------------------------------------------------------
-struct MortarAtlas {
-    const uint8_t* templates;   // [(1+N*N)][84][84][3]
-    const uint8_t* sprites;     // [8][dim][dim] palette indices, stored [x][y] (column-major like the frame)
-    const uint8_t* glyphs;      // [10][gdim][gdim] stored [x][y], 0/1
-    int sprite_dim, glyph_box;  // glyph_box = allocated square per glyph
-    int glyph_dim[10];          // actual side of each glyph (22 or 31)
-    int glyph_x0;               // blit position (== y)
-    uint32_t palette[PAL_COUNT];  // 0x00BBGGRR byte order r,g,b in the low three bytes
-};
-
-__device__ __forceinline__ void put_px(uint8_t* frame, int x, int y, uint32_t rgb) {
-    uint8_t* p = frame + (x * SCREEN + y) * 3;
-    p[0] = (uint8_t)rgb;
-    p[1] = (uint8_t)(rgb >> 8);
-    p[2] = (uint8_t)(rgb >> 16);
-}
-
-__global__ __launch_bounds__(256) void mortar_raster_kernel(const MortarDesc* __restrict__ descs, MortarAtlas A,
-                                                            uint8_t* __restrict__ obs) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t frame[];
-    const int env = blockIdx.x, tid = threadIdx.x;
-    const MortarDesc d = descs[env];
-    if (d.tmpl == 0xFFFF) return;
-
-    const uint4* src = reinterpret_cast<const uint4*>(A.templates + (size_t)d.tmpl * FRAME_BYTES);
-    uint4* lds = reinterpret_cast<uint4*>(frame);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        int c = tid + k * 256;
-        if (c < FRAME_VEC16) lds[c] = src[c];
-    }
-    __syncthreads();
-
-    if (d.sprite != 0xFF) {
-        const int D = A.sprite_dim;
-        const uint8_t* sp = A.sprites + (int)d.sprite * D * D;
-        for (int p = tid; p < D * D; p += 256) {
-            int px = p / D, py = p - px * D;
-            uint8_t idx = sp[p];
-            int X = d.sx + px, Y = d.sy + py;
-            if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_px(frame, X, Y, A.palette[idx]);
-        }
-    }
-    if (d.glyph < 9) {  // 9 = blank glyph, 0xFF = none: nothing to draw
-        __syncthreads();
-        const int G = A.glyph_dim[d.glyph], B = A.glyph_box;
-        const uint8_t* gp = A.glyphs + (int)d.glyph * B * B;
-        for (int p = tid; p < G * G; p += 256) {
-            int px = p / G, py = p - px * G;
-            if (gp[px * B + py]) put_px(frame, A.glyph_x0 + px, A.glyph_x0 + py, 0x00FFFFFFu);
-        }
-    }
-    __syncthreads();
-
-    uint4* dst = reinterpret_cast<uint4*>(obs + (size_t)env * FRAME_BYTES);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        int c = tid + k * 256;
-        if (c < FRAME_VEC16) dst[c] = lds[c];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -494,7 +449,7 @@ class MortarFamily : public Family {
         state_.alloc(n);
         cmds_.alloc((size_t)n * P_.cmd_cap);
         desc_.alloc(n);
-        rng_s_hi_.alloc(n); rng_s_lo_.alloc(n); rng_i_hi_.alloc(n); rng_i_lo_.alloc(n); rng_buf_.alloc(n);
+        rng_.alloc(n);
         hipLaunchKernelGGL(mortar_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, state_.p);
         MG_HIP(hipDeviceSynchronize());
         rebuild();
@@ -576,21 +531,12 @@ class MortarFamily : public Family {
     }
 
     std::vector<std::pair<void*, size_t>> state_blobs() override {
-        return {{state_.p, state_.bytes()}, {cmds_.p, cmds_.bytes()},       {rng_s_hi_.p, rng_s_hi_.bytes()},
-                {rng_s_lo_.p, rng_s_lo_.bytes()}, {rng_i_hi_.p, rng_i_hi_.bytes()}, {rng_i_lo_.p, rng_i_lo_.bytes()},
-                {rng_buf_.p, rng_buf_.bytes()}};
+        std::vector<std::pair<void*, size_t>> v = {{state_.p, state_.bytes()}, {cmds_.p, cmds_.bytes()}};
+        rng_.blobs(v);
+        return v;
     }
 
-    void debug_rng(int i, uint64_t out[6]) override {
-        uint64_t b;
-        MG_HIP(hipMemcpy(&out[0], rng_s_hi_.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&out[1], rng_s_lo_.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&out[2], rng_i_hi_.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&out[3], rng_i_lo_.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&b, rng_buf_.p + i, 8, hipMemcpyDeviceToHost));
-        out[4] = (b >> 32) & 1;
-        out[5] = b & 0xFFFFFFFFull;
-    }
+    void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
 
    private:
     static void set_list(OptList& l, std::initializer_list<int> v) {
@@ -601,7 +547,7 @@ class MortarFamily : public Family {
         MortarIO o;
         o.state = state_.p;
         o.cmds = cmds_.p;
-        o.rng = RngSoA{rng_s_hi_.p, rng_s_lo_.p, rng_i_hi_.p, rng_i_lo_.p, rng_buf_.p};
+        o.rng = rng_.view();
         o.desc = desc_.p;
         return o;
     }
@@ -623,48 +569,29 @@ class MortarFamily : public Family {
         P_.off_lo = (int)(-8 * SCALE);
         P_.off_hi = (int)(8 * SCALE);
 
-        int D = P_.sprite_dim;
-        std::vector<uint8_t> sp((size_t)8 * D * D);
-        for (int k = 0; k < 8; ++k)
-            for (int x = 0; x < D; ++x)
-                for (int y = 0; y < D; ++y) sp[(size_t)k * D * D + x * D + y] = sprites[k].get(x, y);
-        int B = 0;
-        for (auto& g : glyphs) B = std::max(B, std::max(g.w, g.h));
-        std::vector<uint8_t> gl((size_t)10 * B * B, 0);
-        for (int k = 0; k < 10; ++k) {
-            A_.glyph_dim[k] = glyphs[k].w;
-            for (int x = 0; x < glyphs[k].w; ++x)
-                for (int y = 0; y < glyphs[k].h; ++y) gl[(size_t)k * B * B + x * B + y] = glyphs[k].get(x, y) ? 1 : 0;
-        }
-        sprites_dev_.upload(sp);
-        glyphs_dev_.upload(gl);
-        templates_dev_.upload(build_mortar_templates(P_.N, SCALE, SCREEN));
-        A_.templates = templates_dev_.p;
-        A_.sprites = sprites_dev_.p;
-        A_.glyphs = glyphs_dev_.p;
-        A_.sprite_dim = D;
-        A_.glyph_box = B;
-        A_.glyph_x0 = (int)((SCREEN / 2) - std::floor(88 * SCALE / 2));
-        for (int k = 0; k < PAL_COUNT; ++k)
-            A_.palette[k] = (uint32_t)PALETTE_RGB[k][0] | ((uint32_t)PALETTE_RGB[k][1] << 8) | ((uint32_t)PALETTE_RGB[k][2] << 16);
+        atlas_.reset(new Atlas());
+        for (auto& sp : sprites) atlas_->add_stamp(sp);   // ids 0..7
+        for (auto& g : glyphs) atlas_->add_stamp(g);      // ids 8..17
+        atlas_->set_templates(build_mortar_templates(P_.N, SCALE, SCREEN));
+        atlas_->upload();
+        P_.glyph_x0 = (int)((SCREEN / 2) - std::floor(88 * SCALE / 2));
         dirty_ = false;
     }
 
     void raster(uint8_t* obs, hipStream_t s) {
-        hipLaunchKernelGGL(mortar_raster_kernel, dim3(n_), dim3(256), FRAME_BYTES, s, desc_.p, A_, obs);
+        launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, n_, s);
         MG_HIP(hipGetLastError());
     }
 
     int n_;
     MortarParams P_;
-    MortarAtlas A_;
+    std::unique_ptr<Atlas> atlas_;
     double agent_scale_, agent_speed_;
     bool dirty_ = true, seeded_ = false;
     DevArray<MortarState> state_;
     DevArray<uint8_t> cmds_;
     DevArray<MortarDesc> desc_;
-    DevArray<uint64_t> rng_s_hi_, rng_s_lo_, rng_i_hi_, rng_i_lo_, rng_buf_;
-    DevArray<uint8_t> sprites_dev_, glyphs_dev_, templates_dev_;
+    RngStore rng_;
 };
 
 Family* make_mortar(int variant, int num_envs) { return new MortarFamily(variant, num_envs); }

@@ -1,0 +1,230 @@
+// mg_raster.hpp -- the raster skeleton shared by every environment family (gfx950).
+//
+// raster_kernel<Composer>: PERSISTENT workgroups (256 lanes = 4 waves); each walks frames
+// env = blockIdx.x, blockIdx.x + gridDim.x, ...  For one frame it
+//   1. reads the family's small per-instance frame descriptor (workgroup-uniform -> scalar loads),
+//   2. composes the 84x84x3 observation in 21,168 B of LDS with the helpers below, in the reference's blit order
+//      (its _draw_surfaces(), e.g. memory_gym/mortar_mayhem_grid.py:92-102,367-370,
+//      endless_searing_spotlights.py:464-479, endless_mystery_path.py:134-160),
+//   3. streams it to HBM as 1,323 x 16-byte stores, lane-contiguous (1 KiB per wave instruction).
+// The stores are fire-and-forget, so the workgroup composes its next frame while they drain; a
+// one-frame-per-workgroup launch keeps the LDS hostage until the stores are acknowledged (measured 322 us vs 264 us
+// per 65,536 frames; an interpreter over a generic display list measured 390-415 us: tools/microbench/raster_bench.hip).
+// Roofline: HBM write bandwidth; algorithmic traffic per instance-step = 21,168 B written + sizeof(Desc) read.
+//
+// Helpers (all lanes of the workgroup call them together; callers place __syncthreads() between overlapping layers):
+//   fill_template  copy a pre-rendered full frame (mortar arena variants, chessboards) from the L2-resident atlas
+//   fill_clear     black frame
+//   stamp          colour-keyed blit of a palette-indexed stamp (agent sprites, glyphs, cross, coin, exit), clipped
+//   rect           filled rectangle with optional 1-px inset border (tiles, bars), clipped
+//   darken         the spotlight layer: pixels outside every hole disc blended towards black with SDL's
+//                  surface-alpha rule d - floor(d*alpha/255)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "mg_device.hpp"
+
+namespace mg {
+
+constexpr int DISC_RMAX = 64;
+constexpr int MAX_STAMPS = 48;
+constexpr int PALETTE_SIZE = 32;
+constexpr int MASK_WORDS = 3;                 // 84 bits per column
+constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
+constexpr int RASTER_GRID = 256 * 7 * 8;      // 7 workgroups fit one CU's 160 KiB of LDS; 8 rounds of persistent workgroups (bench sweep: best of 2..37)
+constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
+
+struct StampInfo {
+    uint32_t off;  // byte offset into the stamp data, pixels stored [x][y] (column-major like the frame)
+    uint16_t w, h;
+};
+
+struct AtlasTables {
+    StampInfo stamps[MAX_STAMPS];
+    uint32_t palette[PALETTE_SIZE];   // r | g<<8 | b<<16
+    uint8_t border_of[PALETTE_SIZE];  // palette id of the 1-px border drawn around a bordered rect of this fill colour
+};
+
+// Everything the raster kernel samples (device pointers; small enough to sit in the scalar/L1/L2 caches).
+struct RasterAtlas {
+    const uint8_t* templates;   // [n_templates][84][84][3]
+    const uint8_t* stamp_data;  // palette indices, 0 = transparent
+    const int8_t* disc_span;    // [DISC_RMAX+1][2*DISC_RMAX][2]: per column i of a radius-r disc, (lo, hi) y offsets; lo > hi = empty
+    const AtlasTables* tables;
+};
+
+// Palette ids shared by all families
+enum : uint8_t {
+    C_KEY = 0, C_BODY = 1, C_HAND = 2, C_OUTLINE = 3, C_WHITE = 4, C_RED = 5, C_GREEN = 6, C_BLUE = 7, C_YELLOW = 8,
+    C_ORANGE = 9, C_GREY50 = 10, C_GREY120 = 11, C_PURPLE = 12, C_ACT_ORANGE = 13, C_GREY210 = 14, C_BLACK = 15,
+    C_EXIT_OPEN = 16, C_EXIT_CLOSED = 17, C_ICY = 18
+};
+
+struct RasterCtx {
+    uint8_t* frame;   // LDS, [x][y][c]
+    uint32_t* mask;   // LDS, [84][MASK_WORDS] hole mask scratch
+    RasterAtlas A;
+    int tid;
+};
+
+__device__ __forceinline__ void put_rgb(uint8_t* frame, int x, int y, uint32_t rgb) {
+    uint8_t* p = frame + (x * SCREEN + y) * 3;
+    p[0] = (uint8_t)rgb;
+    p[1] = (uint8_t)(rgb >> 8);
+    p[2] = (uint8_t)(rgb >> 16);
+}
+
+// all six 16-byte loads are issued before the first LDS write (one L2 round trip, not six)
+__device__ __forceinline__ void fill_template(const RasterCtx& R, int t) {
+    uint4* lds16 = reinterpret_cast<uint4*>(R.frame);
+    const uint4* src = reinterpret_cast<const uint4*>(R.A.templates + (size_t)t * FRAME_BYTES);
+    const int tid = R.tid;
+    uint4 v0 = src[tid], v1 = src[tid + 256], v2 = src[tid + 512], v3 = src[tid + 768], v4 = src[tid + 1024];
+    uint4 v5 = make_uint4(0, 0, 0, 0);
+    if (tid < TAIL) v5 = src[tid + 1280];
+    lds16[tid] = v0; lds16[tid + 256] = v1; lds16[tid + 512] = v2; lds16[tid + 768] = v3; lds16[tid + 1024] = v4;
+    if (tid < TAIL) lds16[tid + 1280] = v5;
+}
+
+__device__ __forceinline__ void fill_clear(const RasterCtx& R) {
+    uint4* lds16 = reinterpret_cast<uint4*>(R.frame);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const int tid = R.tid;
+    lds16[tid] = z; lds16[tid + 256] = z; lds16[tid + 512] = z; lds16[tid + 768] = z; lds16[tid + 1024] = z;
+    if (tid < TAIL) lds16[tid + 1280] = z;
+}
+
+__device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
+    const StampInfo si = R.A.tables->stamps[id];
+    const uint8_t* sp = R.A.stamp_data + si.off;
+    const int h = si.h, npx = si.w * h;
+    for (int p = R.tid; p < npx; p += 256) {
+        int px = p / h, py = p - px * h;
+        uint8_t idx = sp[p];
+        int X = x + px, Y = y + py;
+        if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, R.A.tables->palette[idx]);
+    }
+}
+
+__device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, int h, int fill, bool bordered) {
+    const uint32_t cf = R.A.tables->palette[fill], ce = R.A.tables->palette[R.A.tables->border_of[fill]];
+    for (int p = R.tid; p < w * h; p += 256) {
+        int px = p / h, py = p - px * h;
+        int X = x + px, Y = y + py;
+        bool on_edge = bordered && (px == 0 || py == 0 || px == w - 1 || py == h - 1);
+        if ((unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, on_edge ? ce : cf);
+    }
+}
+
+// d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black); exact for d,a in 0..255
+__device__ __forceinline__ uint32_t darken4(uint32_t v, uint32_t a) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t d = (v >> (8 * k)) & 255u, t = d * a;
+        uint32_t q = (t + 1u + (t >> 8)) >> 8;  // == t / 255 for t <= 65535
+        r |= (d - q) << (8 * k);
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
+    return (uint32_t)(x + 128) | ((uint32_t)(y + 128) << 9) | ((uint32_t)r << 18);
+}
+
+// holes[i] = pack_hole(x, y, r): filled discs (pygame's even-diameter midpoint disc) that stay lit.
+// Contains its own barriers; the caller synchronises before (frame complete) and after (before drawing on top).
+__device__ __forceinline__ void darken(const RasterCtx& R, uint32_t alpha, const uint32_t* holes, int nholes) {
+    const int tid = R.tid;
+    uint32_t* mask = R.mask;
+    if (tid < SCREEN * MASK_WORDS) mask[tid] = 0u;
+    __syncthreads();
+    for (int hI = 0; hI < nholes; ++hI) {  // union of the hole discs as an 84x84 bit mask, one column per lane
+        const uint32_t hv = holes[hI];
+        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
+        if (tid < 2 * r) {
+            int X = hx - r + tid;
+            int lo = R.A.disc_span[(r * 2 * DISC_RMAX + tid) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + tid) * 2 + 1];
+            int y0 = hy + lo, y1 = hy + hi;
+            y0 = y0 < 0 ? 0 : y0;
+            y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
+            if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) {
+                for (int wI = 0; wI < MASK_WORDS; ++wI) {
+                    int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
+                    a0 = a0 < 0 ? 0 : a0;
+                    a1 = a1 > 31 ? 31 : a1;
+                    if (a0 <= a1) {
+                        uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
+                        atomicOr(&mask[X * MASK_WORDS + wI], bits);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // in-place darkening, 4 pixels (12 bytes = 3 dwords) per task: 84 columns x 21 segments
+    uint32_t* f32 = reinterpret_cast<uint32_t*>(R.frame);
+    for (int k = tid; k < SCREEN * 21; k += 256) {
+        int X = k / 21, seg = k - X * 21, y0 = seg * 4;
+        uint32_t lit = (mask[X * MASK_WORDS + (y0 >> 5)] >> (y0 & 31)) & 0xFu;
+        if (lit == 0xFu) continue;
+        uint32_t* p = f32 + X * (COL_BYTES / 4) + seg * 3;
+        uint32_t v0 = p[0], v1 = p[1], v2 = p[2];
+        uint32_t m0 = ((lit & 1u) ? 0x00FFFFFFu : 0u) | ((lit & 2u) ? 0xFF000000u : 0u);
+        uint32_t m1 = ((lit & 2u) ? 0x0000FFFFu : 0u) | ((lit & 4u) ? 0xFFFF0000u : 0u);
+        uint32_t m2 = ((lit & 4u) ? 0x000000FFu : 0u) | ((lit & 8u) ? 0xFFFFFF00u : 0u);
+        uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
+        if (alpha < 255u) {
+            d0 = darken4(v0, alpha);
+            d1 = darken4(v1, alpha);
+            d2 = darken4(v2, alpha);
+        }
+        p[0] = (v0 & m0) | (d0 & ~m0);
+        p[1] = (v1 & m1) | (d1 & ~m1);
+        p[2] = (v2 & m2) | (d2 & ~m2);
+    }
+}
+
+// Composer concept:
+//   struct Desc;                                   trivially copyable, sizeof % 16 == 0
+//   static __device__ bool skip(const Desc&);      true: leave the frame untouched (masked reset)
+//   static __device__ void compose(const Desc&, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
+template <class Composer>
+__global__ __launch_bounds__(256) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
+                                                     uint8_t* __restrict__ obs, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.tid = threadIdx.x;
+    uint4* lds16 = reinterpret_cast<uint4*>(smem);
+    const int tid = threadIdx.x;
+    for (int env = blockIdx.x; env < n; env += gridDim.x) {
+        const typename Composer::Desc d = descs[env];  // workgroup-uniform
+        if (Composer::skip(d)) continue;
+        Composer::compose(d, R);
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(obs + (size_t)env * FRAME_BYTES);
+        uint4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
+        uint4 v5 = make_uint4(0, 0, 0, 0);
+        if (tid < TAIL) v5 = lds16[tid + 1280];
+        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
+        if (tid < TAIL) dst[tid + 1280] = v5;
+        __syncthreads();  // the LDS frame is reused by the next iteration
+    }
+}
+
+template <class Composer>
+inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, uint8_t* obs, int n, hipStream_t s) {
+    static const int tuned = [] {  // MEMGYM_RASTER_GRID overrides the persistent grid size (tuning experiments)
+        const char* e = getenv("MEMGYM_RASTER_GRID");
+        return e ? atoi(e) : RASTER_GRID;
+    }();
+    const int grid = n < tuned ? n : tuned;
+    hipLaunchKernelGGL(raster_kernel<Composer>, dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+}
+
+}  // namespace mg

@@ -191,9 +191,8 @@ inline void rotate_vec(double x, double y, double deg, double& ox, double& oy) {
     }
 }
 
-enum : uint8_t { PAL_KEY = 0, PAL_BODY = 1, PAL_HAND = 2, PAL_OUTLINE = 3, PAL_WHITE = 4, PAL_RED = 5, PAL_COUNT = 8 };
-static const uint8_t PALETTE_RGB[PAL_COUNT][3] = {
-    {0, 0, 0}, {250, 204, 153}, {250, 250, 250}, {50, 50, 50}, {255, 255, 255}, {255, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+// stamp pixel values are ids of the shared palette (mg_raster.hpp): 0 key, 1 body, 2 hand, 3 hand outline, 4 white, 5 red
+enum : uint8_t { PAL_KEY = 0, PAL_BODY = 1, PAL_HAND = 2, PAL_OUTLINE = 3, PAL_WHITE = 4, PAL_RED = 5 };
 
 // 8 agent sprites; sprite k shows rotation 45k degrees (the hands are rotated by 360-45k about the centre).
 inline std::vector<Stamp> build_agent_sprites(double agent_scale, int* radius_out) {
