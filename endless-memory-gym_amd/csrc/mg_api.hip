@@ -53,6 +53,8 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
         if (id == "MortarMayhem-Grid-v0") fam = mg::make_mortar(0, num_envs);
         else if (id == "MortarMayhem-v0") fam = mg::make_mortar(1, num_envs);
         else if (id == "Endless-MortarMayhem-v0") fam = mg::make_mortar(2, num_envs);
+        else if (id == "Endless-SearingSpotlights-v0") fam = mg::make_spot(1, num_envs);
+        else if (id == "SearingSpotlights-v0") fam = mg::make_spot(0, num_envs);
         else {
             mg::set_error("mg_create: environment id not available in this build: " + id);
             return -5;

@@ -118,16 +118,16 @@ __device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, in
     }
 }
 
-// d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black); exact for d,a in 0..255
+// d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black), two bytes at a time in
+// 16-bit lanes: t = d*a <= 65025 and t + 1 + (t >> 8) <= 65280 never carry into the neighbouring lane, and
+// (t + 1 + (t >> 8)) >> 8 == t / 255 for every t <= 65535.
+__device__ __forceinline__ uint32_t darken2(uint32_t x, uint32_t a) {  // x = 0x00dd00dd
+    uint32_t t = x * a;
+    uint32_t q = ((t + 0x00010001u + ((t >> 8) & 0x00FF00FFu)) >> 8) & 0x00FF00FFu;
+    return x - q;
+}
 __device__ __forceinline__ uint32_t darken4(uint32_t v, uint32_t a) {
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t d = (v >> (8 * k)) & 255u, t = d * a;
-        uint32_t q = (t + 1u + (t >> 8)) >> 8;  // == t / 255 for t <= 65535
-        r |= (d - q) << (8 * k);
-    }
-    return r;
+    return darken2(v & 0x00FF00FFu, a) | (darken2((v >> 8) & 0x00FF00FFu, a) << 8);
 }
 
 __device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {

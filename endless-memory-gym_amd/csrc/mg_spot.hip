@@ -1,0 +1,817 @@
+// mg_spot.hip -- Searing Spotlights family on gfx950: Endless-SearingSpotlights-v0 and SearingSpotlights-v0.
+//
+// Reference behaviour reproduced (bit-exact observations, rewards, dones, RNG consumption):
+//   memory_gym/endless_searing_spotlights.py  reset :294-407  step :409-506  _step_spotlight_task :179-231
+//                                             _spawn_coin :256-269  _step_coin_task :271-292
+//   memory_gym/searing_spotlights.py          reset :332-450  step :452-562  helpers :137-330
+//   memory_gym/pygame_assets.py               GridPositionSampler :7-59  Spotlight :61-131  Coin :133-167  Exit :169-220
+//   memory_gym/character_controller.py        CharacterController.step :89-146
+//
+//   spot_step_kernel : one LANE per instance.  float64 spotlight trajectories (lerp of lerp, un-fused multiply-add:
+//                      the library is built with -ffp-contract=off), hit tests, coin/exit logic, grid sampler
+//                      (k-th free cell by per-row disc spans + popcount), RNG.  Spotlight slots are SoA [slot][N];
+//                      the Python list semantics (append / remove-while-iterating) live in a 16-nibble order word.
+//   raster_kernel<SpotComposer> : chessboard template -> coin(s)/exit -> agent -> darken(alpha, holes) -> coin(s)
+//                      shown above the dark layer -> top bar.
+#include <memory>
+
+#include "mg_atlas.hpp"
+#include "mg_device.hpp"
+#include "mg_family.hpp"
+#include "mg_raster.hpp"
+#include "mg_stamps.hpp"
+
+namespace mg {
+
+constexpr int SLOTS = 16;
+constexpr int MAX_COINS = 8;
+constexpr int MAX_HOLES = 24;
+
+struct SpotParams {
+    int endless, n;
+    int max_steps, steps_per_coin, initial_spawns, spawn_interval, interval0, num_spawns;
+    int visual_feedback, dim_duration, dim_step, light_threshold;
+    int coin_enabled, coin_show_duration, coins_visible, sample_agent_position, show_last_action, show_last_positive_reward;
+    int r_lo, r_hi;                 // radius = integers(r_lo, r_hi)
+    int agent_radius, sprite_dim, coin_radius;
+    int v_axis_i, v_diag_i;
+    int spawn_clamp;                // _process_spawn_pos offset
+    int bar_x, bar_w, quarter;
+    double speed_lo, speed_hi, damage, agent_health, exit_radius, half_diag;
+    double r_inside, r_outside, r_death, r_coin, r_exit;
+    OptList num_coins;
+    const double* cos_tab;          // [360] integer degrees, exact for multiples of 90
+    const double* sin_tab;
+};
+
+struct __attribute__((aligned(16))) SpotCore {
+    int16_t ax, ay;
+    uint8_t rot8, alpha, la0, la1;
+    uint8_t red_w, n_spots, exit_open, n_coins;
+    uint8_t n_intervals, last_pos, bg_red, has_coin;
+    int32_t spawn_timer, t, coin_t, coins_collected;
+    int16_t coin_x, coin_y, exit_x, exit_y;
+    int32_t num_coins, ep_len;
+    double health, ep_sum;
+    uint64_t order;  // spotlight list: nibble k = slot of the k-th element
+    uint32_t free_mask, pad;
+};
+static_assert(sizeof(SpotCore) == 80, "SpotCore must be 80 bytes");
+
+struct __attribute__((aligned(16))) SpotDesc {
+    uint8_t valid, bg, sprite, alpha;
+    int16_t sx, sy;
+    uint8_t n_holes, n_coins, coin_above, red_w;
+    uint8_t c_base, c_act0, c_act1, c_bar;
+    uint8_t bar_x, bar_w, quarter, exit_stamp;
+    int16_t exit_x, exit_y;
+    uint32_t pad[2];
+    uint32_t coins[MAX_COINS];  // (x+128) | (y+128)<<16 : top-left of the coin stamp
+    uint32_t holes[MAX_HOLES];
+};
+static_assert(sizeof(SpotDesc) == 160, "SpotDesc must be 160 bytes");
+
+constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
+
+struct SpotComposer {
+    typedef SpotDesc Desc;
+    static __device__ __forceinline__ bool skip(const Desc& d) { return d.valid == 0; }
+    static __device__ __forceinline__ void coins(const Desc& d, const RasterCtx& R) {
+        for (int k = 0; k < d.n_coins; ++k) stamp(R, ST_COIN, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128);
+    }
+    static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
+        fill_template(R, d.bg);
+        __syncthreads();
+        if (!d.coin_above && d.n_coins) {
+            coins(d, R);
+            __syncthreads();
+        }
+        if (d.exit_stamp != 0xFF) {
+            stamp(R, d.exit_stamp, d.exit_x, d.exit_y);
+            __syncthreads();
+        }
+        stamp(R, d.sprite, d.sx, d.sy);
+        __syncthreads();
+        if (d.alpha) {
+            darken(R, d.alpha, d.holes, d.n_holes);
+            __syncthreads();
+        }
+        if (d.coin_above && d.n_coins) {
+            coins(d, R);
+            __syncthreads();
+        }
+        // top bar: rows y < 4 of every column; priority reward bar > action rects > red > green > base
+        const AtlasTables* T = R.A.tables;
+        for (int p = R.tid; p < SCREEN * 4; p += 256) {
+            int x = p >> 2, y = p & 3;
+            int c = d.c_base;
+            if (x < 2 * d.quarter) c = x < d.red_w ? C_RED : C_GREEN;
+            else if (d.c_act0 != 0xFF) c = x < 3 * d.quarter ? d.c_act0 : d.c_act1;
+            if (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w) c = d.c_bar;
+            if (c != 0xFF) put_rgb(R.frame, x, y, T->palette[c]);
+        }
+    }
+};
+
+struct SpotIO {
+    SpotCore* core;
+    double *sp_t, *sp_speed, *sp_sx, *sp_sy, *sp_tx, *sp_ty, *sp_ox, *sp_oy;  // [slot][N]
+    uint8_t *sp_r, *sp_done;                                                    // [slot][N]
+    uint32_t* coins;  // [N][MAX_COINS] (x | y<<16), finite variant
+    RngSoA rng;
+    SpotDesc* desc;
+    int* err;
+};
+
+__device__ __forceinline__ int isqrt_floor(int v) {
+    int r = (int)sqrt((double)v);
+    while (r * r > v) --r;
+    while ((r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+
+// GridPositionSampler.sample: k-th un-blocked cell (row-major) of the 84x84 grid; discs: (x, y, r) with strict <
+__device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, int nd, int* ox, int* oy) {
+    int free_total = 0;
+    // pass 1: count
+    for (int pass = 0; pass < 2; ++pass) {
+        int k = 0;
+        if (pass == 1) k = g.integers(0, free_total);
+        for (int y = 0; y < SCREEN; ++y) {
+            uint64_t m_lo = 0;  // bits 0..63
+            uint32_t m_hi = 0;  // bits 64..83
+            for (int d = 0; d < nd; ++d) {
+                int ddy = y - dy[d], rem = dr[d] * dr[d] - ddy * ddy - 1;
+                if (rem < 0) continue;
+                int hw = isqrt_floor(rem);
+                int a = dx[d] - hw, b = dx[d] + hw;
+                a = a < 0 ? 0 : a;
+                b = b > SCREEN - 1 ? SCREEN - 1 : b;
+                if (a > b) continue;
+                for (int x = a; x <= b; ++x) {
+                    if (x < 64) m_lo |= 1ull << x;
+                    else m_hi |= 1u << (x - 64);
+                }
+            }
+            int fr = SCREEN - __popcll(m_lo) - __popc(m_hi);
+            if (pass == 0) {
+                free_total += fr;
+            } else {
+                if (k < fr) {
+                    for (int x = 0; x < SCREEN; ++x) {
+                        bool blocked = x < 64 ? ((m_lo >> x) & 1ull) : ((m_hi >> (x - 64)) & 1u);
+                        if (!blocked) {
+                            if (k == 0) {
+                                *ox = x;
+                                *oy = y;
+                                return free_total;
+                            }
+                            --k;
+                        }
+                    }
+                }
+                k -= fr;
+            }
+        }
+    }
+    *ox = 0;
+    *oy = 0;
+    return free_total;
+}
+
+__device__ __forceinline__ void clamp_spawn(const SpotParams& P, int& x, int& y) {
+    int off = P.spawn_clamp;
+    if (x < off) x = off; else if (x > SCREEN - off) x = SCREEN - off;
+    if (y < off) y = off; else if (y > SCREEN - off) y = SCREEN - off;
+}
+
+// Spotlight.__init__: 5 draws (radius, speed, start angle, target delta, offset delta)
+__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, SpotCore& s, Pcg& g) {
+    int radius = g.integers(P.r_lo, P.r_hi);
+    double speed = g.uniform(P.speed_lo, P.speed_hi);
+    int start = g.integers(0, 360);
+    int target = start + 180 + g.integers(-45, 45);
+    int offset = target + g.integers(-135, 135);
+    if (s.n_spots >= SLOTS || s.free_mask == 0) {
+        atomicOr(io.err, 1);
+        return;
+    }
+    int slot = __ffs(s.free_mask) - 1;
+    s.free_mask &= ~(1u << slot);
+    s.order |= (uint64_t)slot << (4 * s.n_spots);
+    s.n_spots++;
+    size_t k = (size_t)slot * P.n + i;
+    double R = P.half_diag + (double)radius, c = SCREEN / 2;
+    io.sp_r[k] = (uint8_t)radius;
+    io.sp_done[k] = 0;
+    io.sp_t[k] = 0.0;
+    io.sp_speed[k] = speed;
+    io.sp_sx[k] = c + P.cos_tab[start % 360] * R;
+    io.sp_sy[k] = c + P.sin_tab[start % 360] * R;
+    io.sp_tx[k] = c + P.cos_tab[target % 360] * R;
+    io.sp_ty[k] = c + P.sin_tab[target % 360] * R;
+    io.sp_ox[k] = c + P.cos_tab[offset % 360] * R;
+    io.sp_oy[k] = c + P.sin_tab[offset % 360] * R;
+}
+
+__device__ void fill_topbar(const SpotParams& P, const SpotCore& s, SpotDesc& d, bool reset_frame, int a0, int a1) {
+    d.c_base = P.endless ? C_BLACK : C_GREY50;
+    d.red_w = s.red_w;
+    d.quarter = (uint8_t)P.quarter;
+    const uint8_t ACT[3] = {C_GREY120, C_PURPLE, C_ACT_ORANGE};
+    d.c_act0 = d.c_act1 = 0xFF;
+    if (P.show_last_action) {
+        d.c_act0 = ACT[a0];
+        d.c_act1 = ACT[a1];
+    }
+    d.c_bar = 0xFF;
+    d.bar_x = (uint8_t)P.bar_x;
+    d.bar_w = (uint8_t)P.bar_w;
+    if (!reset_frame && P.show_last_positive_reward) d.c_bar = s.last_pos ? C_YELLOW : C_GREY50;
+}
+
+__device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, SpotCore& s, Pcg& g, SpotDesc& d, float* gt) {
+    s.t = 0;
+    s.coin_t = 0;
+    s.ep_sum = 0.0;
+    s.ep_len = 0;
+    s.la0 = s.la1 = 0;
+    s.rot8 = (uint8_t)g.integers(0, 8);  // choice([0, 45, ..., 315])
+    int bx[1 + MAX_COINS + 1], by[1 + MAX_COINS + 1], br[1 + MAX_COINS + 1], nb = 0;
+    int ax, ay;
+    if (P.sample_agent_position) {
+        int cx, cy;
+        sample_cell(g, bx, by, br, 0, &cx, &cy);
+        bx[nb] = cx; by[nb] = cy; br[nb++] = 28;
+        ax = cx + g.integers(2, 4);
+        ay = cy + g.integers(2, 4);
+    } else {
+        ax = SCREEN / 2;
+        ay = SCREEN / 2;
+        bx[nb] = ax; by[nb] = ay; br[nb++] = 21;
+    }
+    s.ax = (int16_t)ax;
+    s.ay = (int16_t)ay;
+    s.health = P.agent_health;
+    s.red_w = 0;
+    s.last_pos = 0;
+    s.alpha = (uint8_t)(P.dim_duration > 0 ? 0 : P.light_threshold);
+    s.n_spots = 0;
+    s.order = 0;
+    s.free_mask = 0xFFFFu;
+    s.spawn_timer = 0;
+    s.n_intervals = (uint8_t)P.num_spawns;
+    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, s, g);
+    s.coins_collected = 0;
+    s.n_coins = 0;
+    s.has_coin = 0;
+    s.exit_open = 0;
+    uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
+    if (P.endless) {
+        if (P.coin_enabled) {  // _spawn_coin: the sampler is reset first, self.coin is None -> nothing blocked
+            int cx, cy;
+            sample_cell(g, bx, by, br, 0, &cx, &cy);
+            cx += g.integers(2, 4);
+            cy += g.integers(2, 4);
+            clamp_spawn(P, cx, cy);
+            s.coin_x = (int16_t)cx;
+            s.coin_y = (int16_t)cy;
+            s.has_coin = 1;
+            s.n_coins = 1;
+        }
+    } else {
+        int nc = P.num_coins.n > 0 ? choice(g, P.num_coins) : 0;
+        s.num_coins = nc;
+        for (int k = 0; k < nc && k < MAX_COINS; ++k) {
+            int cx, cy;
+            sample_cell(g, bx, by, br, nb, &cx, &cy);
+            bx[nb] = cx; by[nb] = cy; br[nb++] = 21;
+            cx += g.integers(2, 4);
+            cy += g.integers(2, 4);
+            clamp_spawn(P, cx, cy);
+            coins[k] = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
+            s.n_coins++;
+        }
+        int ex, ey;
+        sample_cell(g, bx, by, br, nb, &ex, &ey);
+        ex += g.integers(2, 4);
+        ey += g.integers(2, 4);
+        clamp_spawn(P, ex, ey);
+        s.exit_x = (int16_t)ex;
+        s.exit_y = (int16_t)ey;
+    }
+    s.bg_red = 0;
+
+    // reset frame: blue board, sprite index 0 (not the sampled rotation), dark layer at the reset alpha
+    // (its hole pattern is whatever the previous episode left -- only visible if light_dim_off_duration == 0,
+    // which this build rejects), coin(s) shown above the dark layer while coin_t < coin_show_duration
+    memset(&d, 0, sizeof(d));
+    d.valid = 1;
+    d.bg = 0;
+    d.sprite = 0;
+    d.sx = (int16_t)(ax - P.sprite_dim / 2);
+    d.sy = (int16_t)(ay - P.sprite_dim / 2);
+    d.alpha = s.alpha;
+    d.n_holes = 0;
+    d.exit_stamp = 0xFF;
+    if (P.endless) {
+        d.n_coins = s.n_coins;
+        d.coin_above = (P.coins_visible || s.coin_t < P.coin_show_duration) ? 1 : 0;
+        d.coins[0] = (uint32_t)(s.coin_x - P.coin_radius + 128) | ((uint32_t)(s.coin_y - P.coin_radius + 128) << 16);
+    } else {
+        d.n_coins = s.n_coins;
+        d.coin_above = P.coins_visible ? 1 : 0;
+        for (int k = 0; k < s.n_coins; ++k) {
+            int cx = (int)(int16_t)(coins[k] & 0xFFFF), cy = (int)(coins[k] >> 16);
+            d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+        }
+        d.exit_stamp = ST_EXIT_CLOSED;
+        d.exit_x = (int16_t)(s.exit_x - 5);
+        d.exit_y = (int16_t)(s.exit_y - 5);
+    }
+    fill_topbar(P, s, d, true, 0, 0);
+    if (gt) {
+        gt[0] = (float)((double)ax / SCREEN);
+        gt[1] = (float)((double)ay / SCREEN);
+        gt[2] = (float)(P.coin_enabled ? (double)s.coin_x / SCREEN : 0.0);
+        gt[3] = (float)(P.coin_enabled ? (double)s.coin_y / SCREEN : 0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void spot_init_kernel(int n, SpotCore* core) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SpotCore s;
+    memset(&s, 0, sizeof(s));
+    core[i] = s;
+}
+
+__global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io, const int64_t* seeds, const uint8_t* mask,
+                                                         float* gt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    if (mask && !mask[i]) {
+        io.desc[i].valid = 0;
+        return;
+    }
+    Pcg g;
+    if (seeds) g.seed((uint64_t)seeds[i]);
+    else g.load(io.rng, i);
+    SpotCore s = io.core[i];
+    SpotDesc d;
+    spot_reset(P, io, i, s, g, d, (gt && P.endless) ? gt + 4 * i : nullptr);
+    io.core[i] = s;
+    g.store(io.rng, i);
+    io.desc[i] = d;
+}
+
+__global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io, const int32_t* actions, float* reward_out,
+                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    SpotCore s = io.core[i];
+    Pcg g;
+    g.load(io.rng, i);
+    uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
+
+    // CharacterController.step(action, walkable_rect)
+    int a0 = actions[2 * i], a1 = actions[2 * i + 1];
+    int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
+    int rot = s.rot8 * 45;
+    if (a0 == 1) rot = 90;
+    if (a0 == 2) rot = 270;
+    if (a1 == 1) rot = 0;
+    if (a1 == 2) rot = 180;
+    if (dxs < 0 && dys < 0) rot = 45;
+    if (dxs < 0 && dys > 0) rot = 135;
+    if (dxs > 0 && dys < 0) rot = 315;
+    if (dxs > 0 && dys > 0) rot = 225;
+    s.rot8 = (uint8_t)(rot / 45);
+    int v = (dxs != 0 && dys != 0) ? P.v_diag_i : P.v_axis_i;
+    int ax = s.ax + dxs * v, ay = s.ay + dys * v;
+    {   // walkable_rect = (0, 4, 84, 80)
+        int lox = P.agent_radius, hix = SCREEN - P.agent_radius, loy = 4 + P.agent_radius, hiy = SCREEN - P.agent_radius;
+        ax = ax > hix ? hix : ax;
+        ax = ax < lox ? lox : ax;
+        ay = ay > hiy ? hiy : ay;
+        ay = ay < loy ? loy : ay;
+    }
+    s.ax = (int16_t)ax;
+    s.ay = (int16_t)ay;
+    // the top bar shows the PREVIOUS action
+    int shown0 = s.la0, shown1 = s.la1;
+    if (P.endless || P.show_last_action) {
+        s.la0 = (uint8_t)a0;
+        s.la1 = (uint8_t)a1;
+    }
+    // dim the light until off
+    if ((int)s.alpha <= P.light_threshold) {
+        int a = P.dim_duration > 0 ? (int)s.alpha + P.dim_step : P.light_threshold;
+        s.alpha = (uint8_t)(a > 255 ? 255 : a);
+    }
+
+    SpotDesc d;
+    memset(&d, 0, sizeof(d));
+    d.valid = 1;
+
+    // ---- spotlight task ----
+    double reward = 0.0, r = 0.0;
+    bool spot_done = false;
+    s.spawn_timer++;
+    if (P.endless) {
+        if (s.spawn_timer >= P.spawn_interval) {
+            new_spot(P, io, i, s, g);
+            s.spawn_timer = 0;
+        }
+    } else if (s.n_intervals > 0) {
+        if (s.spawn_timer >= P.interval0) {
+            new_spot(P, io, i, s, g);
+            s.n_intervals--;
+            s.spawn_timer = 0;
+        }
+    }
+    int hit = 0, nh = 0;
+    for (int pos = 0; pos < s.n_spots; ++pos) {  // list mutated while iterated: the element after a removed one is skipped
+        int slot = (int)((s.order >> (4 * pos)) & 15u);
+        size_t k = (size_t)slot * P.n + i;
+        if (io.sp_done[k]) {
+            uint64_t low = s.order & ((1ull << (4 * pos)) - 1ull);
+            uint64_t high = pos == 15 ? 0ull : (s.order >> (4 * (pos + 1))) << (4 * pos);
+            s.order = low | high;
+            s.free_mask |= 1u << slot;
+            s.n_spots--;
+        } else {
+            double t = io.sp_t[k];
+            double lx = io.sp_tx[k] * (1 - t) + io.sp_ox[k] * t, ly = io.sp_ty[k] * (1 - t) + io.sp_oy[k] * t;
+            double cx = io.sp_sx[k] * (1 - t) + lx * t, cy = io.sp_sy[k] * (1 - t) + ly * t;
+            int radius = io.sp_r[k];
+            if (nh < MAX_HOLES) d.holes[nh++] = pack_hole((int)cx, (int)cy, radius);
+            t += io.sp_speed[k];
+            if (t >= 1.0) {
+                t = 1.0;
+                io.sp_done[k] = 1;
+            }
+            io.sp_t[k] = t;
+            double ddx = (double)ax - cx, ddy = (double)ay - cy;
+            if (sqrt(ddx * ddx + ddy * ddy) <= (double)(radius + P.agent_radius)) hit++;
+        }
+    }
+    if (hit > 0) {
+        s.health -= P.damage;
+        r += P.r_inside;
+        s.red_w = (uint8_t)(int)((SCREEN / 2) * (1 - s.health / P.agent_health));
+        s.bg_red = P.visual_feedback ? 1 : 0;
+    } else {
+        s.bg_red = 0;
+        r += P.r_outside;
+    }
+    if (s.health <= 0) {
+        spot_done = true;
+        r += P.r_death;
+    }
+    reward += r;
+
+    // ---- coin / exit tasks ----
+    bool done = false;
+    int success = 0;
+    if (P.endless) {
+        if (P.coin_enabled) {
+            double cr = 0.0;
+            double ddx = (double)ax - (double)s.coin_x, ddy = (double)ay - (double)s.coin_y;
+            if (sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius)) {
+                cr += P.r_coin;
+                s.coins_collected++;
+                s.coin_t = 0;
+                // _spawn_coin: sampler reset, previous coin blocked with r = 28
+                int bx[1] = {s.coin_x}, by[1] = {s.coin_y}, br[1] = {28};
+                int cx, cy;
+                sample_cell(g, bx, by, br, 1, &cx, &cy);
+                cx += g.integers(2, 4);
+                cy += g.integers(2, 4);
+                clamp_spawn(P, cx, cy);
+                s.coin_x = (int16_t)cx;
+                s.coin_y = (int16_t)cy;
+            }
+            reward += cr;
+        }
+        if (spot_done) done = true;
+        s.t++;
+        s.coin_t++;
+        if (s.coin_t == P.steps_per_coin && P.coin_enabled) done = true;
+        if (s.t == P.max_steps) done = true;
+    } else {
+        bool coins_done;
+        if (s.num_coins > 0) {
+            double cr = 0.0;
+            for (int k = 0; k < s.n_coins; ++k) {  // remove-while-iterating: the coin after a collected one is skipped
+                int cx = (int)(int16_t)(coins[k] & 0xFFFF), cy = (int)(coins[k] >> 16);
+                double ddx = (double)ax - cx, ddy = (double)ay - cy;
+                if (sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius)) {
+                    for (int j = k; j < s.n_coins - 1; ++j) coins[j] = coins[j + 1];
+                    s.n_coins--;
+                    cr += P.r_coin;
+                    s.coins_collected++;
+                }
+            }
+            coins_done = s.n_coins == 0;
+            reward += cr;
+        } else {
+            coins_done = true;
+        }
+        bool exit_done = false;
+        double er = 0.0;
+        if (coins_done) {
+            s.exit_open = 1;
+            double ddx = (double)ax - (double)s.exit_x, ddy = (double)ay - (double)s.exit_y;
+            if (sqrt(ddx * ddx + ddy * ddy) <= P.exit_radius + (double)P.agent_radius) {
+                exit_done = true;
+                er = P.r_exit;
+            }
+        }
+        reward += er;
+        if (spot_done) done = true;
+        else if (coins_done && exit_done) { done = true; success = 1; }
+        s.t++;
+        if (s.t == P.max_steps) done = true;
+    }
+    bool shown_last_pos = s.last_pos;
+    if (P.show_last_positive_reward) s.last_pos = reward > 0 ? 1 : 0;
+    s.ep_sum += reward;
+    s.ep_len++;
+
+    if (done) {
+        if (info.ep_reward_dev) info.ep_reward_dev[i] = s.ep_sum;
+        if (info.ep_length_dev) info.ep_length_dev[i] = s.ep_len;
+        if (info.aux_dev[0]) info.aux_dev[0][i] = (float)(s.health / P.agent_health);
+        if (P.endless) {
+            if (info.aux_dev[1]) info.aux_dev[1][i] = (float)s.coins_collected;
+        } else {
+            if (info.aux_dev[1]) info.aux_dev[1][i] = (float)((double)s.coins_collected / (double)s.num_coins);
+            if (info.aux_dev[2]) info.aux_dev[2][i] = (float)success;
+        }
+    }
+    reward_out[i] = (float)reward;
+    done_out[i] = done ? 1 : 0;
+
+    if (done && autoreset) {
+        spot_reset(P, io, i, s, g, d, (gt && P.endless) ? gt + 4 * i : nullptr);
+    } else {
+        d.bg = s.bg_red;
+        d.sprite = s.rot8;
+        d.sx = (int16_t)(ax - P.sprite_dim / 2);
+        d.sy = (int16_t)(ay - P.sprite_dim / 2);
+        d.alpha = s.alpha;
+        d.n_holes = (uint8_t)nh;
+        d.exit_stamp = 0xFF;
+        if (P.endless) {
+            d.n_coins = P.coin_enabled ? 1 : 0;
+            d.coin_above = (P.coins_visible || s.coin_t < P.coin_show_duration) ? 1 : 0;
+            d.coins[0] = (uint32_t)(s.coin_x - P.coin_radius + 128) | ((uint32_t)(s.coin_y - P.coin_radius + 128) << 16);
+        } else {
+            d.n_coins = s.n_coins;
+            d.coin_above = P.coins_visible ? 1 : 0;
+            for (int k = 0; k < s.n_coins; ++k) {
+                int cx = (int)(int16_t)(coins[k] & 0xFFFF), cy = (int)(coins[k] >> 16);
+                d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+            }
+            d.exit_stamp = s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED;
+            d.exit_x = (int16_t)(s.exit_x - 5);
+            d.exit_y = (int16_t)(s.exit_y - 5);
+        }
+        SpotCore tb = s;
+        tb.last_pos = shown_last_pos;  // the bar shows whether the PREVIOUS reward was positive
+        fill_topbar(P, tb, d, false, shown0, shown1);
+        if (gt && P.endless) {
+            gt[4 * i + 0] = (float)((double)ax / SCREEN);
+            gt[4 * i + 1] = (float)((double)ay / SCREEN);
+            gt[4 * i + 2] = (float)(P.coin_enabled ? (double)s.coin_x / SCREEN : 0.0);
+            gt[4 * i + 3] = (float)(P.coin_enabled ? (double)s.coin_y / SCREEN : 0.0);
+        }
+    }
+    g.store(io.rng, i);
+    io.core[i] = s;
+    io.desc[i] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static const double SCALE = 0.25;
+
+// sin / cos by two separate libm calls (a merged sincos() differs by 1 ulp for a few integer-degree angles)
+static __attribute__((noinline)) double sin_only(double x) { volatile double v = x; return std::sin(v); }
+static __attribute__((noinline)) double cos_only(double x) { volatile double v = x; return std::cos(v); }
+
+class SpotFamily : public Family {
+   public:
+    SpotFamily(int endless, int n) : n_(n) {
+        memset(&P_, 0, sizeof(P_));
+        P_.endless = endless;
+        P_.n = n;
+        spot_min_radius_ = 30.0 * SCALE; spot_max_radius_ = 55.0 * SCALE;
+        P_.speed_lo = 0.0025; P_.speed_hi = 0.0075; P_.damage = 1.0;
+        P_.visual_feedback = 1; dim_duration_ = 6; P_.light_threshold = 255;
+        coin_scale_ = 1.5 * SCALE; agent_speed_ = 12.0 * SCALE; agent_scale_ = 1.0 * SCALE; exit_scale_ = 2.0 * SCALE;
+        P_.sample_agent_position = 1; P_.show_last_action = 1; P_.show_last_positive_reward = 1;
+        P_.r_coin = 0.25;
+        if (endless) {
+            P_.max_steps = -1; P_.steps_per_coin = 160; P_.initial_spawns = 3; P_.spawn_interval = 50;
+            P_.coin_enabled = 1; P_.coin_show_duration = 6; P_.agent_health = 10;
+        } else {
+            P_.max_steps = 256; P_.initial_spawns = 4; P_.num_spawns = 30;
+            initial_spawn_interval_ = 30; spawn_interval_threshold_ = 10;
+            P_.num_coins.n = 1; P_.num_coins.v[0] = 1; P_.agent_health = 5; P_.r_exit = 1.0;
+        }
+        core_.alloc(n);
+        for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) a->alloc((size_t)SLOTS * n);
+        sp_r_.alloc((size_t)SLOTS * n);
+        sp_done_.alloc((size_t)SLOTS * n);
+        coins_.alloc((size_t)MAX_COINS * n);
+        desc_.alloc(n);
+        rng_.alloc(n);
+        err_.alloc(1);
+        std::vector<double> ct(360), st(360);
+        for (int a = 0; a < 360; ++a) {
+            if (a % 90 == 0) {
+                static const double C4[4] = {1, 0, -1, 0}, S4[4] = {0, 1, 0, -1};
+                ct[a] = C4[a / 90];
+                st[a] = S4[a / 90];
+            } else {
+                double rad = (double)a * M_PI / 180.0;
+                ct[a] = cos_only(rad);
+                st[a] = sin_only(rad);
+            }
+        }
+        cos_.upload(ct);
+        sin_.upload(st);
+        hipLaunchKernelGGL(spot_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, core_.p);
+        MG_HIP(hipDeviceSynchronize());
+        rebuild();
+    }
+
+    int action_dim() const override { return 2; }
+    int gt_dim() const override { return P_.endless ? 4 : 0; }
+    const char* info_name(int k) const override {
+        if (k == 0) return "agent_health";
+        if (k == 1) return "coins_collected";
+        if (k == 2 && !P_.endless) return "success";
+        return nullptr;
+    }
+
+    void set_option(const std::string& key, const double* v, int n) override {
+        const bool e = P_.endless;
+        auto I = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
+        auto B = [&](int& dst) { dst = v[0] != 0.0; };
+        auto must_be = [&](bool ok) { if (!ok) throw OptionError{-3, "reset parameter " + key + ": this value is not supported by the MI355X build"}; };
+        if (key == "max_steps") I(P_.max_steps);
+        else if (key == "initial_spawns") { I(P_.initial_spawns); must_be(P_.initial_spawns >= 0 && P_.initial_spawns <= SLOTS); }
+        else if (key == "spot_min_radius") { spot_min_radius_ = v[0]; dirty_ = true; }
+        else if (key == "spot_max_radius") { spot_max_radius_ = v[0]; dirty_ = true; }
+        else if (key == "spot_min_speed") P_.speed_lo = v[0];
+        else if (key == "spot_max_speed") P_.speed_hi = v[0];
+        else if (key == "spot_damage") P_.damage = v[0];
+        else if (key == "visual_feedback") B(P_.visual_feedback);
+        else if (key == "black_background" || key == "hide_chessboard") must_be(v[0] == 0.0);
+        else if (key == "light_dim_off_duration") { I(dim_duration_); must_be(dim_duration_ > 0); dirty_ = true; }
+        else if (key == "light_threshold") { I(P_.light_threshold); must_be(P_.light_threshold == 255); }
+        else if (key == "coin_scale") { coin_scale_ = v[0]; dirty_ = true; }
+        else if (key == "coins_visible") B(P_.coins_visible);
+        else if (key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
+        else if (key == "agent_health") P_.agent_health = v[0];
+        else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
+        else if (key == "agent_visible") must_be(v[0] == 0.0);
+        else if (key == "sample_agent_position") B(P_.sample_agent_position);
+        else if (key == "show_last_action") B(P_.show_last_action);
+        else if (key == "show_last_positive_reward") B(P_.show_last_positive_reward);
+        else if (key == "reward_inside_spotlight") P_.r_inside = v[0];
+        else if (key == "reward_outside_spotlight") P_.r_outside = v[0];
+        else if (key == "reward_death") P_.r_death = v[0];
+        else if (key == "reward_coin") P_.r_coin = v[0];
+        else if (e && key == "steps_per_coin") I(P_.steps_per_coin);
+        else if (e && key == "spawn_interval") I(P_.spawn_interval);
+        else if (e && key == "coin_enabled") B(P_.coin_enabled);
+        else if (e && key == "coin_show_duration") I(P_.coin_show_duration);
+        else if (!e && key == "num_spawns") { I(P_.num_spawns); must_be(P_.num_spawns >= 0 && P_.num_spawns <= 255); }
+        else if (!e && key == "initial_spawn_interval") { initial_spawn_interval_ = v[0]; dirty_ = true; }
+        else if (!e && key == "spawn_interval_threshold") { spawn_interval_threshold_ = v[0]; dirty_ = true; }
+        else if (!e && key == "spawn_interval_decay") { /* only intervals[0] is ever read (pop() takes the last) */ }
+        else if (!e && key == "num_coins") {
+            must_be(n >= 1 && n <= 8);
+            P_.num_coins.n = n;
+            for (int k = 0; k < n; ++k) {
+                P_.num_coins.v[k] = to_int_checked(v[k], key.c_str());
+                must_be(P_.num_coins.v[k] >= 1 && P_.num_coins.v[k] <= MAX_COINS);
+            }
+        }
+        else if (!e && key == "use_exit") must_be(v[0] != 0.0);  // use_exit=False crashes the reference itself
+        else if (!e && key == "exit_scale") { exit_scale_ = v[0]; dirty_ = true; }
+        else if (!e && key == "exit_visible") must_be(v[0] == 0.0);
+        else if (!e && key == "reward_exit") P_.r_exit = v[0];
+        else if (!e && key == "reward_max_steps") {}
+        else throw OptionError{-2, "unknown reset parameter " + key};
+    }
+
+    void reset(const int64_t* seeds, const uint8_t* mask, uint8_t* obs, float* gt, hipStream_t s) override {
+        if (dirty_) rebuild();
+        if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
+        if (seeds) seeded_ = true;
+        hipLaunchKernelGGL(spot_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        raster(obs, s);
+    }
+
+    void step(const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,
+              int autoreset, hipStream_t s) override {
+        if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next step");
+        mg_info_buffers ib;
+        memset(&ib, 0, sizeof(ib));
+        if (info) ib = *info;
+        prof.begin(0, s);
+        hipLaunchKernelGGL(spot_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+        prof.end(0, s);
+        prof.begin(1, s);
+        raster(obs, s);
+        prof.end(1, s);
+    }
+
+    std::vector<std::pair<void*, size_t>> state_blobs() override {
+        std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {coins_.p, coins_.bytes()}, {sp_r_.p, sp_r_.bytes()},
+                                                  {sp_done_.p, sp_done_.bytes()}};
+        for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) v.push_back({a->p, a->bytes()});
+        rng_.blobs(v);
+        return v;
+    }
+    void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+
+   private:
+    SpotIO io() {
+        SpotIO o;
+        o.core = core_.p;
+        o.sp_t = sp_t_.p; o.sp_speed = sp_speed_.p; o.sp_sx = sp_sx_.p; o.sp_sy = sp_sy_.p;
+        o.sp_tx = sp_tx_.p; o.sp_ty = sp_ty_.p; o.sp_ox = sp_ox_.p; o.sp_oy = sp_oy_.p;
+        o.sp_r = sp_r_.p; o.sp_done = sp_done_.p;
+        o.coins = coins_.p;
+        o.rng = rng_.view();
+        o.desc = desc_.p;
+        o.err = err_.p;
+        return o;
+    }
+
+    void rebuild() {
+        int radius = 0;
+        std::vector<Stamp> sprites = build_agent_sprites(agent_scale_, &radius);
+        P_.agent_radius = radius;
+        P_.sprite_dim = sprites[0].w;
+        double inv = 1.0 / std::sqrt(2.0);
+        P_.v_axis_i = (int)((1.0 / 1.0) * agent_speed_);
+        P_.v_diag_i = (int)(inv * agent_speed_);
+        P_.r_lo = (int)spot_min_radius_;
+        P_.r_hi = (int)(spot_max_radius_ + 1);
+        if (P_.r_hi - 1 > DISC_RMAX || P_.r_lo < 1 || P_.r_hi <= P_.r_lo) throw OptionError{-3, "spot radius range not supported"};
+        P_.dim_duration = dim_duration_;
+        P_.dim_step = (int)(255.0 / dim_duration_);
+        P_.coin_radius = (int)(10 * coin_scale_);
+        P_.spawn_clamp = (int)(30 * SCALE);
+        P_.quarter = (int)(SCREEN / 4);
+        if (P_.show_last_action) { P_.bar_x = (int)(P_.quarter * 2.75); P_.bar_w = (int)(P_.quarter * 0.5); }
+        else { P_.bar_x = P_.quarter * 2; P_.bar_w = P_.quarter * 2; }
+        P_.half_diag = std::sqrt(std::pow((double)SCREEN, 2) + std::pow((double)SCREEN, 2)) / 2;
+        P_.exit_radius = 20.0 / 2 * exit_scale_;
+        P_.interval0 = (int)(initial_spawn_interval_ + spawn_interval_threshold_);
+        P_.cos_tab = cos_.p;
+        P_.sin_tab = sin_.p;
+
+        atlas_.reset(new Atlas());
+        for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
+        atlas_->add_stamp(build_coin(coin_scale_));       // 8
+        if (!P_.endless) {
+            if (exit_scale_ != 2.0 * SCALE) throw OptionError{-3, "exit_scale other than the default is not supported"};
+            atlas_->add_stamp(build_exit(exit_scale_, false));  // 9
+            atlas_->add_stamp(build_exit(exit_scale_, true));   // 10
+        }
+        atlas_->set_templates(build_chessboards(SCALE, SCREEN));
+        atlas_->upload();
+        dirty_ = false;
+    }
+
+    void raster(uint8_t* obs, hipStream_t s) {
+        launch_raster<SpotComposer>(desc_.p, atlas_->dev(), obs, n_, s);
+        MG_HIP(hipGetLastError());
+    }
+
+    int n_;
+    SpotParams P_;
+    double spot_min_radius_, spot_max_radius_, coin_scale_, agent_speed_, agent_scale_, exit_scale_;
+    double initial_spawn_interval_ = 30, spawn_interval_threshold_ = 10;
+    int dim_duration_;
+    bool dirty_ = true, seeded_ = false;
+    std::unique_ptr<Atlas> atlas_;
+    DevArray<SpotCore> core_;
+    DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;
+    DevArray<uint8_t> sp_r_, sp_done_;
+    DevArray<uint32_t> coins_;
+    DevArray<SpotDesc> desc_;
+    DevArray<int> err_;
+    RngStore rng_;
+};
+
+Family* make_spot(int endless, int num_envs) { return new SpotFamily(endless, num_envs); }
+
+}  // namespace mg

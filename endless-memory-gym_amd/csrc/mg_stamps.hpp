@@ -192,7 +192,8 @@ inline void rotate_vec(double x, double y, double deg, double& ox, double& oy) {
 }
 
 // stamp pixel values are ids of the shared palette (mg_raster.hpp): 0 key, 1 body, 2 hand, 3 hand outline, 4 white, 5 red
-enum : uint8_t { PAL_KEY = 0, PAL_BODY = 1, PAL_HAND = 2, PAL_OUTLINE = 3, PAL_WHITE = 4, PAL_RED = 5 };
+enum : uint8_t { PAL_KEY = 0, PAL_BODY = 1, PAL_HAND = 2, PAL_OUTLINE = 3, PAL_WHITE = 4, PAL_RED = 5, PAL_YELLOW = 8, PAL_ORANGE = 9,
+                 PAL_BLACK = 15, PAL_EXIT_OPEN = 16, PAL_EXIT_CLOSED = 17 };
 
 // 8 agent sprites; sprite k shows rotation 45k degrees (the hands are rotated by 360-45k about the centre).
 inline std::vector<Stamp> build_agent_sprites(double agent_scale, int* radius_out) {
@@ -268,6 +269,125 @@ inline std::vector<uint8_t> build_mortar_templates(int N, double scale, int scre
             }
     }
     return out;
+}
+
+// Coin (pygame_assets.py:133-152): yellow disc, then an orange circle of width int(2*scale) (0 = filled) on top.
+// Box 2r x 2r, disc centre at (r, r): blit with the top-left at (x - r, y - r).
+inline Stamp build_coin(double coin_scale) {
+    int r = (int)(10 * coin_scale);
+    Stamp s(2 * r > 0 ? 2 * r : 1, 2 * r > 0 ? 2 * r : 1);
+    circle(s, r, r, r, 0, PAL_YELLOW);
+    circle(s, r, r, r, (int)(2 * coin_scale), PAL_ORANGE);
+    return s;
+}
+
+// Chessboard backgrounds (pygame_assets.py:222-239) as frame templates [x][y][c]: 0 = white/blue, 1 = white/red.
+inline std::vector<uint8_t> build_chessboards(double scale, int screen) {
+    int ts = (int)(50 * scale);
+    size_t frame = (size_t)screen * screen * 3;
+    std::vector<uint8_t> out(2 * frame, 0);
+    for (int t = 0; t < 2; ++t)
+        for (int x = 0; x < screen; ++x)
+            for (int y = 0; y < screen; ++y) {
+                bool white = ((x / ts) + (y / ts)) % 2 == 0;
+                uint8_t* p = out.data() + t * frame + ((size_t)x * screen + y) * 3;
+                p[0] = white ? 255 : (t == 1 ? 255 : 0);
+                p[1] = white ? 255 : 0;
+                p[2] = white ? 255 : (t == 0 ? 255 : 0);
+            }
+    return out;
+}
+
+// Rounded rectangle pieces of pygame's draw.rect(..., border_*_radius): filled circle quadrants / quadrant arcs.
+inline void quadrant(Stamp& s, int x0, int y0, int radius, int thickness, uint8_t v, bool tr, bool tl, bool bl, bool br) {
+    int f = 1 - radius, ddx = 0, ddy = -2 * radius, x = 0, y = radius;
+    int i_y = radius - thickness, i_f = 1 - i_y, i_ddx = 0, i_ddy = -2 * i_y;
+    if (radius == 1) {
+        if (tr) s.span(x0, y0 - 1, x0, v);
+        if (tl) s.span(x0 - 1, y0 - 1, x0 - 1, v);
+        if (bl) s.span(x0 - 1, y0, x0 - 1, v);
+        if (br) s.span(x0, y0, x0, v);
+        return;
+    }
+    if (thickness != 0) {
+        while (x < y) {
+            if (f >= 0) { --y; ddy += 2; f += ddy; }
+            if (i_f >= 0) { --i_y; i_ddy += 2; i_f += i_ddy; }
+            ++x; ddx += 2; f += ddx + 1;
+            i_ddx += 2; i_f += i_ddx + 1;
+            if (thickness > 1) thickness = y - i_y;
+            for (int i = 0; i < thickness; ++i) {
+                int y1 = y - i;
+                if (tr) { if ((y0 - y1) < (y0 - x)) s.span(x0 + x - 1, y0 - y1, x0 + x - 1, v); if ((x0 + y1 - 1) >= (x0 + x - 1)) s.span(x0 + y1 - 1, y0 - x, x0 + y1 - 1, v); }
+                if (tl) { if ((y0 - y1) <= (y0 - x)) s.span(x0 - x, y0 - y1, x0 - x, v); if ((x0 - y1) < (x0 - x)) s.span(x0 - y1, y0 - x, x0 - y1, v); }
+                if (bl) { if ((x0 - y1) <= (x0 - x)) s.span(x0 - y1, y0 + x - 1, x0 - y1, v); if ((y0 + y1 - 1) > (y0 + x - 1)) s.span(x0 - x, y0 + y1 - 1, x0 - x, v); }
+                if (br) { if ((y0 + y1 - 1) >= (y0 + x - 1)) s.span(x0 + x - 1, y0 + y1 - 1, x0 + x - 1, v); if ((x0 + y1 - 1) > (x0 + x - 1)) s.span(x0 + y1 - 1, y0 + x - 1, x0 + y1 - 1, v); }
+            }
+        }
+    } else {
+        while (x < y) {
+            if (f >= 0) { --y; ddy += 2; f += ddy; }
+            ++x; ddx += 2; f += ddx + 1;
+            if (tr) { for (int y1 = y0 - x; y1 <= y0; ++y1) s.span(x0 + y - 1, y1, x0 + y - 1, v); for (int y1 = y0 - y; y1 <= y0; ++y1) s.span(x0 + x - 1, y1, x0 + x - 1, v); }
+            if (tl) { for (int y1 = y0 - x; y1 <= y0; ++y1) s.span(x0 - y, y1, x0 - y, v); for (int y1 = y0 - y; y1 <= y0; ++y1) s.span(x0 - x, y1, x0 - x, v); }
+            if (bl) { for (int y1 = y0; y1 < y0 + x; ++y1) s.span(x0 - y, y1, x0 - y, v); for (int y1 = y0; y1 < y0 + y; ++y1) s.span(x0 - x, y1, x0 - x, v); }
+            if (br) { for (int y1 = y0; y1 < y0 + x; ++y1) s.span(x0 + y - 1, y1, x0 + y - 1, v); for (int y1 = y0; y1 < y0 + y; ++y1) s.span(x0 + x - 1, y1, x0 + x - 1, v); }
+        }
+    }
+}
+
+inline void round_rect(Stamp& s, uint8_t v, int x1, int y1, int x2, int y2, int width, int tl, int tr, int bl, int br) {
+    int w = x2 - x1 + 1, h = y2 - y1 + 1;
+    if ((tl + tr) > w || (tl + bl) > h || (tr + br) > h || (bl + br) > w) {
+        float qt = w / (float)(tl + tr), ql = h / (float)(tl + bl), qb = w / (float)(bl + br), qr = h / (float)(tr + br);
+        float f = std::fmin(std::fmin(std::fmin(qt, ql), qb), qr);
+        tl = (int)(tl * f); tr = (int)(tr * f); bl = (int)(bl * f); br = (int)(br * f);
+    }
+    if (width == 0) {
+        for (int y = y1; y <= y2; ++y) {  // octagon between the corner cut-offs
+            int xa = x1, xb = x2;
+            if (y < y1 + tl) xa = x1 + (tl - (y - y1));
+            if (y < y1 + tr) xb = x2 - (tr - (y - y1));
+            if (y > y2 - bl) xa = x1 + (bl - (y2 - y));
+            if (y > y2 - br) xb = x2 - (br - (y2 - y));
+            s.span(xa, y, xb, v);
+        }
+        quadrant(s, x2 - tr + 1, y1 + tr, tr, 0, v, true, false, false, false);
+        quadrant(s, x1 + tl, y1 + tl, tl, 0, v, false, true, false, false);
+        quadrant(s, x1 + bl, y2 - bl + 1, bl, 0, v, false, false, true, false);
+        quadrant(s, x2 - br + 1, y2 - br + 1, br, 0, v, false, false, false, true);
+    } else {
+        int o = width / 2 - 1 + width % 2, o2 = width / 2;
+        auto hline_or_line = [&](int ax, int ay, int bx, int by) {
+            if (width == 1) {
+                if (ay == by) s.span(ax, ay, bx, v);
+                else s.vspan(ay < by ? ay : by, ax, ay < by ? by : ay, v);
+            } else thick_line(s, ax, ay, bx, by, width, v);
+        };
+        if (x2 - tr == x1 + tl) { for (int i = 0; i < width; ++i) s.span(x1 + tl, y1 + i, x1 + tl, v); }
+        else hline_or_line(x1 + tl, y1 + o, x2 - tr, y1 + o);
+        if (y2 - bl == y1 + tl) { for (int i = 0; i < width; ++i) s.span(x1 + i, y1 + tl, x1 + i, v); }
+        else hline_or_line(x1 + o, y1 + tl, x1 + o, y2 - bl);
+        if (x2 - br == x1 + bl) { for (int i = 0; i < width; ++i) s.span(x1 + bl, y2 - i, x1 + bl, v); }
+        else hline_or_line(x1 + bl, y2 - o2, x2 - br, y2 - o2);
+        if (y2 - br == y1 + tr) { for (int i = 0; i < width; ++i) s.span(x2 - i, y1 + tr, x2 - i, v); }
+        else hline_or_line(x2 - o2, y1 + tr, x2 - o2, y2 - br);
+        quadrant(s, x2 - tr + 1, y1 + tr, tr, width, v, true, false, false, false);
+        quadrant(s, x1 + tl, y1 + tl, tl, width, v, false, true, false, false);
+        quadrant(s, x1 + bl, y2 - bl + 1, bl, width, v, false, false, true, false);
+        quadrant(s, x2 - br + 1, y2 - br + 1, br, width, v, false, false, false, true);
+    }
+}
+
+// Exit (pygame_assets.py:169-205): rect_dim = 20*scale square, top corners rounded with radius int(10*scale),
+// filled open/closed colour, then a black outline of width int(2*scale).
+inline Stamp build_exit(double exit_scale, bool open) {
+    int d = (int)(20 * exit_scale), r = (int)(10 * exit_scale), w = (int)(2 * exit_scale);
+    Stamp s(d, d);
+    uint8_t c = open ? PAL_EXIT_OPEN : PAL_EXIT_CLOSED;
+    round_rect(s, c, 0, 0, d - 1, d - 1, 0, r, r, 0, 0);
+    round_rect(s, PAL_BLACK, 0, 0, d - 1, d - 1, w, r, r, 0, 0);
+    return s;
 }
 
 }  // namespace mg

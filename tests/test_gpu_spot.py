@@ -1,0 +1,85 @@
+"""GPU parity (-m gpu) for the Searing Spotlights family: HIP path through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from gpu_parity import check_terminal_info, run_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _toward(d):
+    return 0 if abs(d) < 3 else (1 if d < 0 else 2)
+
+
+def coin_seeker(e, prng):
+    if prng.random() > 0.9:
+        return [int(prng.integers(0, 3)), int(prng.integers(0, 3))]
+    tx, ty = e.get("coin_x"), e.get("coin_y")
+    if tx is None:  # finite variant: first remaining coin, else the exit
+        c = e.get_list("coins")
+        if c is not None and len(c) >= 2:
+            tx, ty = c[0], c[1]
+        else:
+            tx, ty = e.get("exit_x"), e.get("exit_y")
+    return [_toward(tx - e.get("ax")), _toward(ty - e.get("ay"))]
+
+
+ESS_OPTS = [
+    None,
+    dict(agent_health=40, steps_per_coin=60, initial_spawns=5, spawn_interval=20, max_steps=400, reward_death=-1.0,
+         reward_inside_spotlight=-0.01, reward_outside_spotlight=0.001),
+    dict(agent_health=1000, spot_min_speed=0.01, spot_max_speed=0.05, spawn_interval=10),
+    dict(sample_agent_position=False, visual_feedback=False, coins_visible=True),
+]
+SS_OPTS = [
+    None,
+    dict(num_coins=[1, 2, 3], agent_health=20, initial_spawns=2, max_steps=128, reward_death=-1.0,
+         reward_inside_spotlight=-0.01, reward_outside_spotlight=0.001),
+    dict(num_coins=[2], agent_health=50, light_dim_off_duration=3),
+    dict(sample_agent_position=False, agent_health=100),
+]
+
+
+@pytest.mark.parametrize("opt_idx", range(len(ESS_OPTS)))
+def test_endless_parity(opt_idx):
+    n_done = run_parity("Endless-SearingSpotlights-v0", ESS_OPTS[opt_idx], n=160, steps=320, policy=coin_seeker, n_policy=64)
+    assert n_done > 0 or opt_idx == 2
+
+
+@pytest.mark.parametrize("opt_idx", range(len(SS_OPTS)))
+def test_finite_parity(opt_idx):
+    n_done = run_parity("SearingSpotlights-v0", SS_OPTS[opt_idx], n=160, steps=300, policy=coin_seeker, n_policy=64)
+    assert n_done > 0
+
+
+def test_terminal_info():
+    assert check_terminal_info("Endless-SearingSpotlights-v0", steps=220) > 0
+    assert check_terminal_info("SearingSpotlights-v0", steps=220) > 0
+
+
+def test_full_size_sample():
+    """BASELINE config C4 size (16,384 instances): a sample of instances must match single-instance oracles."""
+    import memory_gym_amd
+    import oracle_lib
+    import torch
+
+    n = 16384
+    env = memory_gym_amd.make("Endless-SearingSpotlights-v0", num_envs=n, device=0)
+    obs, _ = env.reset(seed=0)
+    sample = [0, 1, 255, 4095, 8192, 16383]
+    refs = {i: oracle_lib.OracleEnv("Endless-SearingSpotlights-v0") for i in sample}
+    first = obs[sample].cpu().numpy()
+    for k, i in enumerate(sample):
+        assert np.array_equal(first[k], refs[i].reset(i))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(120):
+        a = torch.randint(0, 3, (n, 2), device="cuda", generator=g, dtype=torch.int32)
+        obs, rew, done, _, _ = env.step(a)
+        ac = a[sample].cpu().numpy()
+        got = obs[sample].cpu().numpy()
+        for k, i in enumerate(sample):
+            o, r, d = refs[i].step(ac[k])
+            if d:
+                o = refs[i].reset(None)
+            assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t)
+    env.close()
