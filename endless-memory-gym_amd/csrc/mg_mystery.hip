@@ -1,0 +1,809 @@
+// mg_mystery.hip -- Mystery Path family on gfx950: MysteryPath-v0 and Endless-MysteryPath-v0.
+//
+// Reference behaviour reproduced (bit-exact observations, rewards, dones, RNG consumption):
+//   memory_gym/mystery_path.py          reset :130-200  step :202-276
+//   memory_gym/endless_mystery_path.py  reset :195-280  step :282-444  drawing :111-160
+//   memory_gym/pygame_assets.py         Node :438-493  EndlessMysteryPath :495-604  MysteryPath (noisy A*) :606-736
+//   memory_gym/character_controller.py  CharacterController.step :89-146
+//
+//   mystery_step_kernel : one LANE per instance.  Path following / fall-off logic; the procedural path generator
+//                         (33 % inner walls, 4 or 8 outer walls, A* with integers(1,9) noise on every relaxation,
+//                         Python-list open/closed-set semantics incl. the reference's tie-breaking and its
+//                         `neighbor.g = g` typo) runs in the same kernel for instances that (auto-)reset.
+//   raster_kernel<MysteryComposer> : black frame -> goal/origin or past-path tiles -> agent sprite -> fall-off cross.
+#include <memory>
+
+#include "mg_atlas.hpp"
+#include "mg_device.hpp"
+#include "mg_family.hpp"
+#include "mg_raster.hpp"
+#include "mg_stamps.hpp"
+
+namespace mg {
+
+constexpr int G = 7;             // grid_dim
+constexpr int SEG_STRIDE = 52;   // bytes per stored segment: [0] = length, [1..50] nodes
+constexpr int SEG_NODES = 50;
+constexpr int MAX_SEG = 128;
+constexpr int MAX_FALL = 128;
+constexpr int ST_CROSS = 8;
+
+struct MysteryParams {
+    int endless, n;
+    int max_steps, show_origin, show_goal, visual_feedback, show_past_path, show_stamina, stamina_level, depth;
+    int agent_radius, sprite_dim, v_axis_i, v_diag_i, tile, cross_dim;
+    int camera_offset;  // integral at the supported camera_offset_scale values
+    OptList cardinal;
+    double r_goal, r_fall, r_progress, r_dense, r_step;
+};
+
+struct __attribute__((aligned(16))) MysteryCore {
+    int16_t ax, ay;
+    uint8_t rot8, off, cross_on, path_len;
+    uint8_t sx, sy, ex, ey;
+    int16_t cross_x, cross_y;           // fall_off_rect centre
+    int32_t fails, t, ep_len, stamina;
+    int32_t max_x, tiles_visited, cur_seg, num_seg;
+    int32_t cur_node_seg, cur_node_idx, camera_x, n_falloff;
+    uint64_t path_mask, visited_mask;   // finite: bit (x*7+y)
+    double ep_sum;
+    uint8_t td[3], have_start;
+    int8_t end_y;
+    uint8_t pad[3];
+};
+static_assert(sizeof(MysteryCore) == 96, "MysteryCore must be 96 bytes");
+
+struct __attribute__((aligned(16))) MysteryDesc {
+    uint8_t valid, sprite, n_tiles, cross_on;
+    int16_t sx, sy, cross_x, cross_y;        // top-left of the sprite / of the cross stamp
+    uint8_t goal_on, goal_x, goal_y, origin_on, origin_x, origin_y, stamina_on, stamina_red;
+    // past-path tiles (endless): bit (col*7 + row) of the 16-column x 7-row window whose column 0 is drawn at tile_x0
+    uint64_t tile_mask[2];
+    int32_t tile_x0;
+    uint32_t pad[3];
+};
+static_assert(sizeof(MysteryDesc) == 64, "MysteryDesc must be 64 bytes");
+
+struct MysteryComposer {
+    typedef MysteryDesc Desc;
+    static __device__ __forceinline__ bool skip(const Desc& d) { return d.valid == 0; }
+    static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
+        fill_clear(R);
+        __syncthreads();
+        if (d.goal_on) rect(R, d.goal_x * 12, d.goal_y * 12, 12, 12, C_GREEN, false);
+        if (d.origin_on) rect(R, d.origin_x * 12, d.origin_y * 12, 12, 12, C_BLUE, false);
+        for (int h = 0; h < 2; ++h) {  // distinct path cells: no overlap between them, no barrier needed
+            uint64_t m = d.tile_mask[h];
+            while (m) {
+                int b = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                int cell = h * 64 + b, col = cell / G, row = cell - col * G;
+                rect(R, d.tile_x0 + 12 * col, 12 * row, 12, 12, C_WHITE, true);
+            }
+        }
+        __syncthreads();
+        stamp(R, d.sprite, d.sx, d.sy);
+        if (d.stamina_on) {
+            __syncthreads();
+            rect(R, SCREEN - 4, 0, 4, SCREEN, C_GREEN, false);
+            if (d.stamina_red) {
+                __syncthreads();
+                rect(R, SCREEN - 4, 0, 4, d.stamina_red, C_RED, false);
+            }
+        }
+        if (d.cross_on) {
+            __syncthreads();
+            stamp(R, ST_CROSS, d.cross_x, d.cross_y);
+        }
+    }
+};
+
+struct MysteryIO {
+    MysteryCore* core;
+    uint8_t* segs;      // endless: [N][MAX_SEG][SEG_STRIDE]; node byte = x_rel | y<<3 | rvis<<6 | svis<<7
+    uint32_t* falloff;  // endless: [N][MAX_FALL]  (x | y<<16, y biased by 1024)
+    RngSoA rng;
+    MysteryDesc* desc;
+    int* err;
+};
+
+// ---- MysteryPath.__init__: walls + noisy A* on a 7x7 grid.  Returns the path length; out[] = flat indices
+// (x*7+y), END FIRST like the reference's list.  -1 = "No valid path found".
+__device__ __forceinline__ int nb_of(int idx, int k) {  // Node.add_neighbors order: x+1, x-1, y+1, y-1
+    int x = idx / G, y = idx - x * G;
+    if (k == 0) return x < G - 1 ? idx + G : -1;
+    if (k == 1) return x > 0 ? idx - G : -1;
+    if (k == 2) return y < G - 1 ? idx + 1 : -1;
+    return y > 0 ? idx - 1 : -1;
+}
+__device__ __forceinline__ int diag_of(int idx, int k) {
+    int x = idx / G, y = idx - x * G;
+    if (k == 0) return (x < G - 1 && y < G - 1) ? idx + G + 1 : -1;
+    if (k == 1) return (x > 0 && y > 0) ? idx - G - 1 : -1;
+    if (k == 2) return (x < G - 1 && y > 0) ? idx + G - 1 : -1;
+    return (x > 0 && y < G - 1) ? idx - G + 1 : -1;
+}
+
+__device__ __noinline__ int generate_path(Pcg& g, int sx, int sy, int ex, int ey, uint8_t* out) {
+    uint64_t wall = 0, closed = 0, in_open = 0;
+    int gcost[G * G];
+    double fcost[G * G];
+    int8_t prev[G * G];
+    for (int i = 0; i < G * G; ++i) {
+        gcost[i] = 0;
+        fcost[i] = 0.0;
+        prev[i] = -1;
+    }
+    for (int i = 0; i < G; ++i)
+        for (int j = 0; j < G; ++j)
+            if (i > 0 && i < G - 2 && j > 0 && j < G - 2)
+                if (g.integers(0, 100) < 33) wall |= 1ull << (i * G + j);
+    const int start = sx * G + sy, end = ex * G + ey;
+    uint8_t outer[4 * G];
+    int n_outer = 0;
+    for (int i = 0; i < G; ++i)
+        for (int j = 0; j < G; ++j) {
+            if (!(i == 0 || i == G - 1 || j == 0 || j == G - 1)) continue;
+            int idx = i * G + j;
+            if (idx == start || idx == end) continue;
+            bool near = false;
+            for (int k = 0; k < 4; ++k) near = near || nb_of(start, k) == idx || nb_of(end, k) == idx;
+            if (near) continue;
+            bool adj = false;
+            for (int k = 0; k < 4; ++k) {
+                int q = nb_of(idx, k);
+                if (q >= 0 && ((wall >> q) & 1ull)) adj = true;
+                q = diag_of(idx, k);
+                if (q >= 0 && ((wall >> q) & 1ull)) adj = true;
+            }
+            if (!adj) outer[n_outer++] = (uint8_t)idx;
+        }
+    int n_iter = g.integers(0, 2) == 0 ? 4 : 8;  // rng.choice([4, 8])
+    for (int it = 0; it < n_iter; ++it) {
+        if (n_outer > 0) {
+            int k = g.integers(0, n_outer);
+            int idx = outer[k];
+            wall |= 1ull << idx;
+            for (int q = k; q < n_outer - 1; ++q) outer[q] = outer[q + 1];
+            --n_outer;
+        }
+    }
+    uint8_t open[G * G];
+    int n_open = 0;
+    open[n_open++] = (uint8_t)start;
+    in_open |= 1ull << start;
+    for (;;) {
+        if (n_open == 0) return -1;
+        int w = 0;
+        for (int i = 0; i < n_open; ++i)
+            if (fcost[open[i]] < fcost[open[0]]) {  // first strictly better than open[0], then break
+                w = i;
+                break;
+            }
+        int cur = open[w];
+        if (cur == end) {
+            int len = 0, t = cur;
+            out[len++] = (uint8_t)end;
+            while (prev[t] >= 0) {
+                out[len++] = (uint8_t)prev[t];
+                t = prev[t];
+            }
+            return len;
+        }
+        for (int q = w; q < n_open - 1; ++q) open[q] = open[q + 1];
+        --n_open;
+        in_open &= ~(1ull << cur);
+        closed |= 1ull << cur;
+        for (int k = 0; k < 4; ++k) {
+            int nb = nb_of(cur, k);
+            if (nb < 0) continue;
+            if (((closed >> nb) & 1ull) || ((wall >> nb) & 1ull)) continue;
+            int gg = gcost[cur] + g.integers(1, 9);
+            bool new_path = false;
+            if ((in_open >> nb) & 1ull) {
+                if (gg < gcost[nb]) new_path = true;  // `neighbor.g = g` typo: g_cost is NOT updated
+            } else {
+                gcost[nb] = gg;
+                new_path = true;
+                open[n_open++] = (uint8_t)nb;
+                in_open |= 1ull << nb;
+            }
+            if (new_path) {
+                int ax = nb / G, ay = nb - ax * G;
+                int ddx = ax - ex, ddy = ay - ey;
+                double h = sqrt((double)(ddx * ddx) + (double)(ddy * ddy));
+                fcost[nb] = (double)gcost[nb] + h;
+                prev[nb] = (int8_t)cur;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int floordiv_pos(int a, int b) {
+    int q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+// CharacterController.step with an optional clamp box
+__device__ __forceinline__ void move_agent(const MysteryParams& P, MysteryCore& s, int a0, int a1, bool clamp) {
+    int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
+    int rot = s.rot8 * 45;
+    if (a0 == 1) rot = 90;
+    if (a0 == 2) rot = 270;
+    if (a1 == 1) rot = 0;
+    if (a1 == 2) rot = 180;
+    if (dxs < 0 && dys < 0) rot = 45;
+    if (dxs < 0 && dys > 0) rot = 135;
+    if (dxs > 0 && dys < 0) rot = 315;
+    if (dxs > 0 && dys > 0) rot = 225;
+    s.rot8 = (uint8_t)(rot / 45);
+    int v = (dxs != 0 && dys != 0) ? P.v_diag_i : P.v_axis_i;
+    int ax = s.ax + dxs * v, ay = s.ay + dys * v;
+    if (clamp) {
+        int lo = P.agent_radius, hi = SCREEN - P.agent_radius;
+        ax = ax > hi ? hi : ax;
+        ax = ax < lo ? lo : ax;
+        ay = ay > hi ? hi : ay;
+        ay = ay < lo ? lo : ay;
+    }
+    s.ax = (int16_t)ax;
+    s.ay = (int16_t)ay;
+}
+
+// ============================================ finite ============================================
+__device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, MysteryCore& s, Pcg& g, MysteryDesc& d) {
+    s.t = 0;
+    s.ep_sum = 0.0;
+    s.ep_len = 0;
+    int cardinal = choice(g, P.cardinal);
+    int sx, sy, ex, ey;
+    if (cardinal == 0) { sx = 0; sy = g.integers(0, G); ex = G - 1; ey = g.integers(0, G); }
+    else if (cardinal == 1) { sx = G - 1; sy = g.integers(0, G); ex = 0; ey = g.integers(0, G); }
+    else if (cardinal == 2) { sx = g.integers(0, G); sy = 0; ex = g.integers(0, G); ey = G - 1; }
+    else { sx = g.integers(0, G); sy = G - 1; ex = g.integers(0, G); ey = 0; }
+    uint8_t path[G * G];
+    int len = generate_path(g, sx, sy, ex, ey, path);
+    if (len < 0) {
+        atomicOr(io.err, 2);
+        len = 0;
+    }
+    uint64_t pm = 0;
+    for (int k = 0; k < len; ++k) pm |= 1ull << path[k];
+    s.path_mask = pm;
+    s.visited_mask = 0;
+    s.path_len = (uint8_t)len;
+    s.sx = (uint8_t)sx; s.sy = (uint8_t)sy; s.ex = (uint8_t)ex; s.ey = (uint8_t)ey;
+    s.ax = (int16_t)(sx * P.tile + P.agent_radius);
+    s.ay = (int16_t)(sy * P.tile + P.agent_radius);
+    s.rot8 = 0;
+    s.off = 0;
+    s.fails = 0;
+    s.cross_on = 0;
+    memset(&d, 0, sizeof(d));
+    d.valid = 1;
+    d.sprite = 0;
+    d.sx = (int16_t)(s.ax - P.sprite_dim / 2);
+    d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
+    d.goal_on = P.show_goal ? 1 : 0; d.goal_x = (uint8_t)ex; d.goal_y = (uint8_t)ey;
+    d.origin_on = P.show_origin ? 1 : 0; d.origin_x = (uint8_t)sx; d.origin_y = (uint8_t)sy;
+}
+
+__device__ void mp_step(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
+                        const int32_t* actions, float* reward_out, uint8_t* done_out, const mg_info_buffers& info,
+                        int autoreset, MysteryDesc& d) {
+    double reward = 0.0;
+    bool done = false;
+    int success = 0;
+    if (!s.off) {
+        move_agent(P, s, actions[2 * i], actions[2 * i + 1], true);
+    } else {
+        s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
+        s.ay = (int16_t)(s.sy * P.tile + P.agent_radius);
+        move_agent(P, s, 0, 0, true);
+    }
+    int nx = s.ax / P.tile, ny = s.ay / P.tile;
+    if (nx == s.ex && ny == s.ey) {
+        reward += P.r_goal;
+        done = true;
+        success = 1;
+    } else {
+        int cell = nx * G + ny;
+        bool on_path = (s.path_mask >> cell) & 1ull;
+        if (on_path) {
+            bool special = (nx == s.sx && ny == s.sy) || (nx == s.ex && ny == s.ey);
+            if (!((s.visited_mask >> cell) & 1ull) && !special) {
+                reward += P.r_progress;
+                s.visited_mask |= 1ull << cell;
+            }
+            s.cross_on = 0;
+            s.off = 0;
+        } else {
+            reward += P.r_fall;
+            s.fails++;
+            if (P.visual_feedback) s.cross_on = 1;
+            s.off = 1;
+        }
+        s.cross_x = s.ax;
+        s.cross_y = s.ay;
+    }
+    reward += P.r_step;
+    s.t++;
+    if (s.t == P.max_steps) done = true;
+    s.ep_sum += reward;
+    s.ep_len++;
+    if (done) {
+        if (info.ep_reward_dev) info.ep_reward_dev[i] = s.ep_sum;
+        if (info.ep_length_dev) info.ep_length_dev[i] = s.ep_len;
+        if (info.aux_dev[0]) info.aux_dev[0][i] = (float)success;
+        if (info.aux_dev[1]) info.aux_dev[1][i] = (float)s.fails;
+    }
+    reward_out[i] = (float)reward;
+    done_out[i] = done ? 1 : 0;
+    if (done && autoreset) {
+        mp_reset(P, io, s, g, d);
+        rng_dirty = true;
+    } else {
+        memset(&d, 0, sizeof(d));
+        d.valid = 1;
+        d.sprite = s.rot8;
+        d.sx = (int16_t)(s.ax - P.sprite_dim / 2);
+        d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
+        d.cross_on = s.cross_on;
+        d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
+        d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
+        d.goal_on = P.show_goal ? 1 : 0; d.goal_x = s.ex; d.goal_y = s.ey;
+        d.origin_on = P.show_origin ? 1 : 0; d.origin_x = s.sx; d.origin_y = s.sy;
+    }
+}
+
+// ============================================ endless ============================================
+__device__ __forceinline__ uint8_t* seg_ptr(const MysteryIO& io, int i, int seg) {
+    return io.segs + ((size_t)i * MAX_SEG + seg) * SEG_STRIDE;
+}
+__device__ __forceinline__ int node_x(int seg, uint8_t b) { return seg * (G + 1) + (b & 7); }
+__device__ __forceinline__ int node_y(uint8_t b) { return (b >> 3) & 7; }
+
+// EndlessMysteryPath.add_path_segment
+__device__ void emp_add_segment(const MysteryIO& io, int i, MysteryCore& s, Pcg& g) {
+    int sy;
+    if (!s.have_start) {
+        sy = g.integers(0, G);
+        s.have_start = 1;
+    } else {
+        sy = s.end_y;
+    }
+    int ey = g.integers(0, G);
+    s.end_y = (int8_t)ey;
+    uint8_t path[G * G];
+    int len = generate_path(g, 0, sy, G - 1, ey, path);
+    if (len < 0) {
+        atomicOr(io.err, 2);
+        len = 0;
+    }
+    if (s.num_seg >= MAX_SEG) {
+        atomicOr(io.err, 4);
+        return;
+    }
+    uint8_t* sp = seg_ptr(io, i, s.num_seg);
+    int n = 0;
+    for (int k = len - 1; k >= 0; --k) {
+        int x = path[k] / G, y = path[k] - x * G;
+        sp[1 + n++] = (uint8_t)(x | (y << 3));
+    }
+    sp[1 + n++] = (uint8_t)(7 | (ey << 3));  // transition node at x = 8*seg + 7
+    sp[0] = (uint8_t)n;
+    s.num_seg++;
+}
+
+__device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float* gt) {
+    const uint8_t* sp = seg_ptr(io, i, s.cur_node_seg);
+    int cx = node_x(s.cur_node_seg, sp[1 + s.cur_node_idx]), cy = node_y(sp[1 + s.cur_node_idx]);
+    int nseg = s.cur_node_seg, nidx = s.cur_node_idx + 1;
+    if (nidx >= sp[0]) {
+        nseg++;
+        nidx = 0;
+    }
+    if (nseg < s.num_seg) {
+        const uint8_t* np = seg_ptr(io, i, nseg);
+        int x = node_x(nseg, np[1 + nidx]) - cx, y = node_y(np[1 + nidx]) - cy;
+        if (x == 1) { s.td[0] = 1; s.td[1] = 0; s.td[2] = 0; }
+        else if (y == -1) { s.td[0] = 0; s.td[1] = 1; s.td[2] = 0; }
+        else if (y == 1) { s.td[0] = 0; s.td[1] = 0; s.td[2] = 1; }
+    }
+    if (gt) {
+        gt[0] = (float)s.td[0];
+        gt[1] = (float)s.td[1];
+        gt[2] = (float)s.td[2];
+    }
+}
+
+__device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx) {
+    memset(&d, 0, sizeof(d));
+    d.valid = 1;
+    d.sprite = s.rot8;
+    d.sx = (int16_t)((s.sx * P.tile + P.agent_radius - P.sprite_dim / 2) - P.camera_offset);  // agent_draw_x (fixed at reset)
+    d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
+    d.cross_on = (P.visual_feedback && s.cross_on) ? 1 : 0;
+    d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
+    d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
+    if (P.show_stamina) {
+        d.stamina_on = 1;
+        int st = s.stamina < P.stamina_level ? s.stamina : P.stamina_level;
+        d.stamina_red = (uint8_t)(int)(SCREEN * (1 - ((double)st / P.stamina_level)));
+    }
+    if (P.show_past_path) {  // _draw_past_path
+        int x = nx - 1;
+        if (x >= 0) {
+            int past_x = x - P.depth > 0 ? x - P.depth : 0;
+            d.tile_x0 = past_x * P.tile - s.camera_x;
+            int seg = s.cur_node_seg, idx = s.cur_node_idx - 1;
+            while (x >= past_x && x >= 0) {
+                if (idx < 0) {
+                    seg--;
+                    if (seg < 0) break;
+                    idx = seg_ptr(io, i, seg)[0] - 1;
+                }
+                uint8_t b = seg_ptr(io, i, seg)[1 + idx];
+                x = node_x(seg, b);
+                int y = node_y(b);
+                int col = x - past_x;
+                if (col >= 0 && col < 16) {
+                    int cell = col * G + y;
+                    d.tile_mask[cell >> 6] |= 1ull << (cell & 63);
+                } else if (col >= 16) {
+                    atomicOr(io.err, 16);
+                }
+                if (x == past_x) break;
+                idx--;
+            }
+        }
+    }
+}
+
+__device__ void emp_reset(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, Pcg& g, MysteryDesc& d, float* gt) {
+    s.t = 0;
+    s.ep_sum = 0.0;
+    s.ep_len = 0;
+    s.num_seg = 0;
+    s.have_start = 0;
+    for (int k = 0; k < 3; ++k) emp_add_segment(io, i, s, g);
+    uint8_t* s0 = seg_ptr(io, i, 0);
+    s0[1] |= 1u << 6;  // the first node of the path shall not yield any reward
+    s.sx = (uint8_t)node_x(0, s0[1]);
+    s.sy = (uint8_t)node_y(s0[1]);
+    s.camera_x = P.camera_offset;
+    s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
+    s.ay = (int16_t)(s.sy * P.tile + P.agent_radius);
+    s.rot8 = 6;  // 270 degrees
+    s.cur_node_seg = 0;
+    s.cur_node_idx = 0;
+    emp_direction(io, i, s, gt);
+    s.off = 0;
+    s.cross_on = 0;
+    s.cross_x = s.cross_y = 0;
+    s.cur_seg = 0;
+    s.fails = 0;
+    s.n_falloff = 0;
+    s.stamina = P.stamina_level;
+    s.max_x = 0;
+    s.tiles_visited = 0;
+    emp_fill_desc(P, io, i, s, d, s.ax / P.tile);
+    d.cross_on = 0;
+    if (P.show_stamina) d.stamina_red = 0;
+}
+
+__device__ void emp_step(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
+                         const int32_t* actions, float* reward_out, uint8_t* done_out, float* gt,
+                         const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
+    int a = actions[i];
+    int a0 = a == 1 ? 2 : 0, a1 = a == 2 ? 1 : (a == 3 ? 2 : 0);
+    double reward = 0.0;
+    bool done = false;
+    if (!s.off) {
+        int before = s.ax;
+        move_agent(P, s, a0, a1, false);
+        s.camera_x += s.ax - before;  // camera follows the agent's x velocity
+    } else {
+        s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
+        s.ay = (int16_t)(s.sy * P.tile + P.agent_radius);
+        move_agent(P, s, 0, 0, false);
+        s.camera_x = P.camera_offset;
+    }
+    int nx = floordiv_pos(s.ax, P.tile), ny = floordiv_pos(s.ay, P.tile);
+    s.cur_seg = nx / (G + 1);
+    int seg = s.cur_seg;
+    if (s.cur_seg > s.num_seg - 2) {
+        emp_add_segment(io, i, s, g);
+        rng_dirty = true;
+    }
+    bool on_path = false;
+    if (seg < s.num_seg) {
+        uint8_t* sp = seg_ptr(io, i, seg);
+        int n = sp[0];
+        for (int k = 0; k < n; ++k) {
+            uint8_t b = sp[1 + k];
+            if (node_x(seg, b) == nx && node_y(b) == ny) {
+                on_path = true;
+                s.cur_node_seg = seg;
+                s.cur_node_idx = k;
+                bool is_start = nx == s.sx && ny == s.sy;
+                if (!(b & 0x40) && !is_start) {
+                    reward += P.r_progress;
+                    s.tiles_visited++;
+                    b |= 0x40;
+                }
+                if (!(b & 0x80) && !is_start) {
+                    reward += P.r_dense;
+                    s.stamina = P.stamina_level;
+                    b |= 0x80;
+                }
+                sp[1 + k] = b;
+                break;
+            }
+        }
+    }
+    if (!on_path) {
+        reward += P.r_fall;
+        s.fails++;
+        if (P.visual_feedback) s.cross_on = 1;
+        s.off = 1;
+        if (nx < s.max_x) {
+            done = true;
+        } else {
+            uint32_t* fl = io.falloff + (size_t)i * MAX_FALL;
+            uint32_t key = (uint32_t)(nx & 0xFFFF) | ((uint32_t)(ny + 1024) << 16);
+            bool found = false;
+            for (int k = 0; k < s.n_falloff; ++k)
+                if (fl[k] == key) {
+                    done = true;
+                    found = true;
+                    break;
+                }
+            if (!found) {
+                if (s.n_falloff < MAX_FALL) fl[s.n_falloff++] = key;
+                else atomicOr(io.err, 8);
+            }
+        }
+        for (int q = 0; q < s.num_seg; ++q) {  // reset all stamina flags
+            uint8_t* sp = seg_ptr(io, i, q);
+            int n = sp[0];
+            for (int k = 0; k < n; ++k) sp[1 + k] &= 0x7F;
+        }
+        s.stamina = P.stamina_level;
+    } else {
+        s.cross_on = 0;
+        s.off = 0;
+    }
+    s.cross_x = (int16_t)(s.ax - s.camera_x);
+    s.cross_y = s.ay;
+    reward += P.r_step;
+    s.stamina--;
+    if (s.stamina == 0) done = true;
+    s.t++;
+    if (s.t == P.max_steps) done = true;
+    emp_direction(io, i, s, gt);
+    if (nx > s.max_x && on_path) s.max_x = nx;
+    s.ep_sum += reward;
+    s.ep_len++;
+    if (done) {
+        if (info.ep_reward_dev) info.ep_reward_dev[i] = s.ep_sum;
+        if (info.ep_length_dev) info.ep_length_dev[i] = s.ep_len;
+        if (info.aux_dev[0]) info.aux_dev[0][i] = (float)s.fails;
+        if (info.aux_dev[1]) info.aux_dev[1][i] = (float)s.max_x;
+        if (info.aux_dev[2]) info.aux_dev[2][i] = (float)s.tiles_visited;
+    }
+    reward_out[i] = (float)reward;
+    done_out[i] = done ? 1 : 0;
+    if (done && autoreset) {
+        emp_reset(P, io, i, s, g, d, gt);
+        rng_dirty = true;
+    } else {
+        emp_fill_desc(P, io, i, s, d, nx);
+    }
+}
+
+__global__ __launch_bounds__(256) void mystery_init_kernel(int n, MysteryCore* core) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    MysteryCore s;
+    memset(&s, 0, sizeof(s));
+    core[i] = s;
+}
+
+__global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds,
+                                                            const uint8_t* mask, float* gt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    if (mask && !mask[i]) {
+        io.desc[i].valid = 0;
+        return;
+    }
+    Pcg g;
+    if (seeds) g.seed((uint64_t)seeds[i]);
+    else g.load(io.rng, i);
+    MysteryCore s = io.core[i];
+    MysteryDesc d;
+    if (P.endless) emp_reset(P, io, i, s, g, d, gt ? gt + 3 * i : nullptr);
+    else mp_reset(P, io, s, g, d);
+    io.core[i] = s;
+    g.store(io.rng, i);
+    io.desc[i] = d;
+}
+
+__global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions,
+                                                           float* reward_out, uint8_t* done_out, float* gt,
+                                                           mg_info_buffers info, int autoreset) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    MysteryCore s = io.core[i];
+    Pcg g;
+    g.load(io.rng, i);
+    bool rng_dirty = false;
+    MysteryDesc d;
+    if (P.endless) emp_step(P, io, i, s, g, rng_dirty, actions, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+    else mp_step(P, io, i, s, g, rng_dirty, actions, reward_out, done_out, info, autoreset, d);
+    if (rng_dirty) g.store(io.rng, i);
+    io.core[i] = s;
+    io.desc[i] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static const double SCALE = 0.25;
+
+class MysteryFamily : public Family {
+   public:
+    MysteryFamily(int endless, int n) : n_(n) {
+        memset(&P_, 0, sizeof(P_));
+        P_.endless = endless;
+        P_.n = n;
+        agent_scale_ = 1.0 * SCALE;
+        agent_speed_ = 12.0 * SCALE;
+        P_.visual_feedback = 1;
+        P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
+        if (endless) {
+            P_.max_steps = -1; P_.show_past_path = 1; camera_offset_scale_ = 5.0; P_.stamina_level = 20;
+        } else {
+            P_.max_steps = 512;
+            P_.cardinal.n = 4;
+            for (int k = 0; k < 4; ++k) P_.cardinal.v[k] = k;
+            P_.r_goal = 1.0;
+        }
+        core_.alloc(n);
+        desc_.alloc(n);
+        rng_.alloc(n);
+        err_.alloc(1);
+        if (endless) {
+            segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
+            falloff_.alloc((size_t)n * MAX_FALL);
+        } else {
+            segs_.alloc(16);
+            falloff_.alloc(4);
+        }
+        hipLaunchKernelGGL(mystery_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, core_.p);
+        MG_HIP(hipDeviceSynchronize());
+        rebuild();
+    }
+
+    int action_dim() const override { return P_.endless ? 1 : 2; }
+    int gt_dim() const override { return P_.endless ? 3 : 0; }
+    const char* info_name(int k) const override {
+        if (P_.endless) return k == 0 ? "num_fails" : (k == 1 ? "max_x" : (k == 2 ? "tiles_visited" : nullptr));
+        return k == 0 ? "success" : (k == 1 ? "num_fails" : nullptr);
+    }
+
+    void set_option(const std::string& key, const double* v, int n) override {
+        const bool e = P_.endless;
+        auto I = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
+        auto B = [&](int& dst) { dst = v[0] != 0.0; };
+        auto must_be = [&](bool ok) { if (!ok) throw OptionError{-3, "reset parameter " + key + ": this value is not supported by the MI355X build"}; };
+        if (key == "max_steps") I(P_.max_steps);
+        else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
+        else if (key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
+        else if (key == "show_origin") { B(P_.show_origin); if (e) P_.show_origin = 0; /* dead branch in the reference (:150) */ }
+        else if (key == "visual_feedback") B(P_.visual_feedback);
+        else if (key == "reward_fall_off") P_.r_fall = v[0];
+        else if (key == "reward_path_progress") P_.r_progress = v[0];
+        else if (key == "reward_step") P_.r_step = v[0];
+        else if (e && key == "show_past_path") B(P_.show_past_path);
+        else if (e && key == "show_background") must_be(v[0] == 0.0);
+        else if (e && key == "show_stamina") B(P_.show_stamina);
+        else if (e && key == "camera_offset_scale") { camera_offset_scale_ = v[0]; dirty_ = true; }
+        else if (e && key == "stamina_level") { I(P_.stamina_level); must_be(P_.stamina_level > 0); }
+        else if (e && key == "reward_path_progress_dense") P_.r_dense = v[0];
+        else if (!e && key == "cardinal_origin_choice") {
+            must_be(n >= 1 && n <= 8);
+            P_.cardinal.n = n;
+            for (int k = 0; k < n; ++k) P_.cardinal.v[k] = to_int_checked(v[k], key.c_str());
+        }
+        else if (!e && key == "show_goal") B(P_.show_goal);
+        else if (!e && key == "reward_goal") P_.r_goal = v[0];
+        else throw OptionError{-2, "unknown reset parameter " + key};
+    }
+
+    void reset(const int64_t* seeds, const uint8_t* mask, uint8_t* obs, float* gt, hipStream_t s) override {
+        if (dirty_) rebuild();
+        if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
+        if (seeds) seeded_ = true;
+        hipLaunchKernelGGL(mystery_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt_dim() ? gt : nullptr);
+        raster(obs, s);
+    }
+
+    void step(const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,
+              int autoreset, hipStream_t s) override {
+        if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next step");
+        mg_info_buffers ib;
+        memset(&ib, 0, sizeof(ib));
+        if (info) ib = *info;
+        prof.begin(0, s);
+        hipLaunchKernelGGL(mystery_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done,
+                           gt_dim() ? gt : nullptr, ib, autoreset);
+        prof.end(0, s);
+        prof.begin(1, s);
+        raster(obs, s);
+        prof.end(1, s);
+    }
+
+    std::vector<std::pair<void*, size_t>> state_blobs() override {
+        std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {segs_.p, segs_.bytes()}, {falloff_.p, falloff_.bytes()}};
+        rng_.blobs(v);
+        return v;
+    }
+    void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+
+   private:
+    MysteryIO io() {
+        MysteryIO o;
+        o.core = core_.p;
+        o.segs = segs_.p;
+        o.falloff = falloff_.p;
+        o.rng = rng_.view();
+        o.desc = desc_.p;
+        o.err = err_.p;
+        return o;
+    }
+
+    void rebuild() {
+        int radius = 0;
+        std::vector<Stamp> sprites = build_agent_sprites(agent_scale_, &radius);
+        P_.agent_radius = radius;
+        P_.sprite_dim = sprites[0].w;
+        double inv = 1.0 / std::sqrt(2.0);
+        P_.v_axis_i = (int)((1.0 / 1.0) * agent_speed_);
+        P_.v_diag_i = (int)(inv * agent_speed_);
+        P_.tile = SCREEN / G;
+        double cos_ = camera_offset_scale_ < 0 ? 0 : (camera_offset_scale_ > 5.5 ? 5.5 : camera_offset_scale_);
+        double cam = -P_.tile * cos_;
+        if (cam != std::floor(cam)) throw OptionError{-3, "camera_offset_scale must give an integral pixel offset (multiples of 1/12)"};
+        P_.camera_offset = (int)cam;
+        P_.depth = (int)camera_offset_scale_;
+        if (P_.depth > 7) throw OptionError{-3, "camera_offset_scale too large"};
+        Stamp cross = build_cross(SCALE);
+        P_.cross_dim = cross.w;
+        atlas_.reset(new Atlas());
+        for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
+        atlas_->add_stamp(cross);                         // 8
+        atlas_->upload();
+        dirty_ = false;
+    }
+
+    void raster(uint8_t* obs, hipStream_t s) {
+        launch_raster<MysteryComposer>(desc_.p, atlas_->dev(), obs, n_, s);
+        MG_HIP(hipGetLastError());
+    }
+
+    int n_;
+    MysteryParams P_;
+    double agent_scale_, agent_speed_, camera_offset_scale_ = 5.0;
+    bool dirty_ = true, seeded_ = false;
+    std::unique_ptr<Atlas> atlas_;
+    DevArray<MysteryCore> core_;
+    DevArray<uint8_t> segs_;
+    DevArray<uint32_t> falloff_;
+    DevArray<MysteryDesc> desc_;
+    DevArray<int> err_;
+    RngStore rng_;
+};
+
+Family* make_mystery(int endless, int num_envs) { return new MysteryFamily(endless, num_envs); }
+
+}  // namespace mg

@@ -271,6 +271,15 @@ inline std::vector<uint8_t> build_mortar_templates(int N, double scale, int scre
     return out;
 }
 
+// Fall-off cross (mystery_path.py:175-182): 40*scale square, two diagonal lines of width int(12*scale), red on colour key.
+inline Stamp build_cross(double scale) {
+    double dim = 40 * scale;
+    Stamp s((int)dim, (int)dim);
+    thick_line(s, 0, 0, (int)(dim - 1), (int)(dim - 1), (int)(12 * scale), PAL_RED);
+    thick_line(s, (int)(dim - 1), 0, 0, (int)(dim - 1), (int)(12 * scale), PAL_RED);
+    return s;
+}
+
 // Coin (pygame_assets.py:133-152): yellow disc, then an orange circle of width int(2*scale) (0 = filled) on top.
 // Box 2r x 2r, disc centre at (r, r): blit with the top-left at (x - r, y - r).
 inline Stamp build_coin(double coin_scale) {

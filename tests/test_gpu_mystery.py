@@ -1,0 +1,109 @@
+"""GPU parity (-m gpu) for the Mystery Path family: HIP path through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from gpu_parity import check_terminal_info, run_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _toward(d):
+    return 0 if d == 0 else (1 if d < 0 else 2)
+
+
+def path_follower(e, prng):
+    """MysteryPath-v0: walk along the oracle's path (end-first list) with occasional mistakes."""
+    if prng.random() > 0.93:
+        return [int(prng.integers(0, 3)), int(prng.integers(0, 3))]
+    path = e.get_list("path").reshape(-1, 2)
+    pos = (e.get("nx"), e.get("ny"))
+    idx = None
+    for k, (x, y) in enumerate(path):
+        if (x, y) == pos:
+            idx = k
+            break
+    if idx is None or idx == 0:
+        return [0, 0]
+    nx, ny = path[idx - 1]
+    return [_toward(nx * 12 + 6 - e.get("ax")), _toward(ny * 12 + 6 - e.get("ay"))]
+
+
+def endless_follower(e, prng):
+    if prng.random() > 0.96:
+        return [int(prng.integers(0, 4)), 0]
+    path = e.get_list("path").reshape(-1, 2)
+    cur = (e.get("cur_nx"), e.get("cur_ny"))
+    k = next((j for j, (x, y) in enumerate(path) if (x, y) == cur), None)
+    if k is None or k + 1 >= len(path):
+        return [0, 0]
+    nx, ny = path[k + 1]
+    dx, dy = nx * 12 + 6 - e.get("ax"), ny * 12 + 6 - e.get("ay")
+    if dy < 0:
+        return [2, 0]
+    if dy > 0:
+        return [3, 0]
+    if dx > 0:
+        return [1, 0]
+    return [0, 0]
+
+
+MP_OPTS = [
+    None,
+    dict(max_steps=64, cardinal_origin_choice=[2], show_origin=True, show_goal=True, reward_fall_off=-0.1, reward_step=-0.01,
+         reward_goal=2.0),
+    dict(cardinal_origin_choice=[1, 3], visual_feedback=False),
+]
+EMP_OPTS = [
+    None,
+    dict(max_steps=300, stamina_level=12, reward_fall_off=-0.1, reward_path_progress_dense=0.05, reward_step=-0.001,
+         camera_offset_scale=3.0),
+    dict(show_stamina=True, show_past_path=False, visual_feedback=False),
+]
+
+
+@pytest.mark.parametrize("opt_idx", range(len(MP_OPTS)))
+def test_finite_parity(opt_idx):
+    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=560 if opt_idx != 1 else 200, policy=path_follower, n_policy=64)
+    assert n_done > 0
+
+
+@pytest.mark.parametrize("opt_idx", range(len(EMP_OPTS)))
+def test_endless_parity(opt_idx):
+    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=400, policy=endless_follower, n_policy=64)
+    assert n_done > 0
+
+
+def test_terminal_info():
+    assert check_terminal_info("MysteryPath-v0", steps=520) > 0
+    assert check_terminal_info("Endless-MysteryPath-v0", steps=200) > 0
+
+
+def test_full_size_sample():
+    """BASELINE config C3 size (32,768 instances): a sample of instances must match single-instance oracles,
+    including the A* path generation at reset (seed = instance index)."""
+    import memory_gym_amd
+    import oracle_lib
+    import torch
+
+    n = 32768
+    env = memory_gym_amd.make("MysteryPath-v0", num_envs=n, device=0)
+    obs, _ = env.reset(seed=0, options=dict(max_steps=40))
+    sample = [0, 1, 255, 4095, 16384, 32767]
+    refs = {i: oracle_lib.OracleEnv("MysteryPath-v0") for i in sample}
+    first = obs[sample].cpu().numpy()
+    for k, i in enumerate(sample):
+        assert np.array_equal(first[k], refs[i].reset(i, options=dict(max_steps=40)))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(130):
+        a = torch.randint(0, 3, (n, 2), device="cuda", generator=g, dtype=torch.int32)
+        obs, rew, done, _, _ = env.step(a)
+        ac = a[sample].cpu().numpy()
+        got = obs[sample].cpu().numpy()
+        for k, i in enumerate(sample):
+            o, r, d = refs[i].step(ac[k])
+            if d:
+                o = refs[i].reset(None)
+            assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t)
+    for i in sample:
+        assert np.array_equal(env.rng_words(i), refs[i].rng_words())
+    env.close()
