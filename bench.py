@@ -124,7 +124,8 @@ def main():
     n_total = n_local * world
     env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank)
     # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
-    seeds = torch.arange(rank * n_local, (rank + 1) * n_local, device=dev, dtype=torch.int64)
+    from memory_gym_amd.dist import gather_to_rank0, shard_seeds
+    seeds = shard_seeds(n_total, rank, world, base_seed=0, device=dev)
     env.reset(seed=seeds)
 
     K, W = args.steps, args.warmup
@@ -135,14 +136,11 @@ def main():
     else:
         acts = [torch.randint(0, 3, (n_local, 2), device=dev, generator=g, dtype=torch.int32) for _ in range(n_act_bufs)]
 
-    gather_bufs = None
-    if args.gather and world > 1:
-        if rank == 0:
-            gather_bufs = [torch.empty_like(env.obs) for _ in range(world)]
+    gather_bufs = [torch.empty_like(env.obs) for _ in range(world)] if (args.gather and world > 1 and rank == 0) else None
 
     def one_step(k):
         obs, rew, done, _, _ = env.step(acts[k % n_act_bufs])
-        if args.gather and world > 1:
+        if args.gather and world > 1:  # equal shards: plain gather into preallocated buffers (no per-step allocation)
             dist.gather(obs, gather_bufs, dst=0)
 
     for k in range(W):

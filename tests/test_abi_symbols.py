@@ -1,0 +1,54 @@
+"""CPU test of the boundary: libmemgym_hip.so loads without a GPU and exports every function include/memgym.h
+declares (no compute calls are made here); the Python mirror keeps the reference's option keys and assertion text."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "endless-memory-gym_amd", "lib", "libmemgym_hip.so")
+
+
+def declared_symbols():
+    h = open(os.path.join(ROOT, "include", "memgym.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg_[a-z_0-9]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build_hip()
+    import torch  # noqa: F401  (same load order as the package: torch's HIP runtime first)
+    lib = ctypes.CDLL(LIB)
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libmemgym_hip.so does not export " + n
+
+
+def test_unknown_env_id_is_rejected_without_touching_the_gpu():
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB)
+    lib.mg_last_error.restype = ctypes.c_char_p
+    h = ctypes.c_void_p()
+    rc = lib.mg_create(b"NoSuchEnv-v0", 4, 0, ctypes.byref(h))
+    assert rc != 0 and h.value is None
+
+
+def test_reset_params_mirror_the_reference():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rp", os.path.join(ROOT, "endless-memory-gym_amd", "memory_gym_amd", "reset_params.py"))
+    rp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rp)
+    assert set(rp.DEFAULTS) == {"MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0", "MysteryPath-v0",
+                                "Endless-MysteryPath-v0", "SearingSpotlights-v0", "Endless-SearingSpotlights-v0"}
+    p = rp.process_reset_params("MortarMayhem-Grid-v0", {"arena_size": 6})
+    assert p["arena_size"] == 6 and p["command_count"] == [10] and p["explosion_delay"] == [6]
+    with pytest.raises(AssertionError, match=r"Provided reset parameter \(agent_speeed\) is not valid. Check spelling."):
+        rp.process_reset_params("MortarMayhem-v0", {"agent_speeed": 1})
+    with pytest.raises(AssertionError):
+        rp.process_reset_params("MortarMayhem-Grid-v0", {"arena_size": 7})
+    # calc_max_episode_steps with the reference's swapped arguments: 119 for MM-Grid, 275 for MM
+    assert rp.calc_max_episode_steps(10, 3, 1, 6, 2) == 119 and rp.calc_max_episode_steps(10, 3, 1, 18, 6) == 275

@@ -1,0 +1,76 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU plumbing in memory_gym_amd/dist.py: shard ranges / seeds are a
+partition that does not depend on the world size, and the rank-0 gather is byte-exact (also for ragged shards)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_dist_module():
+    # import the helper without importing the package __init__ (which loads the HIP library)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mg_dist", os.path.join(ROOT, "endless-memory-gym_amd", "memory_gym_amd", "dist.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _frames_for(lo, hi):
+    """Deterministic fake observations for global instances [lo, hi): frame i is filled with a pattern of i."""
+    idx = torch.arange(lo, hi, dtype=torch.int64)
+    f = (idx[:, None] * 31 + torch.arange(84 * 84 * 3, dtype=torch.int64)[None, :] * 7) % 251
+    return f.to(torch.uint8).reshape(-1, 84, 84, 3)
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _load_dist_module()
+    lo, hi = m.shard_range(n_total, rank, world)
+    seeds = m.shard_seeds(n_total, rank, world, base_seed=5)
+    assert seeds.tolist() == list(range(lo + 5, hi + 5))
+    obs = _frames_for(lo, hi)
+    rew = torch.arange(lo, hi, dtype=torch.float32) * 0.5
+    g_obs = m.gather_to_rank0(obs)
+    g_rew = m.gather_to_rank0(rew)
+    if rank == 0:
+        assert g_obs.shape[0] == n_total and torch.equal(g_obs, _frames_for(0, n_total))
+        assert torch.equal(g_rew, torch.arange(0, n_total, dtype=torch.float32) * 0.5)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert g_obs is None and g_rew is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_ranges_partition():
+    m = _load_dist_module()
+    for n in (1, 7, 64, 65536, 262144, 1000):
+        for w in (1, 2, 3, 8):
+            r = [m.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_gather_world2_even_and_ragged(tmp_path):
+    for n_total in (8, 9):
+        d = tmp_path / ("n%d" % n_total)
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), n_total, str(d)), nprocs=2, join=True)
+        assert (d / "ok").exists()
