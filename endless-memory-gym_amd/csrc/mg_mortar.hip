@@ -73,6 +73,7 @@ constexpr int STAMP_SPRITE0 = 0, STAMP_GLYPH0 = 8;
 
 struct MortarComposer {
     typedef MortarDesc Desc;
+    static constexpr bool TABLES_IN_LDS = false;
     static __device__ __forceinline__ bool skip(const Desc& d) { return d.tmpl == 0xFFFF; }
     static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
         fill_template(R, d.tmpl);

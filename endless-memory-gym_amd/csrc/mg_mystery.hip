@@ -66,6 +66,7 @@ static_assert(sizeof(MysteryDesc) == 64, "MysteryDesc must be 64 bytes");
 
 struct MysteryComposer {
     typedef MysteryDesc Desc;
+    static constexpr bool TABLES_IN_LDS = false;
     static __device__ __forceinline__ bool skip(const Desc& d) { return d.valid == 0; }
     static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
         fill_clear(R);

@@ -34,7 +34,7 @@ constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
 constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
 constexpr int RASTER_GRID = 256 * 7 * 8;      // 7 workgroups fit one CU's 160 KiB of LDS; 8 rounds of persistent workgroups (bench sweep: best of 2..37)
-constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
+constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;  // + sizeof(AtlasTables) when a Composer keeps the tables in LDS
 
 struct StampInfo {
     uint32_t off;  // byte offset into the stamp data, pixels stored [x][y] (column-major like the frame)
@@ -63,8 +63,9 @@ enum : uint8_t {
 };
 
 struct RasterCtx {
-    uint8_t* frame;   // LDS, [x][y][c]
-    uint32_t* mask;   // LDS, [84][MASK_WORDS] hole mask scratch
+    uint8_t* frame;         // LDS, [x][y][c]
+    uint32_t* mask;         // LDS, [84][MASK_WORDS] hole mask scratch
+    const AtlasTables* T;   // palette / stamp infos: the global copy, or an LDS copy made once per persistent workgroup
     RasterAtlas A;
     int tid;
 };
@@ -97,19 +98,54 @@ __device__ __forceinline__ void fill_clear(const RasterCtx& R) {
 }
 
 __device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
-    const StampInfo si = R.A.tables->stamps[id];
+    const StampInfo si = R.T->stamps[id];
     const uint8_t* sp = R.A.stamp_data + si.off;
     const int h = si.h, npx = si.w * h;
     for (int p = R.tid; p < npx; p += 256) {
         int px = p / h, py = p - px * h;
         uint8_t idx = sp[p];
         int X = x + px, Y = y + py;
-        if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, R.A.tables->palette[idx]);
+        if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, R.T->palette[idx]);
+    }
+}
+
+// The same blit split in two so that the stamp's pixels are requested from global memory EARLY (together with the
+// template loads) and applied later: one memory round trip per frame instead of one per layer.  K*256 >= w*h.
+template <int K>
+struct StampRegs {
+    uint8_t idx[K];
+    uint16_t w, h;
+};
+template <int K>
+__device__ __forceinline__ StampRegs<K> stamp_fetch(const RasterCtx& R, int id) {
+    StampRegs<K> s;
+    const StampInfo si = R.T->stamps[id];
+    const uint8_t* sp = R.A.stamp_data + si.off;
+    s.w = si.w;
+    s.h = si.h;
+    const int npx = si.w * si.h;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int p = R.tid + k * 256;
+        s.idx[k] = p < npx ? sp[p] : (uint8_t)0;
+    }
+    return s;
+}
+template <int K>
+__device__ __forceinline__ void stamp_apply(const RasterCtx& R, const StampRegs<K>& s, int x, int y) {
+    const int h = s.h;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int p = R.tid + k * 256;
+        int px = p / h, py = p - px * h;
+        int X = x + px, Y = y + py;
+        uint8_t idx = s.idx[k];
+        if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, R.T->palette[idx]);
     }
 }
 
 __device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, int h, int fill, bool bordered) {
-    const uint32_t cf = R.A.tables->palette[fill], ce = R.A.tables->palette[R.A.tables->border_of[fill]];
+    const uint32_t cf = R.T->palette[fill], ce = R.T->palette[R.T->border_of[fill]];
     for (int p = R.tid; p < w * h; p += 256) {
         int px = p / h, py = p - px * h;
         int X = x + px, Y = y + py;
@@ -135,18 +171,21 @@ __device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
 }
 
 // holes[i] = pack_hole(x, y, r): filled discs (pygame's even-diameter midpoint disc) that stay lit.
-// Contains its own barriers; the caller synchronises before (frame complete) and after (before drawing on top).
-__device__ __forceinline__ void darken(const RasterCtx& R, uint32_t alpha, const uint32_t* holes, int nholes) {
-    const int tid = R.tid;
-    uint32_t* mask = R.mask;
-    if (tid < SCREEN * MASK_WORDS) mask[tid] = 0u;
-    __syncthreads();
-    for (int hI = 0; hI < nholes; ++hI) {  // union of the hole discs as an 84x84 bit mask, one column per lane
+// hole_mask: union of the discs as an 84x84 bit mask in LDS; tasks = (hole, column), 4 holes x 64 columns per round,
+// so the span-table loads of all holes are in flight together.  The mask must have been zeroed (and synchronised).
+__device__ __forceinline__ void zero_mask(const RasterCtx& R) {
+    if (R.tid < SCREEN * MASK_WORDS) R.mask[R.tid] = 0u;
+}
+__device__ __forceinline__ void hole_mask(const RasterCtx& R, const uint32_t* holes, int nholes) {
+    const int sub = R.tid >> 6, col0 = R.tid & 63;
+    for (int base = 0; base < nholes; base += 4) {
+        int hI = base + sub;
+        if (hI >= nholes) continue;
         const uint32_t hv = holes[hI];
         const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
-        if (tid < 2 * r) {
-            int X = hx - r + tid;
-            int lo = R.A.disc_span[(r * 2 * DISC_RMAX + tid) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + tid) * 2 + 1];
+        for (int col = col0; col < 2 * r; col += 64) {
+            int X = hx - r + col;
+            int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
             int y0 = hy + lo, y1 = hy + hi;
             y0 = y0 < 0 ? 0 : y0;
             y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
@@ -157,18 +196,20 @@ __device__ __forceinline__ void darken(const RasterCtx& R, uint32_t alpha, const
                     a1 = a1 > 31 ? 31 : a1;
                     if (a0 <= a1) {
                         uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
-                        atomicOr(&mask[X * MASK_WORDS + wI], bits);
+                        atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
                     }
                 }
             }
         }
     }
-    __syncthreads();
-    // in-place darkening, 4 pixels (12 bytes = 3 dwords) per task: 84 columns x 21 segments
+}
+// in-place darkening of every pixel whose mask bit is clear; 4 pixels (12 bytes = 3 dwords) per task:
+// 84 columns x 21 segments.  The caller synchronises before (frame + mask complete) and after.
+__device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha) {
     uint32_t* f32 = reinterpret_cast<uint32_t*>(R.frame);
-    for (int k = tid; k < SCREEN * 21; k += 256) {
+    for (int k = R.tid; k < SCREEN * 21; k += 256) {
         int X = k / 21, seg = k - X * 21, y0 = seg * 4;
-        uint32_t lit = (mask[X * MASK_WORDS + (y0 >> 5)] >> (y0 & 31)) & 0xFu;
+        uint32_t lit = (R.mask[X * MASK_WORDS + (y0 >> 5)] >> (y0 & 31)) & 0xFu;
         if (lit == 0xFu) continue;
         uint32_t* p = f32 + X * (COL_BYTES / 4) + seg * 3;
         uint32_t v0 = p[0], v1 = p[1], v2 = p[2];
@@ -191,6 +232,7 @@ __device__ __forceinline__ void darken(const RasterCtx& R, uint32_t alpha, const
 //   struct Desc;                                   trivially copyable, sizeof % 16 == 0
 //   static __device__ bool skip(const Desc&);      true: leave the frame untouched (masked reset)
 //   static __device__ void compose(const Desc&, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
+//   static constexpr bool TABLES_IN_LDS;           copy palette/stamp infos to LDS once per persistent workgroup
 template <class Composer>
 __global__ __launch_bounds__(256) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
                                                      uint8_t* __restrict__ obs, int n) {
@@ -199,9 +241,17 @@ __global__ __launch_bounds__(256) void raster_kernel(const typename Composer::De
     R.frame = smem;
     R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
     R.A = A;
+    R.T = A.tables;
     R.tid = threadIdx.x;
     uint4* lds16 = reinterpret_cast<uint4*>(smem);
     const int tid = threadIdx.x;
+    if (Composer::TABLES_IN_LDS) {
+        static_assert(sizeof(AtlasTables) % 4 == 0 && sizeof(AtlasTables) / 4 <= 256, "tables prologue");
+        uint32_t* t = reinterpret_cast<uint32_t*>(smem + RASTER_LDS);
+        if (tid < (int)(sizeof(AtlasTables) / 4)) t[tid] = reinterpret_cast<const uint32_t*>(A.tables)[tid];
+        R.T = reinterpret_cast<const AtlasTables*>(t);
+        __syncthreads();
+    }
     for (int env = blockIdx.x; env < n; env += gridDim.x) {
         const typename Composer::Desc d = descs[env];  // workgroup-uniform
         if (Composer::skip(d)) continue;
@@ -224,7 +274,8 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         return e ? atoi(e) : RASTER_GRID;
     }();
     const int grid = n < tuned ? n : tuned;
-    hipLaunchKernelGGL(raster_kernel<Composer>, dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+    hipLaunchKernelGGL(raster_kernel<Composer>, dim3(grid), dim3(256), RASTER_LDS + (Composer::TABLES_IN_LDS ? sizeof(AtlasTables) : 0), s,
+                       descs, atlas, obs, n);
 }
 
 }  // namespace mg

@@ -7,10 +7,13 @@
 //   memory_gym/pygame_assets.py               GridPositionSampler :7-59  Spotlight :61-131  Coin :133-167  Exit :169-220
 //   memory_gym/character_controller.py        CharacterController.step :89-146
 //
-//   spot_step_kernel : one LANE per instance.  float64 spotlight trajectories (lerp of lerp, un-fused multiply-add:
-//                      the library is built with -ffp-contract=off), hit tests, coin/exit logic, grid sampler
-//                      (k-th free cell by per-row disc spans + popcount), RNG.  Spotlight slots are SoA [slot][N];
-//                      the Python list semantics (append / remove-while-iterating) live in a 16-nibble order word.
+//   spot_step_kernel : SIXTEEN LANES per instance (4 instances per wave).  Lane s owns spotlight slot s: float64
+//                      trajectory (lerp of lerp, un-fused multiply-add: the library is built with
+//                      -ffp-contract=off) and hit test; wave ballots collect the 16 done / hit flags of an instance.
+//                      The instance-level logic (agent, coin/exit, grid sampler, RNG, list bookkeeping) is executed
+//                      redundantly by the 16 lanes -- free under SIMD -- and stored by lane 0.  Slot arrays are
+//                      [N][16] so the 16 lanes of an instance read one contiguous 128-byte row per field; the
+//                      Python list semantics (append / remove-while-iterating) live in a 16-nibble order word.
 //   raster_kernel<SpotComposer> : chessboard template -> coin(s)/exit -> agent -> darken(alpha, holes) -> coin(s)
 //                      shown above the dark layer -> top bar.
 #include <memory>
@@ -75,13 +78,18 @@ constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
 
 struct SpotComposer {
     typedef SpotDesc Desc;
+    static constexpr bool TABLES_IN_LDS = true;
     static __device__ __forceinline__ bool skip(const Desc& d) { return d.valid == 0; }
     static __device__ __forceinline__ void coins(const Desc& d, const RasterCtx& R) {
         for (int k = 0; k < d.n_coins; ++k) stamp(R, ST_COIN, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128);
     }
     static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
+        // every global read of the frame is issued up front: sprite / coin / exit pixels into registers, template -> LDS
+        StampRegs<4> agent = stamp_fetch<4>(R, d.sprite);
         fill_template(R, d.bg);
+        zero_mask(R);
         __syncthreads();
+        if (d.alpha) hole_mask(R, d.holes, d.n_holes);  // mask words are disjoint from the frame
         if (!d.coin_above && d.n_coins) {
             coins(d, R);
             __syncthreads();
@@ -90,10 +98,10 @@ struct SpotComposer {
             stamp(R, d.exit_stamp, d.exit_x, d.exit_y);
             __syncthreads();
         }
-        stamp(R, d.sprite, d.sx, d.sy);
+        stamp_apply<4>(R, agent, d.sx, d.sy);
         __syncthreads();
         if (d.alpha) {
-            darken(R, d.alpha, d.holes, d.n_holes);
+            darken_apply(R, d.alpha);
             __syncthreads();
         }
         if (d.coin_above && d.n_coins) {
@@ -101,7 +109,7 @@ struct SpotComposer {
             __syncthreads();
         }
         // top bar: rows y < 4 of every column; priority reward bar > action rects > red > green > base
-        const AtlasTables* T = R.A.tables;
+        const AtlasTables* T = R.T;
         for (int p = R.tid; p < SCREEN * 4; p += 256) {
             int x = p >> 2, y = p & 3;
             int c = d.c_base;
@@ -115,8 +123,8 @@ struct SpotComposer {
 
 struct SpotIO {
     SpotCore* core;
-    double *sp_t, *sp_speed, *sp_sx, *sp_sy, *sp_tx, *sp_ty, *sp_ox, *sp_oy;  // [slot][N]
-    uint8_t *sp_r, *sp_done;                                                    // [slot][N]
+    double *sp_t, *sp_speed, *sp_sx, *sp_sy, *sp_tx, *sp_ty, *sp_ox, *sp_oy;  // [N][16]
+    uint8_t *sp_r, *sp_done;                                                    // [N][16]
     uint32_t* coins;  // [N][MAX_COINS] (x | y<<16), finite variant
     RngSoA rng;
     SpotDesc* desc;
@@ -130,52 +138,72 @@ __device__ __forceinline__ int isqrt_floor(int v) {
     return r;
 }
 
-// GridPositionSampler.sample: k-th un-blocked cell (row-major) of the 84x84 grid; discs: (x, y, r) with strict <
+// GridPositionSampler.sample: k-th un-blocked cell (row-major) of the 84x84 grid; discs: (x, y, r) with strict <.
+// Each row's blocked set is a union of intervals [cx - hw, cx + hw] with hw = isqrt(r^2 - dy^2 - 1); rows are
+// 84-bit masks built with shifts (no per-cell loops), free cells counted with popcounts.
+typedef unsigned __int128 u128m;
+__device__ __forceinline__ u128m row_mask(const int* dx, const int* dy, const int* dr, int nd, int y) {
+    u128m m = 0;
+    for (int d = 0; d < nd; ++d) {
+        int ddy = y - dy[d], rem = dr[d] * dr[d] - ddy * ddy - 1;
+        if (rem < 0) continue;
+        int hw = isqrt_floor(rem);
+        int a = dx[d] - hw, b = dx[d] + hw;
+        a = a < 0 ? 0 : a;
+        b = b > SCREEN - 1 ? SCREEN - 1 : b;
+        if (a > b) continue;
+        m |= (((u128m)1 << (b + 1)) - 1) ^ (((u128m)1 << a) - 1);
+    }
+    return m;
+}
+__device__ __forceinline__ int popc128(u128m m) { return __popcll((unsigned long long)m) + __popcll((unsigned long long)(m >> 64)); }
+
 __device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, int nd, int* ox, int* oy) {
-    int free_total = 0;
-    // pass 1: count
-    for (int pass = 0; pass < 2; ++pass) {
-        int k = 0;
-        if (pass == 1) k = g.integers(0, free_total);
-        for (int y = 0; y < SCREEN; ++y) {
-            uint64_t m_lo = 0;  // bits 0..63
-            uint32_t m_hi = 0;  // bits 64..83
-            for (int d = 0; d < nd; ++d) {
-                int ddy = y - dy[d], rem = dr[d] * dr[d] - ddy * ddy - 1;
-                if (rem < 0) continue;
-                int hw = isqrt_floor(rem);
-                int a = dx[d] - hw, b = dx[d] + hw;
-                a = a < 0 ? 0 : a;
-                b = b > SCREEN - 1 ? SCREEN - 1 : b;
-                if (a > b) continue;
-                for (int x = a; x <= b; ++x) {
-                    if (x < 64) m_lo |= 1ull << x;
-                    else m_hi |= 1u << (x - 64);
-                }
-            }
-            int fr = SCREEN - __popcll(m_lo) - __popc(m_hi);
-            if (pass == 0) {
-                free_total += fr;
-            } else {
-                if (k < fr) {
-                    for (int x = 0; x < SCREEN; ++x) {
-                        bool blocked = x < 64 ? ((m_lo >> x) & 1ull) : ((m_hi >> (x - 64)) & 1u);
-                        if (!blocked) {
-                            if (k == 0) {
-                                *ox = x;
-                                *oy = y;
-                                return free_total;
-                            }
-                            --k;
-                        }
+    if (nd == 0) {  // empty mask: cell k itself
+        int k = g.integers(0, SCREEN * SCREEN);
+        *oy = k / SCREEN;
+        *ox = k - *oy * SCREEN;
+        return SCREEN * SCREEN;
+    }
+    // only rows within reach of a disc can have blocked cells
+    int ylo = SCREEN, yhi = -1;
+    for (int d = 0; d < nd; ++d) {
+        int a = dy[d] - dr[d] + 1, b = dy[d] + dr[d] - 1;
+        ylo = a < ylo ? a : ylo;
+        yhi = b > yhi ? b : yhi;
+    }
+    ylo = ylo < 0 ? 0 : ylo;
+    yhi = yhi > SCREEN - 1 ? SCREEN - 1 : yhi;
+    int blocked = 0;
+    for (int y = ylo; y <= yhi; ++y) blocked += popc128(row_mask(dx, dy, dr, nd, y));
+    const int free_total = SCREEN * SCREEN - blocked;
+    int k = g.integers(0, free_total);
+    // rows above the first affected row are completely free
+    if (k < ylo * SCREEN) {
+        *oy = k / SCREEN;
+        *ox = k - *oy * SCREEN;
+        return free_total;
+    }
+    k -= ylo * SCREEN;
+    for (int y = ylo; y <= yhi; ++y) {
+        u128m m = row_mask(dx, dy, dr, nd, y);
+        int fr = SCREEN - popc128(m);
+        if (k < fr) {
+            for (int x = 0; x < SCREEN; ++x) {
+                if (!((m >> x) & 1)) {
+                    if (k == 0) {
+                        *ox = x;
+                        *oy = y;
+                        return free_total;
                     }
+                    --k;
                 }
-                k -= fr;
             }
         }
+        k -= fr;
     }
-    *ox = 0;
-    *oy = 0;
+    *oy = yhi + 1 + k / SCREEN;  // rows below the last affected row are completely free
+    *ox = k - (k / SCREEN) * SCREEN;
     return free_total;
 }
 
@@ -186,7 +214,8 @@ __device__ __forceinline__ void clamp_spawn(const SpotParams& P, int& x, int& y)
 }
 
 // Spotlight.__init__: 5 draws (radius, speed, start angle, target delta, offset delta)
-__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, SpotCore& s, Pcg& g) {
+// `ls` = this lane's slot id: every lane of the instance draws the same numbers, the owner of the chosen slot stores them
+__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g) {
     int radius = g.integers(P.r_lo, P.r_hi);
     double speed = g.uniform(P.speed_lo, P.speed_hi);
     int start = g.integers(0, 360);
@@ -200,7 +229,8 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, SpotCore&
     s.free_mask &= ~(1u << slot);
     s.order |= (uint64_t)slot << (4 * s.n_spots);
     s.n_spots++;
-    size_t k = (size_t)slot * P.n + i;
+    if (slot != ls) return;
+    size_t k = (size_t)i * SLOTS + slot;
     double R = P.half_diag + (double)radius, c = SCREEN / 2;
     io.sp_r[k] = (uint8_t)radius;
     io.sp_done[k] = 0;
@@ -230,7 +260,7 @@ __device__ void fill_topbar(const SpotParams& P, const SpotCore& s, SpotDesc& d,
     if (!reset_frame && P.show_last_positive_reward) d.c_bar = s.last_pos ? C_YELLOW : C_GREY50;
 }
 
-__device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, SpotCore& s, Pcg& g, SpotDesc& d, float* gt) {
+__device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt) {
     s.t = 0;
     s.coin_t = 0;
     s.ep_sum = 0.0;
@@ -261,12 +291,13 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, SpotCor
     s.free_mask = 0xFFFFu;
     s.spawn_timer = 0;
     s.n_intervals = (uint8_t)P.num_spawns;
-    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, s, g);
+    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g);
     s.coins_collected = 0;
     s.n_coins = 0;
     s.has_coin = 0;
     s.exit_open = 0;
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
+    uint32_t coin_pos[MAX_COINS];
     if (P.endless) {
         if (P.coin_enabled) {  // _spawn_coin: the sampler is reset first, self.coin is None -> nothing blocked
             int cx, cy;
@@ -289,7 +320,8 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, SpotCor
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
             clamp_spawn(P, cx, cy);
-            coins[k] = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
+            if (ls == 0) coins[k] = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
+            coin_pos[k] = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
             s.n_coins++;
         }
         int ex, ey;
@@ -322,7 +354,7 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, SpotCor
         d.n_coins = s.n_coins;
         d.coin_above = P.coins_visible ? 1 : 0;
         for (int k = 0; k < s.n_coins; ++k) {
-            int cx = (int)(int16_t)(coins[k] & 0xFFFF), cy = (int)(coins[k] >> 16);
+            int cx = (int)(int16_t)(coin_pos[k] & 0xFFFF), cy = (int)(coin_pos[k] >> 16);
             d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
         }
         d.exit_stamp = ST_EXIT_CLOSED;
@@ -346,12 +378,21 @@ __global__ __launch_bounds__(256) void spot_init_kernel(int n, SpotCore* core) {
     core[i] = s;
 }
 
+// the leader stores the descriptor's header + coin positions (first 64 bytes); hole words are written by the slot lanes
+__device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d) {
+    const uint4* src = reinterpret_cast<const uint4*>(&d);
+    uint4* out = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = src[k];
+}
+
 __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io, const int64_t* seeds, const uint8_t* mask,
                                                          float* gt) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = gid >> 4, ls = gid & 15;
     if (i >= P.n) return;
     if (mask && !mask[i]) {
-        io.desc[i].valid = 0;
+        if (ls == 0) io.desc[i].valid = 0;
         return;
     }
     Pcg g;
@@ -359,16 +400,21 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     else g.load(io.rng, i);
     SpotCore s = io.core[i];
     SpotDesc d;
-    spot_reset(P, io, i, s, g, d, (gt && P.endless) ? gt + 4 * i : nullptr);
-    io.core[i] = s;
-    g.store(io.rng, i);
-    io.desc[i] = d;
+    spot_reset(P, io, i, ls, s, g, d, (gt && P.endless && ls == 0) ? gt + 4 * i : nullptr);
+    if (ls == 0) {
+        io.core[i] = s;
+        g.store(io.rng, i);
+        store_desc_head(&io.desc[i], d);
+    }
 }
 
 __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io, const int32_t* actions, float* reward_out,
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = gid >> 4, ls = gid & 15;
     if (i >= P.n) return;
+    const int group_shift = (threadIdx.x & 63) & 48;  // bit position of this instance's 16 lanes in a wave ballot
+    const bool leader = ls == 0;
     SpotCore s = io.core[i];
     Pcg g;
     g.load(io.rng, i);
@@ -420,42 +466,64 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     s.spawn_timer++;
     if (P.endless) {
         if (s.spawn_timer >= P.spawn_interval) {
-            new_spot(P, io, i, s, g);
+            new_spot(P, io, i, ls, s, g);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
         if (s.spawn_timer >= P.interval0) {
-            new_spot(P, io, i, s, g);
+            new_spot(P, io, i, ls, s, g);
             s.n_intervals--;
             s.spawn_timer = 0;
         }
     }
-    int hit = 0, nh = 0;
-    for (int pos = 0; pos < s.n_spots; ++pos) {  // list mutated while iterated: the element after a removed one is skipped
-        int slot = (int)((s.order >> (4 * pos)) & 15u);
-        size_t k = (size_t)slot * P.n + i;
-        if (io.sp_done[k]) {
-            uint64_t low = s.order & ((1ull << (4 * pos)) - 1ull);
-            uint64_t high = pos == 15 ? 0ull : (s.order >> (4 * (pos + 1))) << (4 * pos);
-            s.order = low | high;
-            s.free_mask |= 1u << slot;
-            s.n_spots--;
-        } else {
-            double t = io.sp_t[k];
-            double lx = io.sp_tx[k] * (1 - t) + io.sp_ox[k] * t, ly = io.sp_ty[k] * (1 - t) + io.sp_oy[k] * t;
-            double cx = io.sp_sx[k] * (1 - t) + lx * t, cy = io.sp_sy[k] * (1 - t) + ly * t;
-            int radius = io.sp_r[k];
-            if (nh < MAX_HOLES) d.holes[nh++] = pack_hole((int)cx, (int)cy, radius);
-            t += io.sp_speed[k];
-            if (t >= 1.0) {
-                t = 1.0;
-                io.sp_done[k] = 1;
+    // lane ls looks after slot ls
+    const size_t k = (size_t)i * SLOTS + ls;
+    const bool used = !((s.free_mask >> ls) & 1u);
+    const bool my_done = used && io.sp_done[k] != 0;
+    const uint32_t done_mask = (uint32_t)(__ballot(my_done) >> group_shift) & 0xFFFFu;
+    // `for spot in self.spotlights: if spot.done: self.spotlights.remove(spot) else: draw + hit test`:
+    // removing while iterating skips the element that follows a removed one (it stays in the list untouched)
+    uint32_t processed = 0;
+    {
+        uint64_t new_order = 0;
+        int n_new = 0, n_old = s.n_spots;
+        for (int pos = 0; pos < n_old;) {
+            int slot = (int)((s.order >> (4 * pos)) & 15u);
+            if ((done_mask >> slot) & 1u) {
+                s.free_mask |= 1u << slot;
+                if (pos + 1 < n_old) {
+                    int nxt = (int)((s.order >> (4 * (pos + 1))) & 15u);
+                    new_order |= (uint64_t)nxt << (4 * n_new++);
+                }
+                pos += 2;
+            } else {
+                processed |= 1u << slot;
+                new_order |= (uint64_t)slot << (4 * n_new++);
+                pos += 1;
             }
-            io.sp_t[k] = t;
-            double ddx = (double)ax - cx, ddy = (double)ay - cy;
-            if (sqrt(ddx * ddx + ddy * ddy) <= (double)(radius + P.agent_radius)) hit++;
         }
+        s.order = new_order;
+        s.n_spots = (uint8_t)n_new;
     }
+    bool my_hit = false;
+    if ((processed >> ls) & 1u) {
+        double t = io.sp_t[k];
+        double lx = io.sp_tx[k] * (1 - t) + io.sp_ox[k] * t, ly = io.sp_ty[k] * (1 - t) + io.sp_oy[k] * t;
+        double cx = io.sp_sx[k] * (1 - t) + lx * t, cy = io.sp_sy[k] * (1 - t) + ly * t;
+        int radius = io.sp_r[k];
+        int rank = __popc(processed & ((1u << ls) - 1u));
+        io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius);
+        t += io.sp_speed[k];
+        if (t >= 1.0) {
+            t = 1.0;
+            io.sp_done[k] = 1;
+        }
+        io.sp_t[k] = t;
+        double ddx = (double)ax - cx, ddy = (double)ay - cy;
+        my_hit = sqrt(ddx * ddx + ddy * ddy) <= (double)(radius + P.agent_radius);
+    }
+    const int hit = __popc((uint32_t)(__ballot(my_hit) >> group_shift) & 0xFFFFu);
+    const int nh = __popc(processed);
     if (hit > 0) {
         s.health -= P.damage;
         r += P.r_inside;
@@ -474,6 +542,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     // ---- coin / exit tasks ----
     bool done = false;
     int success = 0;
+    uint32_t coin_pos[MAX_COINS];
     if (P.endless) {
         if (P.coin_enabled) {
             double cr = 0.0;
@@ -501,13 +570,14 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         if (s.t == P.max_steps) done = true;
     } else {
         bool coins_done;
+        for (int q = 0; q < MAX_COINS; ++q) coin_pos[q] = q < s.n_coins ? coins[q] : 0u;
         if (s.num_coins > 0) {
             double cr = 0.0;
-            for (int k = 0; k < s.n_coins; ++k) {  // remove-while-iterating: the coin after a collected one is skipped
-                int cx = (int)(int16_t)(coins[k] & 0xFFFF), cy = (int)(coins[k] >> 16);
+            for (int q = 0; q < s.n_coins; ++q) {  // remove-while-iterating: the coin after a collected one is skipped
+                int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
                 double ddx = (double)ax - cx, ddy = (double)ay - cy;
                 if (sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius)) {
-                    for (int j = k; j < s.n_coins - 1; ++j) coins[j] = coins[j + 1];
+                    for (int j = q; j < s.n_coins - 1; ++j) coin_pos[j] = coin_pos[j + 1];
                     s.n_coins--;
                     cr += P.r_coin;
                     s.coins_collected++;
@@ -539,7 +609,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     s.ep_sum += reward;
     s.ep_len++;
 
-    if (done) {
+    if (done && leader) {
         if (info.ep_reward_dev) info.ep_reward_dev[i] = s.ep_sum;
         if (info.ep_length_dev) info.ep_length_dev[i] = s.ep_len;
         if (info.aux_dev[0]) info.aux_dev[0][i] = (float)(s.health / P.agent_health);
@@ -550,11 +620,13 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
             if (info.aux_dev[2]) info.aux_dev[2][i] = (float)success;
         }
     }
-    reward_out[i] = (float)reward;
-    done_out[i] = done ? 1 : 0;
+    if (leader) {
+        reward_out[i] = (float)reward;
+        done_out[i] = done ? 1 : 0;
+    }
 
     if (done && autoreset) {
-        spot_reset(P, io, i, s, g, d, (gt && P.endless) ? gt + 4 * i : nullptr);
+        spot_reset(P, io, i, ls, s, g, d, (gt && P.endless && leader) ? gt + 4 * i : nullptr);
     } else {
         d.bg = s.bg_red;
         d.sprite = s.rot8;
@@ -570,9 +642,10 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         } else {
             d.n_coins = s.n_coins;
             d.coin_above = P.coins_visible ? 1 : 0;
-            for (int k = 0; k < s.n_coins; ++k) {
-                int cx = (int)(int16_t)(coins[k] & 0xFFFF), cy = (int)(coins[k] >> 16);
-                d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+            for (int q = 0; q < s.n_coins; ++q) {
+                int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
+                d.coins[q] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+                if (leader) coins[q] = coin_pos[q];
             }
             d.exit_stamp = s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED;
             d.exit_x = (int16_t)(s.exit_x - 5);
@@ -581,16 +654,18 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         SpotCore tb = s;
         tb.last_pos = shown_last_pos;  // the bar shows whether the PREVIOUS reward was positive
         fill_topbar(P, tb, d, false, shown0, shown1);
-        if (gt && P.endless) {
+        if (gt && P.endless && leader) {
             gt[4 * i + 0] = (float)((double)ax / SCREEN);
             gt[4 * i + 1] = (float)((double)ay / SCREEN);
             gt[4 * i + 2] = (float)(P.coin_enabled ? (double)s.coin_x / SCREEN : 0.0);
             gt[4 * i + 3] = (float)(P.coin_enabled ? (double)s.coin_y / SCREEN : 0.0);
         }
     }
-    g.store(io.rng, i);
-    io.core[i] = s;
-    io.desc[i] = d;
+    if (leader) {
+        g.store(io.rng, i);
+        io.core[i] = s;
+        store_desc_head(&io.desc[i], d);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -713,7 +788,7 @@ class SpotFamily : public Family {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;
-        hipLaunchKernelGGL(spot_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        hipLaunchKernelGGL(spot_reset_kernel, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
         raster(obs, s);
     }
 
@@ -724,7 +799,7 @@ class SpotFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        hipLaunchKernelGGL(spot_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+        hipLaunchKernelGGL(spot_step_kernel, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
         prof.end(0, s);
         prof.begin(1, s);
         raster(obs, s);
