@@ -28,19 +28,15 @@ class Atlas {
     int add_stamp(const Stamp& s) {
         int id = n_stamps_++;
         if (id >= MAX_STAMPS) throw std::runtime_error("too many stamps");
-        while (data_.size() % 4) data_.push_back(0);
         tables_.stamps[id].off = (uint32_t)data_.size();
         tables_.stamps[id].w = (uint16_t)s.w;
         tables_.stamps[id].h = (uint16_t)s.h;
         for (int x = 0; x < s.w; ++x)
-            for (int y = 0; y < s.h; ++y) data_.push_back(s.get(x, y));
+            for (int y = 0; y < s.h; ++y) data_.push_back(rgba(s.get(x, y)));
         return id;
     }
-    void set_stamp(int id, const Stamp& s) {  // replace in place (same size)
-        uint32_t off = tables_.stamps[id].off;
-        for (int x = 0; x < s.w; ++x)
-            for (int y = 0; y < s.h; ++y) data_[off + (size_t)x * s.h + y] = s.get(x, y);
-    }
+    // palette id -> r | g<<8 | b<<16 | 0xFF<<24 (opaque); id 0 is the colour key -> 0 (transparent)
+    uint32_t rgba(uint8_t id) const { return id ? (tables_.palette[id] | 0xFF000000u) : 0u; }
     int n_stamps() const { return n_stamps_; }
     void set_templates(const std::vector<uint8_t>& t) { templates_ = t; }
 
@@ -85,8 +81,10 @@ class Atlas {
    private:
     AtlasTables tables_;
     int n_stamps_ = 0;
-    std::vector<uint8_t> data_, templates_;
-    DevArray<uint8_t> stamp_dev_, templ_dev_;
+    std::vector<uint32_t> data_;
+    std::vector<uint8_t> templates_;
+    DevArray<uint32_t> stamp_dev_;
+    DevArray<uint8_t> templ_dev_;
     DevArray<int8_t> span_dev_;
     DevArray<AtlasTables> tables_dev_;
     RasterAtlas dev_;

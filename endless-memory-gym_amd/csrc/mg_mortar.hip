@@ -73,9 +73,9 @@ constexpr int STAMP_SPRITE0 = 0, STAMP_GLYPH0 = 8;
 
 struct MortarComposer {
     typedef MortarDesc Desc;
-    static constexpr bool TABLES_IN_LDS = false;
-    static __device__ __forceinline__ bool skip(const Desc& d) { return d.tmpl == 0xFFFF; }
-    static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
+    static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->tmpl == 0xFFFF; }
+    static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
+        const Desc& d = *dp;
         fill_template(R, d.tmpl);
         __syncthreads();
         if (d.sprite != 0xFF) stamp(R, STAMP_SPRITE0 + d.sprite, d.sx, d.sy);

@@ -66,9 +66,9 @@ static_assert(sizeof(MysteryDesc) == 64, "MysteryDesc must be 64 bytes");
 
 struct MysteryComposer {
     typedef MysteryDesc Desc;
-    static constexpr bool TABLES_IN_LDS = false;
-    static __device__ __forceinline__ bool skip(const Desc& d) { return d.valid == 0; }
-    static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
+    static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->valid == 0; }
+    static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
+        const Desc& d = *dp;
         fill_clear(R);
         __syncthreads();
         if (d.goal_on) rect(R, d.goal_x * 12, d.goal_y * 12, 12, 12, C_GREEN, false);

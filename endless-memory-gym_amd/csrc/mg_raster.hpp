@@ -34,10 +34,10 @@ constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
 constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
 constexpr int RASTER_GRID = 256 * 7 * 8;      // 7 workgroups fit one CU's 160 KiB of LDS; 8 rounds of persistent workgroups (bench sweep: best of 2..37)
-constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;  // + sizeof(AtlasTables) when a Composer keeps the tables in LDS
+constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
 
 struct StampInfo {
-    uint32_t off;  // byte offset into the stamp data, pixels stored [x][y] (column-major like the frame)
+    uint32_t off;  // pixel offset into the stamp data, pixels stored [x][y] (column-major like the frame)
     uint16_t w, h;
 };
 
@@ -50,7 +50,7 @@ struct AtlasTables {
 // Everything the raster kernel samples (device pointers; small enough to sit in the scalar/L1/L2 caches).
 struct RasterAtlas {
     const uint8_t* templates;   // [n_templates][84][84][3]
-    const uint8_t* stamp_data;  // palette indices, 0 = transparent
+    const uint32_t* stamp_data; // r | g<<8 | b<<16 | 0xFF<<24 per opaque pixel, 0 = transparent (colour key)
     const int8_t* disc_span;    // [DISC_RMAX+1][2*DISC_RMAX][2]: per column i of a radius-r disc, (lo, hi) y offsets; lo > hi = empty
     const AtlasTables* tables;
 };
@@ -65,7 +65,7 @@ enum : uint8_t {
 struct RasterCtx {
     uint8_t* frame;         // LDS, [x][y][c]
     uint32_t* mask;         // LDS, [84][MASK_WORDS] hole mask scratch
-    const AtlasTables* T;   // palette / stamp infos: the global copy, or an LDS copy made once per persistent workgroup
+    const AtlasTables* T;   // palette / stamp infos (global; indices are workgroup-uniform -> scalar loads)
     RasterAtlas A;
     int tid;
 };
@@ -99,13 +99,13 @@ __device__ __forceinline__ void fill_clear(const RasterCtx& R) {
 
 __device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
     const StampInfo si = R.T->stamps[id];
-    const uint8_t* sp = R.A.stamp_data + si.off;
+    const uint32_t* sp = R.A.stamp_data + si.off;
     const int h = si.h, npx = si.w * h;
     for (int p = R.tid; p < npx; p += 256) {
         int px = p / h, py = p - px * h;
-        uint8_t idx = sp[p];
+        uint32_t c = sp[p];
         int X = x + px, Y = y + py;
-        if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, R.T->palette[idx]);
+        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
     }
 }
 
@@ -113,21 +113,20 @@ __device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) 
 // template loads) and applied later: one memory round trip per frame instead of one per layer.  K*256 >= w*h.
 template <int K>
 struct StampRegs {
-    uint8_t idx[K];
-    uint16_t w, h;
+    uint32_t px[K];
+    int h;
 };
 template <int K>
 __device__ __forceinline__ StampRegs<K> stamp_fetch(const RasterCtx& R, int id) {
     StampRegs<K> s;
     const StampInfo si = R.T->stamps[id];
-    const uint8_t* sp = R.A.stamp_data + si.off;
-    s.w = si.w;
+    const uint32_t* sp = R.A.stamp_data + si.off;
     s.h = si.h;
     const int npx = si.w * si.h;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         int p = R.tid + k * 256;
-        s.idx[k] = p < npx ? sp[p] : (uint8_t)0;
+        s.px[k] = p < npx ? sp[p] : 0u;
     }
     return s;
 }
@@ -139,8 +138,8 @@ __device__ __forceinline__ void stamp_apply(const RasterCtx& R, const StampRegs<
         int p = R.tid + k * 256;
         int px = p / h, py = p - px * h;
         int X = x + px, Y = y + py;
-        uint8_t idx = s.idx[k];
-        if (idx && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, R.T->palette[idx]);
+        uint32_t c = s.px[k];
+        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
     }
 }
 
@@ -203,6 +202,55 @@ __device__ __forceinline__ void hole_mask(const RasterCtx& R, const uint32_t* ho
         }
     }
 }
+// hole_mask split in two for radii <= 32 and <= 16 holes: the span-table bytes are requested up front (with the other
+// global reads of the frame), the LDS atomics happen after the mask has been zeroed.
+struct HoleRegs {
+    uint32_t v[4];  // per round: x | y0 << 8 | y1 << 16 | valid << 24 (column and clipped y range handled by this lane)
+};
+__device__ __forceinline__ bool holes_prefetchable(const uint32_t* holes, int nholes) {
+    bool ok = nholes <= 16;
+    for (int h = 0; h < nholes; ++h) ok = ok && (int)(holes[h] >> 18) <= 32;
+    return ok;
+}
+__device__ __forceinline__ HoleRegs hole_fetch(const RasterCtx& R, const uint32_t* holes, int nholes) {
+    HoleRegs H;
+    const int sub = R.tid >> 6, col = R.tid & 63;
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        H.v[rnd] = 0u;
+        int hI = rnd * 4 + sub;
+        if (hI < nholes) {
+            const uint32_t hv = holes[hI];
+            const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
+            if (col < 2 * r) {
+                int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
+                int X = hx - r + col, y0 = hy + lo, y1 = hy + hi;
+                y0 = y0 < 0 ? 0 : y0;
+                y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
+                if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) H.v[rnd] = (uint32_t)X | ((uint32_t)y0 << 8) | ((uint32_t)y1 << 16) | (1u << 24);
+            }
+        }
+    }
+    return H;
+}
+__device__ __forceinline__ void hole_apply(const RasterCtx& R, const HoleRegs& H) {
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        const uint32_t hv = H.v[rnd];
+        if (!(hv >> 24)) continue;
+        int X = (int)(hv & 255u), y0 = (int)((hv >> 8) & 255u), y1 = (int)((hv >> 16) & 255u);
+        for (int wI = 0; wI < MASK_WORDS; ++wI) {
+            int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
+            a0 = a0 < 0 ? 0 : a0;
+            a1 = a1 > 31 ? 31 : a1;
+            if (a0 <= a1) {
+                uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
+                atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
+            }
+        }
+    }
+}
+
 // in-place darkening of every pixel whose mask bit is clear; 4 pixels (12 bytes = 3 dwords) per task:
 // 84 columns x 21 segments.  The caller synchronises before (frame + mask complete) and after.
 __device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha) {
@@ -230,11 +278,12 @@ __device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha)
 
 // Composer concept:
 //   struct Desc;                                   trivially copyable, sizeof % 16 == 0
-//   static __device__ bool skip(const Desc&);      true: leave the frame untouched (masked reset)
-//   static __device__ void compose(const Desc&, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
-//   static constexpr bool TABLES_IN_LDS;           copy palette/stamp infos to LDS once per persistent workgroup
+//   static __device__ bool skip(const Desc*);      true: leave the frame untouched (masked reset)
+//   static __device__ void compose(const Desc*, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
+// The descriptor is read through its (workgroup-uniform) global pointer, so every field access -- also array
+// elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
 template <class Composer>
-__global__ __launch_bounds__(256) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
+__global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
                                                      uint8_t* __restrict__ obs, int n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     RasterCtx R;
@@ -245,15 +294,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const typename Composer::De
     R.tid = threadIdx.x;
     uint4* lds16 = reinterpret_cast<uint4*>(smem);
     const int tid = threadIdx.x;
-    if (Composer::TABLES_IN_LDS) {
-        static_assert(sizeof(AtlasTables) % 4 == 0 && sizeof(AtlasTables) / 4 <= 256, "tables prologue");
-        uint32_t* t = reinterpret_cast<uint32_t*>(smem + RASTER_LDS);
-        if (tid < (int)(sizeof(AtlasTables) / 4)) t[tid] = reinterpret_cast<const uint32_t*>(A.tables)[tid];
-        R.T = reinterpret_cast<const AtlasTables*>(t);
-        __syncthreads();
-    }
     for (int env = blockIdx.x; env < n; env += gridDim.x) {
-        const typename Composer::Desc d = descs[env];  // workgroup-uniform
+        const typename Composer::Desc* d = descs + env;  // workgroup-uniform
         if (Composer::skip(d)) continue;
         Composer::compose(d, R);
         __syncthreads();
@@ -274,8 +316,7 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         return e ? atoi(e) : RASTER_GRID;
     }();
     const int grid = n < tuned ? n : tuned;
-    hipLaunchKernelGGL(raster_kernel<Composer>, dim3(grid), dim3(256), RASTER_LDS + (Composer::TABLES_IN_LDS ? sizeof(AtlasTables) : 0), s,
-                       descs, atlas, obs, n);
+    hipLaunchKernelGGL(raster_kernel<Composer>, dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
 }
 
 }  // namespace mg

@@ -78,26 +78,38 @@ constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
 
 struct SpotComposer {
     typedef SpotDesc Desc;
-    static constexpr bool TABLES_IN_LDS = true;
-    static __device__ __forceinline__ bool skip(const Desc& d) { return d.valid == 0; }
-    static __device__ __forceinline__ void coins(const Desc& d, const RasterCtx& R) {
-        for (int k = 0; k < d.n_coins; ++k) stamp(R, ST_COIN, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128);
+    static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->valid == 0; }
+    static __device__ __forceinline__ void coins(const Desc& d, const RasterCtx& R, const StampRegs<1>& coin) {
+        for (int k = 0; k < d.n_coins; ++k)  // coins keep their distance from each other (sampler block radius): no overlap
+            stamp_apply<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128);
     }
-    static __device__ __forceinline__ void compose(const Desc& d, const RasterCtx& R) {
-        // every global read of the frame is issued up front: sprite / coin / exit pixels into registers, template -> LDS
+    static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
+        const Desc& d = *dp;
+        // every global read of the frame is issued up front (sprite / coin / exit pixels and disc spans into registers,
+        // template -> LDS): one memory round trip per frame after the descriptor
+        const AtlasTables* T = R.T;
+        const uint32_t c_base = d.c_base != 0xFF ? T->palette[d.c_base] : 0u, c_green = T->palette[C_GREEN], c_red = T->palette[C_RED];
+        const uint32_t c_a0 = d.c_act0 != 0xFF ? T->palette[d.c_act0] : 0u, c_a1 = d.c_act1 != 0xFF ? T->palette[d.c_act1] : 0u;
+        const uint32_t c_bar = d.c_bar != 0xFF ? T->palette[d.c_bar] : 0u;
         StampRegs<4> agent = stamp_fetch<4>(R, d.sprite);
+        StampRegs<1> coin, exitp;
+        coin.px[0] = exitp.px[0] = 0u;
+        coin.h = exitp.h = 1;
+        if (d.n_coins) coin = stamp_fetch<1>(R, ST_COIN);
+        if (d.exit_stamp != 0xFF) exitp = stamp_fetch<1>(R, d.exit_stamp);
+        const bool pre = d.alpha && holes_prefetchable(d.holes, d.n_holes);
+        HoleRegs H;
+        if (pre) H = hole_fetch(R, d.holes, d.n_holes);
         fill_template(R, d.bg);
         zero_mask(R);
         __syncthreads();
-        if (d.alpha) hole_mask(R, d.holes, d.n_holes);  // mask words are disjoint from the frame
-        if (!d.coin_above && d.n_coins) {
-            coins(d, R);
-            __syncthreads();
+        if (d.alpha) {  // the mask words are disjoint from the frame bytes
+            if (pre) hole_apply(R, H);
+            else hole_mask(R, d.holes, d.n_holes);
         }
-        if (d.exit_stamp != 0xFF) {
-            stamp(R, d.exit_stamp, d.exit_x, d.exit_y);
-            __syncthreads();
-        }
+        if (!d.coin_above && d.n_coins) coins(d, R, coin);
+        if (d.exit_stamp != 0xFF) stamp_apply<1>(R, exitp, d.exit_x, d.exit_y);  // never overlaps a coin (sampler)
+        __syncthreads();
         stamp_apply<4>(R, agent, d.sx, d.sy);
         __syncthreads();
         if (d.alpha) {
@@ -105,18 +117,18 @@ struct SpotComposer {
             __syncthreads();
         }
         if (d.coin_above && d.n_coins) {
-            coins(d, R);
+            coins(d, R, coin);
             __syncthreads();
         }
         // top bar: rows y < 4 of every column; priority reward bar > action rects > red > green > base
-        const AtlasTables* T = R.T;
         for (int p = R.tid; p < SCREEN * 4; p += 256) {
             int x = p >> 2, y = p & 3;
-            int c = d.c_base;
-            if (x < 2 * d.quarter) c = x < d.red_w ? C_RED : C_GREEN;
-            else if (d.c_act0 != 0xFF) c = x < 3 * d.quarter ? d.c_act0 : d.c_act1;
-            if (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w) c = d.c_bar;
-            if (c != 0xFF) put_rgb(R.frame, x, y, T->palette[c]);
+            uint32_t c = c_base;
+            bool has = d.c_base != 0xFF;
+            if (x < 2 * d.quarter) { c = x < d.red_w ? c_red : c_green; has = true; }
+            else if (d.c_act0 != 0xFF) { c = x < 3 * d.quarter ? c_a0 : c_a1; has = true; }
+            if (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w) { c = c_bar; has = true; }
+            if (has) put_rgb(R.frame, x, y, c);
         }
     }
 };
