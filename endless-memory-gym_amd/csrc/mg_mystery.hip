@@ -69,6 +69,9 @@ struct MysteryComposer {
     static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->valid == 0; }
     static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
         const Desc& d = *dp;
+        StampRegs<4> sprite = stamp_fetch<4>(R, d.sprite);
+        StampRegs<1> cross;
+        if (d.cross_on) cross = stamp_fetch<1>(R, ST_CROSS);
         fill_clear(R);
         __syncthreads();
         if (d.goal_on) rect(R, d.goal_x * 12, d.goal_y * 12, 12, 12, C_GREEN, false);
@@ -83,7 +86,7 @@ struct MysteryComposer {
             }
         }
         __syncthreads();
-        stamp(R, d.sprite, d.sx, d.sy);
+        stamp_apply<4>(R, sprite, d.sx, d.sy);
         if (d.stamina_on) {
             __syncthreads();
             rect(R, SCREEN - 4, 0, 4, SCREEN, C_GREEN, false);
@@ -94,7 +97,7 @@ struct MysteryComposer {
         }
         if (d.cross_on) {
             __syncthreads();
-            stamp(R, ST_CROSS, d.cross_x, d.cross_y);
+            stamp_apply<1>(R, cross, d.cross_x, d.cross_y);
         }
     }
 };
