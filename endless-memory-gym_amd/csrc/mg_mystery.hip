@@ -128,22 +128,53 @@ __device__ __forceinline__ int diag_of(int idx, int k) {
     return (x > 0 && y < G - 1) ? idx - G + 1 : -1;
 }
 
-__device__ __noinline__ int generate_path(Pcg& g, int sx, int sy, int ex, int ey, uint8_t* out) {
+// Per-lane A* workspace in LDS (the path generator's arrays are indexed with run-time values; in private memory they
+// would live in scratch, i.e. a global-memory round trip per access).  Planes are interleaved by lane:
+// element k of lane t sits at plane[k * 256 + t].
+constexpr int WS_G = 0;                          // uint16 g_cost[49]
+constexpr int WS_PREV = WS_G + 49 * 2 * 256;     // int8  previous_node[49]
+constexpr int WS_OPEN = WS_PREV + 49 * 256;      // uint8 open_set[49] (ordered list)
+constexpr int WS_OUTER = WS_OPEN + 49 * 256;     // uint8 outer_nodes[28]
+constexpr int WS_OUT = WS_OPEN;                  // uint8 path out[49]: reuses the open-set plane (traced back once the search is over)
+constexpr int WS_SQRT = WS_OUTER + 28 * 256;     // double sqrt_tab[80] shared by the block (heuristic values)
+constexpr int WS_BYTES = WS_SQRT + 80 * 8;
+static_assert(WS_SQRT % 8 == 0 && WS_BYTES <= 65536, "A* workspace layout");
+
+struct PathWS {
+    uint8_t* base;
+    int tid;
+    __device__ __forceinline__ uint16_t& g(int k) const { return reinterpret_cast<uint16_t*>(base + WS_G)[k * 256 + tid]; }
+    __device__ __forceinline__ int8_t& prev(int k) const { return reinterpret_cast<int8_t*>(base + WS_PREV)[k * 256 + tid]; }
+    __device__ __forceinline__ uint8_t& open(int k) const { return (base + WS_OPEN)[k * 256 + tid]; }
+    __device__ __forceinline__ uint8_t& outer(int k) const { return (base + WS_OUTER)[k * 256 + tid]; }
+    __device__ __forceinline__ uint8_t& out(int k) const { return (base + WS_OUT)[k * 256 + tid]; }
+    __device__ __forceinline__ double h(int d2) const { return reinterpret_cast<const double*>(base + WS_SQRT)[d2]; }
+};
+
+__device__ __forceinline__ void path_ws_init(uint8_t* smem) {  // all threads of the block, before any path is generated
+    if (threadIdx.x < 80) reinterpret_cast<double*>(smem + WS_SQRT)[threadIdx.x] = sqrt((double)threadIdx.x);
+    __syncthreads();
+}
+
+// f_cost of a node that has entered the open set: the reference stores g_cost + h_cost whenever it (re)computes f, and
+// its `neighbor.g = g` typo means g_cost never changes afterwards -> f is always g_cost + h, no separate array needed.
+__device__ __forceinline__ double f_of(const PathWS& W, int node, int ex, int ey) {
+    int ax = node / G, ay = node - ax * G;
+    int ddx = ax - ex, ddy = ay - ey;
+    return (double)W.g(node) + W.h(ddx * ddx + ddy * ddy);
+}
+
+__device__ __noinline__ int generate_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey) {
     uint64_t wall = 0, closed = 0, in_open = 0;
-    int gcost[G * G];
-    double fcost[G * G];
-    int8_t prev[G * G];
     for (int i = 0; i < G * G; ++i) {
-        gcost[i] = 0;
-        fcost[i] = 0.0;
-        prev[i] = -1;
+        W.g(i) = 0;
+        W.prev(i) = -1;
     }
     for (int i = 0; i < G; ++i)
         for (int j = 0; j < G; ++j)
             if (i > 0 && i < G - 2 && j > 0 && j < G - 2)
                 if (g.integers(0, 100) < 33) wall |= 1ull << (i * G + j);
     const int start = sx * G + sy, end = ex * G + ey;
-    uint8_t outer[4 * G];
     int n_outer = 0;
     for (int i = 0; i < G; ++i)
         for (int j = 0; j < G; ++j) {
@@ -160,65 +191,63 @@ __device__ __noinline__ int generate_path(Pcg& g, int sx, int sy, int ex, int ey
                 q = diag_of(idx, k);
                 if (q >= 0 && ((wall >> q) & 1ull)) adj = true;
             }
-            if (!adj) outer[n_outer++] = (uint8_t)idx;
+            if (!adj) W.outer(n_outer++) = (uint8_t)idx;
         }
     int n_iter = g.integers(0, 2) == 0 ? 4 : 8;  // rng.choice([4, 8])
     for (int it = 0; it < n_iter; ++it) {
         if (n_outer > 0) {
             int k = g.integers(0, n_outer);
-            int idx = outer[k];
+            int idx = W.outer(k);
             wall |= 1ull << idx;
-            for (int q = k; q < n_outer - 1; ++q) outer[q] = outer[q + 1];
+            for (int q = k; q < n_outer - 1; ++q) W.outer(q) = W.outer(q + 1);
             --n_outer;
         }
     }
-    uint8_t open[G * G];
     int n_open = 0;
-    open[n_open++] = (uint8_t)start;
+    W.open(n_open++) = (uint8_t)start;
     in_open |= 1ull << start;
     for (;;) {
         if (n_open == 0) return -1;
         int w = 0;
-        for (int i = 0; i < n_open; ++i)
-            if (fcost[open[i]] < fcost[open[0]]) {  // first strictly better than open[0], then break
-                w = i;
-                break;
-            }
-        int cur = open[w];
+        {
+            const double f0 = f_of(W, W.open(0), ex, ey);
+            for (int i = 1; i < n_open; ++i)
+                if (f_of(W, W.open(i), ex, ey) < f0) {  // first strictly better than open[0], then break
+                    w = i;
+                    break;
+                }
+        }
+        int cur = W.open(w);
         if (cur == end) {
-            int len = 0, t = cur;
-            out[len++] = (uint8_t)end;
-            while (prev[t] >= 0) {
-                out[len++] = (uint8_t)prev[t];
-                t = prev[t];
+            int len = 0, t = cur;  // the open set is dead from here on: its plane receives the path
+            W.out(len++) = (uint8_t)end;
+            while (W.prev(t) >= 0) {
+                int pv = W.prev(t);
+                W.out(len++) = (uint8_t)pv;
+                t = pv;
             }
             return len;
         }
-        for (int q = w; q < n_open - 1; ++q) open[q] = open[q + 1];
+        for (int q = w; q < n_open - 1; ++q) W.open(q) = W.open(q + 1);
         --n_open;
         in_open &= ~(1ull << cur);
         closed |= 1ull << cur;
+        const int gcur = W.g(cur);
         for (int k = 0; k < 4; ++k) {
             int nb = nb_of(cur, k);
             if (nb < 0) continue;
             if (((closed >> nb) & 1ull) || ((wall >> nb) & 1ull)) continue;
-            int gg = gcost[cur] + g.integers(1, 9);
+            int gg = gcur + g.integers(1, 9);
             bool new_path = false;
             if ((in_open >> nb) & 1ull) {
-                if (gg < gcost[nb]) new_path = true;  // `neighbor.g = g` typo: g_cost is NOT updated
+                if (gg < (int)W.g(nb)) new_path = true;  // `neighbor.g = g` typo: g_cost is NOT updated
             } else {
-                gcost[nb] = gg;
+                W.g(nb) = (uint16_t)gg;
                 new_path = true;
-                open[n_open++] = (uint8_t)nb;
+                W.open(n_open++) = (uint8_t)nb;
                 in_open |= 1ull << nb;
             }
-            if (new_path) {
-                int ax = nb / G, ay = nb - ax * G;
-                int ddx = ax - ex, ddy = ay - ey;
-                double h = sqrt((double)(ddx * ddx) + (double)(ddy * ddy));
-                fcost[nb] = (double)gcost[nb] + h;
-                prev[nb] = (int8_t)cur;
-            }
+            if (new_path) W.prev(nb) = (int8_t)cur;
         }
     }
 }
@@ -255,7 +284,7 @@ __device__ __forceinline__ void move_agent(const MysteryParams& P, MysteryCore& 
 }
 
 // ============================================ finite ============================================
-__device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, MysteryCore& s, Pcg& g, MysteryDesc& d) {
+__device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, const PathWS& W, MysteryCore& s, Pcg& g, MysteryDesc& d) {
     s.t = 0;
     s.ep_sum = 0.0;
     s.ep_len = 0;
@@ -265,14 +294,13 @@ __device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, MysteryCor
     else if (cardinal == 1) { sx = G - 1; sy = g.integers(0, G); ex = 0; ey = g.integers(0, G); }
     else if (cardinal == 2) { sx = g.integers(0, G); sy = 0; ex = g.integers(0, G); ey = G - 1; }
     else { sx = g.integers(0, G); sy = G - 1; ex = g.integers(0, G); ey = 0; }
-    uint8_t path[G * G];
-    int len = generate_path(g, sx, sy, ex, ey, path);
+    int len = generate_path(g, W, sx, sy, ex, ey);
     if (len < 0) {
         atomicOr(io.err, 2);
         len = 0;
     }
     uint64_t pm = 0;
-    for (int k = 0; k < len; ++k) pm |= 1ull << path[k];
+    for (int k = 0; k < len; ++k) pm |= 1ull << W.out(k);
     s.path_mask = pm;
     s.visited_mask = 0;
     s.path_len = (uint8_t)len;
@@ -292,7 +320,7 @@ __device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, MysteryCor
     d.origin_on = P.show_origin ? 1 : 0; d.origin_x = (uint8_t)sx; d.origin_y = (uint8_t)sy;
 }
 
-__device__ void mp_step(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
+__device__ void mp_step(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
                         const int32_t* actions, float* reward_out, uint8_t* done_out, const mg_info_buffers& info,
                         int autoreset, MysteryDesc& d) {
     double reward = 0.0;
@@ -344,7 +372,7 @@ __device__ void mp_step(const MysteryParams& P, const MysteryIO& io, int i, Myst
     reward_out[i] = (float)reward;
     done_out[i] = done ? 1 : 0;
     if (done && autoreset) {
-        mp_reset(P, io, s, g, d);
+        mp_reset(P, io, W, s, g, d);
         rng_dirty = true;
     } else {
         memset(&d, 0, sizeof(d));
@@ -368,7 +396,7 @@ __device__ __forceinline__ int node_x(int seg, uint8_t b) { return seg * (G + 1)
 __device__ __forceinline__ int node_y(uint8_t b) { return (b >> 3) & 7; }
 
 // EndlessMysteryPath.add_path_segment
-__device__ void emp_add_segment(const MysteryIO& io, int i, MysteryCore& s, Pcg& g) {
+__device__ void emp_add_segment(const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g) {
     int sy;
     if (!s.have_start) {
         sy = g.integers(0, G);
@@ -378,8 +406,7 @@ __device__ void emp_add_segment(const MysteryIO& io, int i, MysteryCore& s, Pcg&
     }
     int ey = g.integers(0, G);
     s.end_y = (int8_t)ey;
-    uint8_t path[G * G];
-    int len = generate_path(g, 0, sy, G - 1, ey, path);
+    int len = generate_path(g, W, 0, sy, G - 1, ey);
     if (len < 0) {
         atomicOr(io.err, 2);
         len = 0;
@@ -391,7 +418,8 @@ __device__ void emp_add_segment(const MysteryIO& io, int i, MysteryCore& s, Pcg&
     uint8_t* sp = seg_ptr(io, i, s.num_seg);
     int n = 0;
     for (int k = len - 1; k >= 0; --k) {
-        int x = path[k] / G, y = path[k] - x * G;
+        int pk = W.out(k);
+        int x = pk / G, y = pk - x * G;
         sp[1 + n++] = (uint8_t)(x | (y << 3));
     }
     sp[1 + n++] = (uint8_t)(7 | (ey << 3));  // transition node at x = 8*seg + 7
@@ -464,13 +492,13 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
     }
 }
 
-__device__ void emp_reset(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, Pcg& g, MysteryDesc& d, float* gt) {
+__device__ void emp_reset(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g, MysteryDesc& d, float* gt) {
     s.t = 0;
     s.ep_sum = 0.0;
     s.ep_len = 0;
     s.num_seg = 0;
     s.have_start = 0;
-    for (int k = 0; k < 3; ++k) emp_add_segment(io, i, s, g);
+    for (int k = 0; k < 3; ++k) emp_add_segment(io, W, i, s, g);
     uint8_t* s0 = seg_ptr(io, i, 0);
     s0[1] |= 1u << 6;  // the first node of the path shall not yield any reward
     s.sx = (uint8_t)node_x(0, s0[1]);
@@ -496,7 +524,7 @@ __device__ void emp_reset(const MysteryParams& P, const MysteryIO& io, int i, My
     if (P.show_stamina) d.stamina_red = 0;
 }
 
-__device__ void emp_step(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
+__device__ void emp_step(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
                          const int32_t* actions, float* reward_out, uint8_t* done_out, float* gt,
                          const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
     int a = actions[i];
@@ -517,7 +545,7 @@ __device__ void emp_step(const MysteryParams& P, const MysteryIO& io, int i, Mys
     s.cur_seg = nx / (G + 1);
     int seg = s.cur_seg;
     if (s.cur_seg > s.num_seg - 2) {
-        emp_add_segment(io, i, s, g);
+        emp_add_segment(io, W, i, s, g);
         rng_dirty = true;
     }
     bool on_path = false;
@@ -599,7 +627,7 @@ __device__ void emp_step(const MysteryParams& P, const MysteryIO& io, int i, Mys
     reward_out[i] = (float)reward;
     done_out[i] = done ? 1 : 0;
     if (done && autoreset) {
-        emp_reset(P, io, i, s, g, d, gt);
+        emp_reset(P, io, W, i, s, g, d, gt);
         rng_dirty = true;
     } else {
         emp_fill_desc(P, io, i, s, d, nx);
@@ -616,6 +644,9 @@ __global__ __launch_bounds__(256) void mystery_init_kernel(int n, MysteryCore* c
 
 __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds,
                                                             const uint8_t* mask, float* gt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    path_ws_init(smem);
+    const PathWS W{smem, (int)threadIdx.x};
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     if (mask && !mask[i]) {
@@ -627,8 +658,8 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
     else g.load(io.rng, i);
     MysteryCore s = io.core[i];
     MysteryDesc d;
-    if (P.endless) emp_reset(P, io, i, s, g, d, gt ? gt + 3 * i : nullptr);
-    else mp_reset(P, io, s, g, d);
+    if (P.endless) emp_reset(P, io, W, i, s, g, d, gt ? gt + 3 * i : nullptr);
+    else mp_reset(P, io, W, s, g, d);
     io.core[i] = s;
     g.store(io.rng, i);
     io.desc[i] = d;
@@ -637,6 +668,9 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
 __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions,
                                                            float* reward_out, uint8_t* done_out, float* gt,
                                                            mg_info_buffers info, int autoreset) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    path_ws_init(smem);
+    const PathWS W{smem, (int)threadIdx.x};
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     MysteryCore s = io.core[i];
@@ -644,8 +678,8 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
     g.load(io.rng, i);
     bool rng_dirty = false;
     MysteryDesc d;
-    if (P.endless) emp_step(P, io, i, s, g, rng_dirty, actions, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
-    else mp_step(P, io, i, s, g, rng_dirty, actions, reward_out, done_out, info, autoreset, d);
+    if (P.endless) emp_step(P, io, W, i, s, g, rng_dirty, actions, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+    else mp_step(P, io, W, i, s, g, rng_dirty, actions, reward_out, done_out, info, autoreset, d);
     if (rng_dirty) g.store(io.rng, i);
     io.core[i] = s;
     io.desc[i] = d;
@@ -728,7 +762,7 @@ class MysteryFamily : public Family {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;
-        hipLaunchKernelGGL(mystery_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt_dim() ? gt : nullptr);
+        hipLaunchKernelGGL(mystery_reset_kernel, dim3((n_ + 255) / 256), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, gt_dim() ? gt : nullptr);
         raster(obs, s);
     }
 
@@ -739,7 +773,7 @@ class MysteryFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        hipLaunchKernelGGL(mystery_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done,
+        hipLaunchKernelGGL(mystery_step_kernel, dim3((n_ + 255) / 256), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
                            gt_dim() ? gt : nullptr, ib, autoreset);
         prof.end(0, s);
         prof.begin(1, s);
