@@ -147,6 +147,7 @@ int main(int argc, char** argv) {
     int radius;
     auto sprites = build_agent_sprites(0.25, &radius);
     auto glyphs = build_glyphs(0.25);
+    auto templ = build_mortar_templates(5, 0.25, 84);
     std::mt19937 rng(1);
     std::vector<OldDesc> descs(n);
     for (int i = 0; i < n; ++i) {
