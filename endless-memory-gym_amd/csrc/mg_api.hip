@@ -57,6 +57,7 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
         else if (id == "SearingSpotlights-v0") fam = mg::make_spot(0, num_envs);
         else if (id == "MysteryPath-v0") fam = mg::make_mystery(0, num_envs);
         else if (id == "Endless-MysteryPath-v0") fam = mg::make_mystery(1, num_envs);
+        else if (id == "MysteryPath-Grid-v0") fam = mg::make_mystery(2, num_envs);
         else {
             mg::set_error("mg_create: environment id not available in this build: " + id);
             return -5;

@@ -105,7 +105,7 @@ class Family {
 
 Family* make_mortar(int variant, int num_envs);
 Family* make_spot(int endless, int num_envs);
-Family* make_mystery(int endless, int num_envs);
+Family* make_mystery(int variant, int num_envs);
 
 inline int to_int_checked(double v, const char* key) {
     int i = (int)v;

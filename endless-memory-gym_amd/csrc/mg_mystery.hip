@@ -1,7 +1,8 @@
-// mg_mystery.hip -- Mystery Path family on gfx950: MysteryPath-v0 and Endless-MysteryPath-v0.
+// mg_mystery.hip -- Mystery Path family on gfx950: MysteryPath-v0, MysteryPath-Grid-v0 and Endless-MysteryPath-v0.
 //
 // Reference behaviour reproduced (bit-exact observations, rewards, dones, RNG consumption):
 //   memory_gym/mystery_path.py          reset :130-200  step :202-276
+//   memory_gym/mystery_path_grid.py     reset :129-199  step :201-277 (GridCharacterController, Discrete(4))
 //   memory_gym/endless_mystery_path.py  reset :195-280  step :282-444  drawing :111-160
 //   memory_gym/pygame_assets.py         Node :438-493  EndlessMysteryPath :495-604  MysteryPath (noisy A*) :606-736
 //   memory_gym/character_controller.py  CharacterController.step :89-146
@@ -29,7 +30,7 @@ constexpr int MAX_FALL = 128;
 constexpr int ST_CROSS = 8;
 
 struct MysteryParams {
-    int endless, n;
+    int endless, grid, n;
     int max_steps, show_origin, show_goal, visual_feedback, show_past_path, show_stamina, stamina_level, depth;
     int agent_radius, sprite_dim, v_axis_i, v_diag_i, tile, cross_dim;
     int camera_offset;  // integral at the supported camera_offset_scale values
@@ -49,7 +50,7 @@ struct __attribute__((aligned(16))) MysteryCore {
     double ep_sum;
     uint8_t td[3], have_start;
     int8_t end_y;
-    uint8_t pad[3];
+    uint8_t gx, gy, pad;  // grid controller position (MysteryPath-Grid-v0)
 };
 static_assert(sizeof(MysteryCore) == 96, "MysteryCore must be 96 bytes");
 
@@ -305,8 +306,11 @@ __device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, const Path
     s.visited_mask = 0;
     s.path_len = (uint8_t)len;
     s.sx = (uint8_t)sx; s.sy = (uint8_t)sy; s.ex = (uint8_t)ex; s.ey = (uint8_t)ey;
-    s.ax = (int16_t)(sx * P.tile + P.agent_radius);
-    s.ay = (int16_t)(sy * P.tile + P.agent_radius);
+    // free controller: start tile corner + radius; grid controller: cell centre 12*i + 6 -- the same pixel at SCALE 0.25
+    s.ax = (int16_t)(P.grid ? sx * P.tile + P.tile / 2 : sx * P.tile + P.agent_radius);
+    s.ay = (int16_t)(P.grid ? sy * P.tile + P.tile / 2 : sy * P.tile + P.agent_radius);
+    s.gx = (uint8_t)sx;
+    s.gy = (uint8_t)sy;
     s.rot8 = 0;
     s.off = 0;
     s.fails = 0;
@@ -326,7 +330,25 @@ __device__ void mp_step(const MysteryParams& P, const MysteryIO& io, const PathW
     double reward = 0.0;
     bool done = false;
     int success = 0;
-    if (!s.off) {
+    if (P.grid) {  // GridCharacterController.step / reset_position (character_controller.py:177-216)
+        int a = s.off ? 0 : actions[i];
+        int gx = s.off ? s.sx : s.gx, gy = s.off ? s.sy : s.gy;
+        int rot = s.rot8 * 45;
+        if (a == 1) rot = (rot + 90) % 360;
+        if (a == 2) rot = (rot + 270) % 360;
+        if (a == 3) {
+            int face = rot / 90;  // 0 N, 1 W, 2 S, 3 E
+            if (face == 0) { if (gy > 0) gy--; }
+            else if (face == 3) { if (gx < G - 1) gx++; }
+            else if (face == 2) { if (gy < G - 1) gy++; }
+            else { if (gx > 0) gx--; }
+        }
+        s.rot8 = (uint8_t)(rot / 45);
+        s.gx = (uint8_t)gx;
+        s.gy = (uint8_t)gy;
+        s.ax = (int16_t)(gx * P.tile + P.tile / 2);
+        s.ay = (int16_t)(gy * P.tile + P.tile / 2);
+    } else if (!s.off) {
         move_agent(P, s, actions[2 * i], actions[2 * i + 1], true);
     } else {
         s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
@@ -690,9 +712,11 @@ static const double SCALE = 0.25;
 
 class MysteryFamily : public Family {
    public:
-    MysteryFamily(int endless, int n) : n_(n) {
+    MysteryFamily(int variant, int n) : n_(n) {  // 0 MysteryPath-v0, 1 Endless-MysteryPath-v0, 2 MysteryPath-Grid-v0
+        const int endless = variant == 1;
         memset(&P_, 0, sizeof(P_));
         P_.endless = endless;
+        P_.grid = variant == 2;
         P_.n = n;
         agent_scale_ = 1.0 * SCALE;
         agent_speed_ = 12.0 * SCALE;
@@ -701,7 +725,8 @@ class MysteryFamily : public Family {
         if (endless) {
             P_.max_steps = -1; P_.show_past_path = 1; camera_offset_scale_ = 5.0; P_.stamina_level = 20;
         } else {
-            P_.max_steps = 512;
+            P_.max_steps = P_.grid ? 128 : 512;
+            if (P_.grid) P_.r_progress = 0.0;
             P_.cardinal.n = 4;
             for (int k = 0; k < 4; ++k) P_.cardinal.v[k] = k;
             P_.r_goal = 1.0;
@@ -722,7 +747,7 @@ class MysteryFamily : public Family {
         rebuild();
     }
 
-    int action_dim() const override { return P_.endless ? 1 : 2; }
+    int action_dim() const override { return (P_.endless || P_.grid) ? 1 : 2; }
     int gt_dim() const override { return P_.endless ? 3 : 0; }
     const char* info_name(int k) const override {
         if (P_.endless) return k == 0 ? "num_fails" : (k == 1 ? "max_x" : (k == 2 ? "tiles_visited" : nullptr));
@@ -736,7 +761,7 @@ class MysteryFamily : public Family {
         auto must_be = [&](bool ok) { if (!ok) throw OptionError{-3, "reset parameter " + key + ": this value is not supported by the MI355X build"}; };
         if (key == "max_steps") I(P_.max_steps);
         else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
-        else if (key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
+        else if (!P_.grid && key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
         else if (key == "show_origin") { B(P_.show_origin); if (e) P_.show_origin = 0; /* dead branch in the reference (:150) */ }
         else if (key == "visual_feedback") B(P_.visual_feedback);
         else if (key == "reward_fall_off") P_.r_fall = v[0];
@@ -842,6 +867,6 @@ class MysteryFamily : public Family {
     RngStore rng_;
 };
 
-Family* make_mystery(int endless, int num_envs) { return new MysteryFamily(endless, num_envs); }
+Family* make_mystery(int variant, int num_envs) { return new MysteryFamily(variant, num_envs); }
 
 }  // namespace mg

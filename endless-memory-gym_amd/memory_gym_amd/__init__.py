@@ -12,7 +12,7 @@ single-instance adapter), mirroring the reference's registration side effect on 
 from .reset_params import DEFAULTS, process_reset_params  # noqa: F401
 from .vec_env import ENV_IDS, MemoryGymEnv, VecMemoryGym  # noqa: F401
 
-NOT_IN_SCOPE = ["MysteryPath-Grid-v0", "MortarMayhemB-v0", "MortarMayhemB-Grid-v0"]
+NOT_IN_SCOPE = ["MortarMayhemB-v0", "MortarMayhemB-Grid-v0"]
 
 
 def make(env_id, num_envs=None, device=None, render_mode=None):

@@ -4,6 +4,7 @@
   MortarMayhem-v0               memory_gym/mortar_mayhem.py:21-54
   Endless-MortarMayhem-v0       memory_gym/endless_mortar_mayhem.py:21-53
   MysteryPath-v0                memory_gym/mystery_path.py:21-50
+  MysteryPath-Grid-v0           memory_gym/mystery_path_grid.py:21-49
   Endless-MysteryPath-v0        memory_gym/endless_mystery_path.py:22-54
   SearingSpotlights-v0          memory_gym/searing_spotlights.py:22-81
   Endless-SearingSpotlights-v0  memory_gym/endless_searing_spotlights.py:21-73
@@ -36,6 +37,11 @@ DEFAULTS = {
         "max_steps": 512, "agent_scale": 1.0 * SCALE, "agent_speed": 12.0 * SCALE,
         "cardinal_origin_choice": [0, 1, 2, 3], "show_origin": False, "show_goal": False, "visual_feedback": True,
         "reward_goal": 1.0, "reward_fall_off": 0.0, "reward_path_progress": 0.1, "reward_step": 0.0,
+    },
+    "MysteryPath-Grid-v0": {
+        "max_steps": 128, "agent_scale": 1.0 * SCALE, "cardinal_origin_choice": [0, 1, 2, 3], "show_origin": False,
+        "show_goal": False, "visual_feedback": True, "reward_goal": 1.0, "reward_fall_off": 0.0,
+        "reward_path_progress": 0.0, "reward_step": 0.0,
     },
     "Endless-MysteryPath-v0": {
         "max_steps": -1, "agent_scale": 1.0 * SCALE, "agent_speed": 12.0 * SCALE, "show_origin": False,

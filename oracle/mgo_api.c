@@ -22,6 +22,7 @@ mgo_env* mgo_create(const char* env_id, double scale) {
     else if (!strcmp(env_id, "Endless-MortarMayhem-v0")) rc = mgo_mortar_create(e, 2);
     else if (!strcmp(env_id, "MysteryPath-v0")) rc = mgo_mystery_create(e, 0);
     else if (!strcmp(env_id, "Endless-MysteryPath-v0")) rc = mgo_mystery_create(e, 1);
+    else if (!strcmp(env_id, "MysteryPath-Grid-v0")) rc = mgo_mystery_create(e, 2);
     else if (!strcmp(env_id, "SearingSpotlights-v0")) rc = mgo_spot_create(e, 0);
     else if (!strcmp(env_id, "Endless-SearingSpotlights-v0")) rc = mgo_spot_create(e, 1);
     if (rc != 0) {

@@ -2,6 +2,7 @@
  *
  * Restatement of the Mystery Path family:
  *   MysteryPath-v0          memory_gym/mystery_path.py          reset :130-200  step :202-276
+ *   MysteryPath-Grid-v0     memory_gym/mystery_path_grid.py     reset :129-199  step :201-277 (grid locomotion)
  *   Endless-MysteryPath-v0  memory_gym/endless_mystery_path.py  reset :195-280  step :282-444  drawing :111-160
  * plus Node :438-493, EndlessMysteryPath :495-604, MysteryPath (noisy A*) :606-736 and the icy-tile helpers
  * :780-817 of memory_gym/pygame_assets.py.
@@ -18,7 +19,7 @@ typedef struct {
 } pnode;
 
 typedef struct {
-    int endless;
+    int endless, grid;
     /* reset parameters */
     int max_steps, show_origin, show_goal, visual_feedback, show_past_path, show_background, show_stamina, stamina_level;
     double agent_scale, agent_speed, camera_offset_scale;
@@ -237,9 +238,19 @@ static void mpf_reset(mgo_env* e) {
     mgo_surf_free(m->cross);
     m->cross = mp_make_cross(S);
     m->cross_rect = (mgo_rect){0, 0, m->cross->w, m->cross->h};
-    mgo_agent_init(&m->agent, m->agent_speed, m->agent_scale, 0);
+    if (m->grid) { /* GridCharacterController(SCALE, start, mystery_path.to_grid(tile_dim), 0) (mystery_path_grid.py:184-189) */
+        mgo_agent_init(&m->agent, 0, S, 0);
+        m->agent.grid_n = G;
+        m->agent.grid_x0 = m->agent.grid_y0 = floor(m->tile_dim / 2);
+        m->agent.grid_step = m->tile_dim;
+        m->agent.gx = m->sx;
+        m->agent.gy = m->sy;
+        mgo_rect_set_center(&m->agent.rect, m->agent.grid_x0 + m->tile_dim * m->sx, m->agent.grid_y0 + m->tile_dim * m->sy);
+    } else {
+        mgo_agent_init(&m->agent, m->agent_speed, m->agent_scale, 0);
+        mgo_rect_set_center(&m->agent.rect, m->sx * m->tile_dim + m->agent.radius, m->sy * m->tile_dim + m->agent.radius);
+    }
     m->disp_sprite = 0;
-    mgo_rect_set_center(&m->agent.rect, m->sx * m->tile_dim + m->agent.radius, m->sy * m->tile_dim + m->agent.radius);
     m->norm_x = (int)floor(mgo_rect_cx(&m->agent.rect) / m->tile_dim);
     m->norm_y = (int)floor(mgo_rect_cy(&m->agent.rect) / m->tile_dim);
     m->off = 0;
@@ -255,7 +266,16 @@ static void mpf_step(mgo_env* e, const int action[2]) {
     double reward = 0;
     int done = 0, success = 0;
     mgo_rect screen = {0, 0, e->screen_dim, e->screen_dim};
-    if (!m->off) {
+    if (m->grid) {
+        if (!m->off) {
+            mgo_agent_step_grid(&m->agent, action[0]);
+        } else { /* agent.reset_position(start); agent.step(0) (mystery_path_grid.py:218-221) */
+            m->agent.gx = m->sx;
+            m->agent.gy = m->sy;
+            mgo_rect_set_center(&m->agent.rect, m->agent.grid_x0 + m->tile_dim * m->sx, m->agent.grid_y0 + m->tile_dim * m->sy);
+            mgo_agent_step_grid(&m->agent, 0);
+        }
+    } else if (!m->off) {
         mgo_agent_step(&m->agent, action, &screen);
     } else {
         static const int noop[2] = {0, 0};
@@ -545,7 +565,8 @@ static int mp_set_option(mgo_env* e, const char* k, const double* v, int n) {
     mp_t* m = (mp_t*)e->impl;
 #define D(name, field) if (!strcmp(k, name)) { m->field = v[0]; return 0; }
 #define I(name, field) if (!strcmp(k, name)) { m->field = (int)v[0]; return 0; }
-    I("max_steps", max_steps) D("agent_scale", agent_scale) D("agent_speed", agent_speed)
+    I("max_steps", max_steps) D("agent_scale", agent_scale)
+    if (!m->grid) { D("agent_speed", agent_speed) }
     I("show_origin", show_origin) I("visual_feedback", visual_feedback)
     D("reward_fall_off", reward_fall_off) D("reward_path_progress", reward_path_progress) D("reward_step", reward_step)
     if (m->endless) {
@@ -617,16 +638,18 @@ static void mp_destroy(mgo_env* e) {
     free(m);
 }
 
-static const mgo_vtbl MP_VT[2] = {
+static const mgo_vtbl MP_VT[3] = {
     {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy},
     {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy},
+    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy},
 };
 
 int mgo_mystery_create(mgo_env* e, int variant) {
     mp_t* m = (mp_t*)calloc(1, sizeof(mp_t));
     double S = e->scale;
     int dim = e->screen_dim;
-    m->endless = variant;
+    m->endless = variant == 1;
+    m->grid = variant == 2;
     e->vt = &MP_VT[variant];
     e->impl = m;
     m->agent_scale = 1.0 * S;
@@ -636,8 +659,9 @@ int mgo_mystery_create(mgo_env* e, int variant) {
     m->reward_fall_off = 0.0;
     m->reward_path_progress = 0.1;
     m->reward_step = 0.0;
-    if (!variant) {
-        m->max_steps = 512;
+    if (variant != 1) {
+        m->max_steps = m->grid ? 128 : 512;
+        if (m->grid) m->reward_path_progress = 0.0;
         for (int i = 0; i < 4; i++) m->cardinal[i] = i;
         m->n_cardinal = 4;
         m->show_goal = 0;

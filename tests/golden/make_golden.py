@@ -250,6 +250,26 @@ def pol_mp(env, prng, skill):
     return np.array([_toward(dx), _toward(dy)])
 
 
+def pol_mp_grid(env, prng, skill):
+    if prng.random() > skill:
+        return int(prng.integers(0, 4))
+    path = env.mystery_path.path  # end-first
+    pos = env.normalized_agent_position
+    idx = None
+    for i, n in enumerate(path):
+        if (n.x, n.y) == pos:
+            idx = i
+            break
+    if idx is None or idx == 0:
+        return 0
+    nxt = path[idx - 1]
+    dx, dy = nxt.x - pos[0], nxt.y - pos[1]
+    want = 270 if dx > 0 else (90 if dx < 0 else (0 if dy < 0 else 180))
+    if env.agent.rotation == want:
+        return 3
+    return 1 if (want - env.agent.rotation) % 360 in (90, 180) else 2
+
+
 def pol_emp(env, prng, skill):
     if prng.random() > skill:
         return int(prng.integers(0, 4))
@@ -287,6 +307,7 @@ ENVS = {
     "MortarMayhem-v0": dict(snap=snap_mm, pol=pol_mm_free, disc=False),
     "Endless-MortarMayhem-v0": dict(snap=snap_mm, pol=lambda e, p, s: pol_mm_free(e, p, s, True), disc=False),
     "MysteryPath-v0": dict(snap=snap_mp, pol=pol_mp, disc=False),
+    "MysteryPath-Grid-v0": dict(snap=snap_mp, pol=pol_mp_grid, disc=True),
     "Endless-MysteryPath-v0": dict(snap=snap_emp, pol=pol_emp, disc=True),
     "SearingSpotlights-v0": dict(snap=snap_ss, pol=pol_ss, disc=False),
     "Endless-SearingSpotlights-v0": dict(snap=snap_ss, pol=pol_ss, disc=False),
@@ -321,6 +342,12 @@ SESSIONS = {
         (4, dict(max_steps=64, cardinal_origin_choice=[2], show_origin=True, show_goal=True,
                  reward_fall_off=-0.1, reward_step=-0.01, reward_goal=2.0), 0.9, 300),
         (5, dict(cardinal_origin_choice=[1, 3], visual_feedback=False), 0.95, 400),
+    ],
+    "MysteryPath-Grid-v0": [
+        (0, None, 0.0, 300), (1, None, 1.0, 300), (2, None, 0.9, 600),
+        (3, dict(max_steps=40, cardinal_origin_choice=[0, 3], show_origin=True, show_goal=True, reward_fall_off=-0.1,
+                 reward_step=-0.01, reward_goal=2.0, reward_path_progress=0.1), 0.92, 400),
+        (4, dict(visual_feedback=False), 0.8, 300),
     ],
     "Endless-MysteryPath-v0": [
         (0, None, 0.0, 200), (1, None, 1.0, 800), (2, None, 0.97, 1200), (3, None, 0.9, 600),

@@ -47,6 +47,28 @@ def endless_follower(e, prng):
     return [0, 0]
 
 
+def grid_follower(e, prng):
+    """MysteryPath-Grid-v0: rotate towards / step onto the next path tile, with occasional mistakes."""
+    if prng.random() > 0.93:
+        return [int(prng.integers(0, 4)), 0]
+    path = e.get_list("path").reshape(-1, 2)
+    pos = (e.get("nx"), e.get("ny"))
+    idx = next((k for k, (x, y) in enumerate(path) if (x, y) == pos), None)
+    if idx is None or idx == 0:
+        return [0, 0]
+    dx, dy = path[idx - 1][0] - pos[0], path[idx - 1][1] - pos[1]
+    want = 270 if dx > 0 else (90 if dx < 0 else (0 if dy < 0 else 180))
+    rot = e.get("arot")
+    if rot == want:
+        return [3, 0]
+    return [1 if (want - rot) % 360 in (90, 180) else 2, 0]
+
+
+GRID_OPTS = [
+    None,
+    dict(max_steps=40, cardinal_origin_choice=[0, 3], show_origin=True, show_goal=True, reward_fall_off=-0.1, reward_step=-0.01,
+         reward_goal=2.0, reward_path_progress=0.1),
+]
 MP_OPTS = [
     None,
     dict(max_steps=64, cardinal_origin_choice=[2], show_origin=True, show_goal=True, reward_fall_off=-0.1, reward_step=-0.01,
@@ -67,6 +89,12 @@ def test_finite_parity(opt_idx):
     assert n_done > 0
 
 
+@pytest.mark.parametrize("opt_idx", range(len(GRID_OPTS)))
+def test_grid_parity(opt_idx):
+    n_done = run_parity("MysteryPath-Grid-v0", GRID_OPTS[opt_idx], n=160, steps=300, policy=grid_follower, n_policy=64)
+    assert n_done > 0
+
+
 @pytest.mark.parametrize("opt_idx", range(len(EMP_OPTS)))
 def test_endless_parity(opt_idx):
     n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=400, policy=endless_follower, n_policy=64)
@@ -76,6 +104,7 @@ def test_endless_parity(opt_idx):
 def test_terminal_info():
     assert check_terminal_info("MysteryPath-v0", steps=520) > 0
     assert check_terminal_info("Endless-MysteryPath-v0", steps=200) > 0
+    assert check_terminal_info("MysteryPath-Grid-v0", steps=140) > 0
 
 
 def test_full_size_sample():
