@@ -151,6 +151,14 @@ int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches) {
     });
 }
 
+int mg_poll_errors(mg_env* env, int* flags) {
+    return guarded(env, [&] {
+        if (!flags) throw std::runtime_error("mg_poll_errors: NULL");
+        MG_HIP(hipDeviceSynchronize());
+        *flags = env->fam->poll_errors();
+    });
+}
+
 int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
     return guarded(env, [&] {
         if (i < 0 || i >= env->num_envs) throw std::runtime_error("mg_debug_rng: index out of range");

@@ -101,6 +101,8 @@ class Family {
     // checkpoint: list of (device pointer, bytes) making up the state
     virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;
     virtual void debug_rng(int i, uint64_t out[6]) = 0;
+    // device-side error bits accumulated since the last call (0 = none); synchronises
+    virtual int poll_errors() { return 0; }
 };
 
 Family* make_mortar(int variant, int num_envs);

@@ -826,6 +826,12 @@ class SpotFamily : public Family {
         return v;
     }
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+    int poll_errors() override {
+        int v = 0;
+        MG_HIP(hipMemcpy(&v, err_.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (v) MG_HIP(hipMemset(err_.p, 0, sizeof(int)));
+        return v;
+    }
 
    private:
     SpotIO io() {

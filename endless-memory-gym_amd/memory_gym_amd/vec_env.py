@@ -185,6 +185,13 @@ class VecMemoryGym:
         _native.check(_native.LIB.mg_get_profile(self._h, kind, C.byref(ms), C.byref(n)), "mg_get_profile")
         return ms.value, n.value
 
+    def check_errors(self):
+        """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device)."""
+        f = C.c_int()
+        _native.check(_native.LIB.mg_poll_errors(self._h, C.byref(f)), "mg_poll_errors")
+        if f.value:
+            raise RuntimeError("memory_gym_amd: device error flags 0x%x (see include/memgym.h: mg_poll_errors)" % f.value)
+
     def rng_words(self, i):
         w = np.zeros(6, np.uint64)
         _native.check(_native.LIB.mg_debug_rng(self._h, int(i), w.ctypes.data), "mg_debug_rng")

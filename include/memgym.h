@@ -94,6 +94,13 @@ int mg_set_state(mg_env* env, const void* host_buf, size_t size);
 int mg_set_profiling(mg_env* env, int on);
 int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
 
+/* Device-side error bits raised by the kernels since the last call (the reference's only failure paths are Python
+ * exceptions, e.g. pygame_assets.py:723-724 "No valid path found"); 0 = none.  Synchronous.
+ *   1  spotlight slots exhausted (more than 16 live spotlights)      2  path generation found no valid path
+ *   4  endless path longer than 128 segments                         8  more than 128 distinct fall-off cells
+ *  16  past-path window wider than 16 columns */
+int mg_poll_errors(mg_env* env, int* flags);
+
 /* Test hook: copy the numpy-compatible PCG64 words of instance i to host:
  * out[6] = {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}.  Synchronous. */
 int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out);
