@@ -141,7 +141,10 @@ int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
 }
 
 int mg_set_profiling(mg_env* env, int on) {
-    return guarded(env, [&] { env->fam->prof.on = on != 0; });
+    return guarded(env, [&] {
+        env->fam->prof.stride = on < 0 ? 0 : on;
+        env->fam->prof.count[0] = env->fam->prof.count[1] = 0;
+    });
 }
 
 int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches) {

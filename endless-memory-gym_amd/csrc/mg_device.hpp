@@ -127,6 +127,33 @@ struct Pcg {
     __device__ __forceinline__ double uniform(double a, double b) { return a + (b - a) * next_double(); }
 };
 
+// CharacterController.step (character_controller.py:89-146): 8-way move with `int()`-truncated velocity
+// (v_axis = int(speed), v_diag = int(speed / sqrt(2))), rotation from the velocity signs, optional clamp of the
+// centre to [lo_x, hi_x] x [lo_y, hi_y].  rot8 = rotation / 45.
+__device__ __forceinline__ void free_move(int a0, int a1, int v_axis, int v_diag, int& ax, int& ay, uint8_t& rot8, bool clamp,
+                                          int lo_x, int hi_x, int lo_y, int hi_y) {
+    int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
+    int rot = rot8 * 45;
+    if (a0 == 1) rot = 90;
+    if (a0 == 2) rot = 270;
+    if (a1 == 1) rot = 0;
+    if (a1 == 2) rot = 180;
+    if (dxs < 0 && dys < 0) rot = 45;
+    if (dxs < 0 && dys > 0) rot = 135;
+    if (dxs > 0 && dys < 0) rot = 315;
+    if (dxs > 0 && dys > 0) rot = 225;
+    rot8 = (uint8_t)(rot / 45);
+    int v = (dxs != 0 && dys != 0) ? v_diag : v_axis;
+    ax += dxs * v;
+    ay += dys * v;
+    if (clamp) {
+        ax = ax > hi_x ? hi_x : ax;
+        ax = ax < lo_x ? lo_x : ax;
+        ay = ay > hi_y ? hi_y : ay;
+        ay = ay < lo_y ? lo_y : ay;
+    }
+}
+
 // "sample one per episode" option list (np_random.choice(list) == list[integers(0, len)])
 struct OptList {
     int n;

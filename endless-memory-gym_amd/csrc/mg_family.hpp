@@ -56,10 +56,13 @@ struct OptionError {
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
 struct KernelProfile {
-    bool on = false;
+    int stride = 0;          // 0 = off; N = bracket every N-th step (events cost ~7 us per bracketed launch)
+    uint64_t count[2] = {0, 0};
+    bool live[2] = {false, false};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // 0 = logic kernel, 1 = raster kernel
     void begin(int kind, hipStream_t s) {
-        if (!on) return;
+        live[kind] = stride > 0 && (count[kind]++ % (uint64_t)stride) == 0;
+        if (!live[kind]) return;
         hipEvent_t a, b;
         MG_HIP(hipEventCreate(&a));
         MG_HIP(hipEventCreate(&b));
@@ -67,7 +70,7 @@ struct KernelProfile {
         ev[kind].push_back({a, b});
     }
     void end(int kind, hipStream_t s) {
-        if (!on) return;
+        if (!live[kind]) return;
         MG_HIP(hipEventRecord(ev[kind].back().second, s));
     }
     // sum of elapsed ms and launch count for `kind`; synchronises and clears

@@ -28,6 +28,8 @@ constexpr int SEG_NODES = 50;
 constexpr int MAX_SEG = 128;
 constexpr int MAX_FALL = 128;
 constexpr int ST_CROSS = 8;
+constexpr int TILE = SCREEN / G;   // 12 px
+constexpr int STAMINA_W = 4;      // int(16 * SCALE)
 
 struct MysteryParams {
     int endless, grid, n;
@@ -75,25 +77,25 @@ struct MysteryComposer {
         if (d.cross_on) cross = stamp_fetch<1>(R, ST_CROSS);
         fill_clear(R);
         __syncthreads();
-        if (d.goal_on) rect(R, d.goal_x * 12, d.goal_y * 12, 12, 12, C_GREEN, false);
-        if (d.origin_on) rect(R, d.origin_x * 12, d.origin_y * 12, 12, 12, C_BLUE, false);
+        if (d.goal_on) rect(R, d.goal_x * TILE, d.goal_y * TILE, TILE, TILE, C_GREEN, false);
+        if (d.origin_on) rect(R, d.origin_x * TILE, d.origin_y * TILE, TILE, TILE, C_BLUE, false);
         for (int h = 0; h < 2; ++h) {  // distinct path cells: no overlap between them, no barrier needed
             uint64_t m = d.tile_mask[h];
             while (m) {
                 int b = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
                 int cell = h * 64 + b, col = cell / G, row = cell - col * G;
-                rect(R, d.tile_x0 + 12 * col, 12 * row, 12, 12, C_WHITE, true);
+                rect(R, d.tile_x0 + TILE * col, TILE * row, TILE, TILE, C_WHITE, true);
             }
         }
         __syncthreads();
         stamp_apply<4>(R, sprite, d.sx, d.sy);
         if (d.stamina_on) {
             __syncthreads();
-            rect(R, SCREEN - 4, 0, 4, SCREEN, C_GREEN, false);
+            rect(R, SCREEN - STAMINA_W, 0, STAMINA_W, SCREEN, C_GREEN, false);
             if (d.stamina_red) {
                 __syncthreads();
-                rect(R, SCREEN - 4, 0, 4, d.stamina_red, C_RED, false);
+                rect(R, SCREEN - STAMINA_W, 0, STAMINA_W, d.stamina_red, C_RED, false);
             }
         }
         if (d.cross_on) {
@@ -258,28 +260,11 @@ __device__ __forceinline__ int floordiv_pos(int a, int b) {
     return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-// CharacterController.step with an optional clamp box
+// CharacterController.step with an optional clamp to the screen
 __device__ __forceinline__ void move_agent(const MysteryParams& P, MysteryCore& s, int a0, int a1, bool clamp) {
-    int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
-    int rot = s.rot8 * 45;
-    if (a0 == 1) rot = 90;
-    if (a0 == 2) rot = 270;
-    if (a1 == 1) rot = 0;
-    if (a1 == 2) rot = 180;
-    if (dxs < 0 && dys < 0) rot = 45;
-    if (dxs < 0 && dys > 0) rot = 135;
-    if (dxs > 0 && dys < 0) rot = 315;
-    if (dxs > 0 && dys > 0) rot = 225;
-    s.rot8 = (uint8_t)(rot / 45);
-    int v = (dxs != 0 && dys != 0) ? P.v_diag_i : P.v_axis_i;
-    int ax = s.ax + dxs * v, ay = s.ay + dys * v;
-    if (clamp) {
-        int lo = P.agent_radius, hi = SCREEN - P.agent_radius;
-        ax = ax > hi ? hi : ax;
-        ax = ax < lo ? lo : ax;
-        ay = ay > hi ? hi : ay;
-        ay = ay < lo ? lo : ay;
-    }
+    int ax = s.ax, ay = s.ay;
+    free_move(a0, a1, P.v_axis_i, P.v_diag_i, ax, ay, s.rot8, clamp, P.agent_radius, SCREEN - P.agent_radius, P.agent_radius,
+              SCREEN - P.agent_radius);
     s.ax = (int16_t)ax;
     s.ay = (int16_t)ay;
 }

@@ -39,7 +39,7 @@ struct SpotParams {
     int agent_radius, sprite_dim, coin_radius;
     int v_axis_i, v_diag_i;
     int spawn_clamp;                // _process_spawn_pos offset
-    int bar_x, bar_w, quarter;
+    int bar_x, bar_w, quarter, bar_h, exit_half;
     double speed_lo, speed_hi, damage, agent_health, exit_radius, half_diag;
     double r_inside, r_outside, r_death, r_coin, r_exit;
     OptList num_coins;
@@ -75,6 +75,7 @@ struct __attribute__((aligned(16))) SpotDesc {
 static_assert(sizeof(SpotDesc) == 160, "SpotDesc must be 160 bytes");
 
 constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
+constexpr int BAR_H = 4;  // top bar height: int(16 * SCALE)
 
 struct SpotComposer {
     typedef SpotDesc Desc;
@@ -121,8 +122,8 @@ struct SpotComposer {
             __syncthreads();
         }
         // top bar: rows y < 4 of every column; priority reward bar > action rects > red > green > base
-        for (int p = R.tid; p < SCREEN * 4; p += 256) {
-            int x = p >> 2, y = p & 3;
+        for (int p = R.tid; p < SCREEN * BAR_H; p += 256) {
+            int x = p / BAR_H, y = p - x * BAR_H;
             uint32_t c = c_base;
             bool has = d.c_base != 0xFF;
             if (x < 2 * d.quarter) { c = x < d.red_w ? c_red : c_green; has = true; }
@@ -370,8 +371,8 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls,
             d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
         }
         d.exit_stamp = ST_EXIT_CLOSED;
-        d.exit_x = (int16_t)(s.exit_x - 5);
-        d.exit_y = (int16_t)(s.exit_y - 5);
+        d.exit_x = (int16_t)(s.exit_x - P.exit_half);
+        d.exit_y = (int16_t)(s.exit_y - P.exit_half);
     }
     fill_topbar(P, s, d, true, 0, 0);
     if (gt) {
@@ -432,28 +433,11 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     g.load(io.rng, i);
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
 
-    // CharacterController.step(action, walkable_rect)
+    // CharacterController.step(action, walkable_rect = (0, 4, 84, 80))
     int a0 = actions[2 * i], a1 = actions[2 * i + 1];
-    int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
-    int rot = s.rot8 * 45;
-    if (a0 == 1) rot = 90;
-    if (a0 == 2) rot = 270;
-    if (a1 == 1) rot = 0;
-    if (a1 == 2) rot = 180;
-    if (dxs < 0 && dys < 0) rot = 45;
-    if (dxs < 0 && dys > 0) rot = 135;
-    if (dxs > 0 && dys < 0) rot = 315;
-    if (dxs > 0 && dys > 0) rot = 225;
-    s.rot8 = (uint8_t)(rot / 45);
-    int v = (dxs != 0 && dys != 0) ? P.v_diag_i : P.v_axis_i;
-    int ax = s.ax + dxs * v, ay = s.ay + dys * v;
-    {   // walkable_rect = (0, 4, 84, 80)
-        int lox = P.agent_radius, hix = SCREEN - P.agent_radius, loy = 4 + P.agent_radius, hiy = SCREEN - P.agent_radius;
-        ax = ax > hix ? hix : ax;
-        ax = ax < lox ? lox : ax;
-        ay = ay > hiy ? hiy : ay;
-        ay = ay < loy ? loy : ay;
-    }
+    int ax = s.ax, ay = s.ay;
+    free_move(a0, a1, P.v_axis_i, P.v_diag_i, ax, ay, s.rot8, true, P.agent_radius, SCREEN - P.agent_radius, P.bar_h + P.agent_radius,
+              SCREEN - P.agent_radius);
     s.ax = (int16_t)ax;
     s.ay = (int16_t)ay;
     // the top bar shows the PREVIOUS action
@@ -660,8 +644,8 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
                 if (leader) coins[q] = coin_pos[q];
             }
             d.exit_stamp = s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED;
-            d.exit_x = (int16_t)(s.exit_x - 5);
-            d.exit_y = (int16_t)(s.exit_y - 5);
+            d.exit_x = (int16_t)(s.exit_x - P.exit_half);
+            d.exit_y = (int16_t)(s.exit_y - P.exit_half);
         }
         SpotCore tb = s;
         tb.last_pos = shown_last_pos;  // the bar shows whether the PREVIOUS reward was positive
@@ -863,6 +847,8 @@ class SpotFamily : public Family {
         P_.coin_radius = (int)(10 * coin_scale_);
         P_.spawn_clamp = (int)(30 * SCALE);
         P_.quarter = (int)(SCREEN / 4);
+        P_.bar_h = (int)(16 * SCALE);
+        P_.exit_half = (int)(20 * exit_scale_) >> 1;
         if (P_.show_last_action) { P_.bar_x = (int)(P_.quarter * 2.75); P_.bar_w = (int)(P_.quarter * 0.5); }
         else { P_.bar_x = P_.quarter * 2; P_.bar_w = P_.quarter * 2; }
         P_.half_diag = std::sqrt(std::pow((double)SCREEN, 2) + std::pow((double)SCREEN, 2)) / 2;

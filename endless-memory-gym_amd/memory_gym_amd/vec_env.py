@@ -176,8 +176,9 @@ class VecMemoryGym:
         buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
         _native.check(_native.LIB.mg_set_state(self._h, buf.ctypes.data, buf.size), "mg_set_state")
 
-    def set_profiling(self, on):
-        _native.check(_native.LIB.mg_set_profiling(self._h, int(bool(on))), "mg_set_profiling")
+    def set_profiling(self, every):
+        """Bracket the kernels of every `every`-th step with HIP events (0/False = off, 1/True = every step)."""
+        _native.check(_native.LIB.mg_set_profiling(self._h, int(every)), "mg_set_profiling")
 
     def get_profile(self, kind):
         """(total_ms, launches) of the logic (kind 0) or raster (kind 1) kernel since the last call."""

@@ -87,10 +87,11 @@ size_t mg_state_size(const mg_env* env);
 int mg_get_state(mg_env* env, void* host_buf, size_t size);
 int mg_set_state(mg_env* env, const void* host_buf, size_t size);
 
-/* Measurement hooks (bench.py's roofline leg): when profiling is on, every mg_step brackets its kernels with
- * hipEvents recorded on the launch stream.  mg_get_profile(kind) synchronises, returns the summed elapsed
- * milliseconds and the number of launches since the last call, and clears.  kind 0 = logic kernel
- * (one lane per instance), kind 1 = raster kernel (the HBM-write-bound one). */
+/* Measurement hooks (bench.py's roofline leg): mg_set_profiling(env, N) makes every N-th mg_step (N = 1: every step,
+ * 0: off) bracket its kernels with hipEvents recorded on the launch stream (a bracketed step costs ~15 us of stream
+ * time, hence the sampling).  mg_get_profile(kind) synchronises, returns the summed elapsed milliseconds and the
+ * number of bracketed launches since the last call, and clears.  kind 0 = logic kernel (one lane per instance),
+ * kind 1 = raster kernel (the HBM-write-bound one). */
 int mg_set_profiling(mg_env* env, int on);
 int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
 
