@@ -1,0 +1,82 @@
+"""Property tests (hypothesis) on the CPU oracle: invariants of the reference's dynamics that hold for any seed and any
+action stream.  They run on CPU and also guard the fixtures against regressions of the oracle."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import oracle_lib
+
+SET = settings(max_examples=25, deadline=None)
+
+
+@SET
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(2, 6))
+def test_mm_grid_agent_stays_in_arena_and_episode_is_bounded(seed, n):
+    e = oracle_lib.OracleEnv("MortarMayhem-Grid-v0")
+    e.reset(seed, options=dict(arena_size=n), want_obs=False)
+    limit = int(e.get("max_episode_steps"))
+    g = np.random.Generator(np.random.PCG64(seed))
+    x0 = 42 - (14 * n) // 2
+    for t in range(limit + 2):
+        _, r, done = e.step([int(g.integers(0, 4)), 0], want_obs=False)
+        assert 0 <= e.get("nx") < n and 0 <= e.get("ny") < n
+        assert e.get("ax") == x0 + 14 * e.get("nx") + 7 and e.get("ay") == x0 + 14 * e.get("ny") + 7
+        assert r in (0.0, 0.1)
+        if done:
+            assert e.get("info_length") == t + 1 <= limit - 1
+            break
+    else:
+        raise AssertionError("episode longer than calc_max_episode_steps")
+    e.close()
+
+
+@SET
+@given(seed=st.integers(0, 2**31 - 1))
+def test_mystery_path_connects_start_to_end_and_avoids_walls(seed):
+    e = oracle_lib.OracleEnv("MysteryPath-v0")
+    e.reset(seed, want_obs=False)
+    path = e.get_list("path").reshape(-1, 2)
+    walls = {tuple(w) for w in e.get_list("walls").reshape(-1, 2)}
+    assert tuple(path[0]) == (e.get("ex"), e.get("ey")) and tuple(path[-1]) == (e.get("sx"), e.get("sy"))
+    for a, b in zip(path[:-1], path[1:]):
+        assert abs(a[0] - b[0]) + abs(a[1] - b[1]) == 1
+    assert not any(tuple(p) in walls for p in path)
+    assert len({tuple(p) for p in path}) == len(path) <= 49
+    e.close()
+
+
+@SET
+@given(seed=st.integers(0, 2**31 - 1))
+def test_spotlight_agent_stays_in_walkable_rect_and_health_is_monotone(seed):
+    e = oracle_lib.OracleEnv("Endless-SearingSpotlights-v0")
+    e.reset(seed, want_obs=False)
+    g = np.random.Generator(np.random.PCG64(seed ^ 5))
+    health = e.get("health")
+    for t in range(200):
+        _, r, done = e.step(g.integers(0, 3, 2), want_obs=False)
+        assert 6 <= e.get("ax") <= 78 and 10 <= e.get("ay") <= 78
+        assert e.get("health") <= health and r in (0.0, 0.25)
+        assert 7 <= e.get("coin_x") <= 77 and 7 <= e.get("coin_y") <= 77
+        health = e.get("health")
+        if done:
+            assert health <= 0 or e.get("coin_t") == 160
+            break
+    e.close()
+
+
+@SET
+@given(seed=st.integers(0, 2**31 - 1))
+def test_observation_is_a_pure_function_of_seed_and_actions(seed):
+    """Two instances fed the same seed and actions render identical frames (no hidden global state in the oracle)."""
+    for env_id in ("Endless-MortarMayhem-v0", "Endless-MysteryPath-v0"):
+        a, b = oracle_lib.OracleEnv(env_id), oracle_lib.OracleEnv(env_id)
+        assert np.array_equal(a.reset(seed), b.reset(seed))
+        g = np.random.Generator(np.random.PCG64(seed))
+        for t in range(40):
+            act = [int(g.integers(0, 3)), int(g.integers(0, 3))] if not a.discrete else [int(g.integers(0, 4)), 0]
+            oa, ra, da = a.step(act)
+            ob, rb, db = b.step(act)
+            assert np.array_equal(oa, ob) and ra == rb and da == db
+            if da:
+                break
+        a.close()
+        b.close()
