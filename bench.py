@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--env", default="MortarMayhem-Grid-v0")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--obs-format", default="u8_xyc", choices=["u8_xyc", "f32_chw", "f16_chw"],
+                    help="raster stream-out format; the BASELINE.json metric is quoted on the default (the reference's uint8 obs)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of obs/reward/done to rank 0 every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -123,7 +125,8 @@ def main():
     env_id = args.env
     n_local = args.envs_per_gpu or DEFAULT_ENVS[env_id]
     n_total = n_local * world
-    env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank)
+    env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank, obs_format=args.obs_format)
+    obs_elem = {"u8_xyc": 1, "f32_chw": 4, "f16_chw": 2}[args.obs_format]
     # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
     from memory_gym_amd.dist import gather_to_rank0, shard_seeds
     seeds = shard_seeds(n_total, rank, world, base_seed=0, device=dev)
@@ -177,9 +180,9 @@ def main():
         out = {
             "metric": "env steps/sec (aggregate)", "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 u8 obs, same-step auto-reset, uniform random "
-                                   "actions generated on device%s" % (env_id, n_local, world,
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format,
+            "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 obs (%s), same-step auto-reset, uniform random "
+                                   "actions generated on device%s" % (env_id, n_local, world, args.obs_format,
                                                                      ", RCCL obs gather to rank 0" if args.gather and world > 1 else ""),
                        "env_id": env_id, "envs_per_gpu": n_local, "envs_total": n_total,
                        "parallelism": "env-sharded x%d, no data-path collective" % world if not args.gather else
@@ -187,14 +190,14 @@ def main():
         }
         if raster_n:
             avg_ms = raster_ms / raster_n
-            rb = RASTER_BYTES["default"] * n_local
+            rb = (FRAME * obs_elem + 16) * n_local
             achieved = rb / (avg_ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
-                    if j.get("env_id") == env_id and j.get("envs_per_gpu") == n_local:
+                    if j.get("env_id") == env_id and j.get("envs_per_gpu") == n_local and obs_elem == 1:
                         traffic = j.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
@@ -202,7 +205,7 @@ def main():
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                                "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": raster_n, "event_stride": max(1, args.event_stride),
                                "logic_kernel_avg_ms": (logic_ms / logic_n) if logic_n else None,
-                               "whole_step_GBps": STEP_BYTES.get(env_id, FRAME) * n_total / (dt_max / K) / 1e9}
+                               "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * n_total / (dt_max / K) / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(env_id)

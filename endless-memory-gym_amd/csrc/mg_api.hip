@@ -94,14 +94,28 @@ int mg_set_option(mg_env* env, const char* key, const double* values, int n) {
     });
 }
 
-int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, uint8_t* obs_dev, float* gt_dev, void* stream) {
+int mg_set_obs_format(mg_env* env, int format) {
+    return guarded(env, [&] {
+        if (format != MG_OBS_U8_XYC && format != MG_OBS_F32_CYX && format != MG_OBS_F16_CYX)
+            throw mg::OptionError{-3, "mg_set_obs_format: unknown format"};
+        env->fam->obs_format = format;
+    });
+}
+
+size_t mg_obs_bytes(const mg_env* env) {
+    if (!env) return 0;
+    const size_t elem = env->fam->obs_format == MG_OBS_F32_CYX ? 4 : (env->fam->obs_format == MG_OBS_F16_CYX ? 2 : 1);
+    return elem * 84 * 84 * 3;
+}
+
+int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, void* obs_dev, float* gt_dev, void* stream) {
     return guarded(env, [&] {
         if (!obs_dev) throw std::runtime_error("mg_reset: obs_dev is NULL");
         env->fam->reset(seeds_dev, mask_dev, obs_dev, gt_dev, (hipStream_t)stream);
     });
 }
 
-int mg_step(mg_env* env, const int32_t* actions_dev, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, float* gt_dev,
+int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* reward_dev, uint8_t* done_dev, float* gt_dev,
             const mg_info_buffers* info, int autoreset, void* stream) {
     return guarded(env, [&] {
         if (!actions_dev || !obs_dev || !reward_dev || !done_dev) throw std::runtime_error("mg_step: NULL buffer");

@@ -93,13 +93,14 @@ struct KernelProfile {
 class Family {
    public:
     KernelProfile prof;
+    int obs_format = MG_OBS_U8_XYC;  // stream-out format of the raster kernel (include/memgym.h)
     virtual ~Family() {}
     virtual int action_dim() const = 0;
     virtual int gt_dim() const = 0;
     virtual const char* info_name(int k) const = 0;
     virtual void set_option(const std::string& key, const double* v, int n) = 0;  // throws OptionError
-    virtual void reset(const int64_t* seeds, const uint8_t* mask, uint8_t* obs, float* gt, hipStream_t s) = 0;
-    virtual void step(const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, float* gt,
+    virtual void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) = 0;
+    virtual void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt,
                       const mg_info_buffers* info, int autoreset, hipStream_t s) = 0;
     // checkpoint: list of (device pointer, bytes) making up the state
     virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;

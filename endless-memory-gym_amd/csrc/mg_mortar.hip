@@ -507,7 +507,7 @@ class MortarFamily : public Family {
         else throw OptionError{-2, "unknown reset parameter " + key};
     }
 
-    void reset(const int64_t* seeds, const uint8_t* mask, uint8_t* obs, float* gt, hipStream_t s) override {
+    void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) override {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;  // with a mask the caller is responsible for having seeded the other instances
@@ -516,7 +516,7 @@ class MortarFamily : public Family {
         raster(obs, s);
     }
 
-    void step(const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,
+    void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,
               int autoreset, hipStream_t s) override {
         if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next step");
         mg_info_buffers ib;
@@ -579,8 +579,8 @@ class MortarFamily : public Family {
         dirty_ = false;
     }
 
-    void raster(uint8_t* obs, hipStream_t s) {
-        launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, n_, s);
+    void raster(void* obs, hipStream_t s) {
+        launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s);
         MG_HIP(hipGetLastError());
     }
 

@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "../../include/memgym.h"
 #include "mg_device.hpp"
 
 namespace mg {
@@ -282,9 +283,57 @@ __device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha)
 //   static __device__ void compose(const Desc*, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
 // The descriptor is read through its (workgroup-uniform) global pointer, so every field access -- also array
 // elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
-template <class Composer>
+// ---- frame stream-out ---------------------------------------------------------------------------------------
+// MG_OBS_U8_XYC: the reference's observation, pygame.surfarray.array3d order [x][y][c] uint8 (21,168 B = 1,323 x 16 B).
+// MG_OBS_F32_CYX / MG_OBS_F16_CYX: what a trainer builds from it before its CNN: value / 255 as
+// float32 / float16 in image order [c][y][x].  The transpose is done LDS-side (byte gathers, stride 252 B), the
+// global stores stay contiguous 16-B vectors.
+template <int FMT>
+__device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
+    if constexpr (FMT == MG_OBS_U8_XYC) {
+        const uint4* lds16 = reinterpret_cast<const uint4*>(frame);
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
+        uint4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
+        uint4 v5 = make_uint4(0, 0, 0, 0);
+        if (tid < TAIL) v5 = lds16[tid + 1280];
+        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
+        if (tid < TAIL) dst[tid + 1280] = v5;
+    } else if constexpr (FMT == MG_OBS_F32_CYX) {
+        float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame
+        for (int q = tid; q < TOTAL; q += 256) {
+            const int row = q / PER_ROW, x0 = (q - row * PER_ROW) * 4;
+            const int c = row / SCREEN, y = row - c * SCREEN;
+            const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+            float4 v;
+            v.x = (float)src[0] / 255.0f;
+            v.y = (float)src[COL_BYTES] / 255.0f;
+            v.z = (float)src[2 * COL_BYTES] / 255.0f;
+            v.w = (float)src[3 * COL_BYTES] / 255.0f;
+            dst[q] = v;
+        }
+    } else {
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<_Float16*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
+        for (int q = tid; q < TOTAL; q += 256) {
+            union { _Float16 h[8]; uint4 v; } u;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int qq = 2 * q + g;
+                const int row = qq / PER_ROW, x0 = (qq - row * PER_ROW) * 4;
+                const int c = row / SCREEN, y = row - c * SCREEN;
+                const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = (_Float16)((float)src[k * COL_BYTES] / 255.0f);
+            }
+            dst[q] = u.v;
+        }
+    }
+}
+
+template <class Composer, int FMT>
 __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
-                                                     uint8_t* __restrict__ obs, int n) {
+                                                     void* __restrict__ obs, int n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     RasterCtx R;
     R.frame = smem;
@@ -292,31 +341,30 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     R.A = A;
     R.T = A.tables;
     R.tid = threadIdx.x;
-    uint4* lds16 = reinterpret_cast<uint4*>(smem);
     const int tid = threadIdx.x;
     for (int env = blockIdx.x; env < n; env += gridDim.x) {
         const typename Composer::Desc* d = descs + env;  // workgroup-uniform
         if (Composer::skip(d)) continue;
         Composer::compose(d, R);
         __syncthreads();
-        uint4* dst = reinterpret_cast<uint4*>(obs + (size_t)env * FRAME_BYTES);
-        uint4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
-        uint4 v5 = make_uint4(0, 0, 0, 0);
-        if (tid < TAIL) v5 = lds16[tid + 1280];
-        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
-        if (tid < TAIL) dst[tid + 1280] = v5;
+        store_frame<FMT>(smem, obs, env, tid);
         __syncthreads();  // the LDS frame is reused by the next iteration
     }
 }
 
 template <class Composer>
-inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, uint8_t* obs, int n, hipStream_t s) {
+inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s) {
     static const int tuned = [] {  // MEMGYM_RASTER_GRID overrides the persistent grid size (tuning experiments)
         const char* e = getenv("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : RASTER_GRID;
     }();
     const int grid = n < tuned ? n : tuned;
-    hipLaunchKernelGGL(raster_kernel<Composer>, dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+    if (fmt == MG_OBS_F32_CYX)
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+    else if (fmt == MG_OBS_F16_CYX)
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+    else
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
 }
 
 }  // namespace mg

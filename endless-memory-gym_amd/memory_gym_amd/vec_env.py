@@ -50,9 +50,14 @@ def _spaces(action_dim, gt_dim):
 class VecMemoryGym:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
 
-    def __init__(self, env_id, num_envs=1, device=None, render_mode=None):
+    OBS_FORMATS = {"u8_xyc": (0, torch.uint8, (84, 84, 3)), "f32_chw": (1, torch.float32, (3, 84, 84)),
+                   "f16_chw": (2, torch.float16, (3, 84, 84))}
+
+    def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc"):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
+        if obs_format not in self.OBS_FORMATS:
+            raise ValueError("obs_format must be one of %s" % sorted(self.OBS_FORMATS))
         if not torch.cuda.is_available():
             raise RuntimeError("memory_gym_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.env_id = env_id
@@ -68,7 +73,13 @@ class VecMemoryGym:
         self.has_ground_truth_info = self.gt_dim > 0
         self.action_space, self.observation_space, self.ground_truth_space = _spaces(self.action_dim, self.gt_dim)
         N, dev = self.num_envs, self.device
-        self.obs = torch.empty((N, 84, 84, 3), dtype=torch.uint8, device=dev)
+        # "u8_xyc" is the reference's observation; "f32_chw"/"f16_chw" are obs/255 in [c][y][x] order, converted inside
+        # the raster kernel's stream-out (what a trainer would otherwise compute from the uint8 frame every step)
+        self.obs_format = obs_format
+        code, dt, shape = self.OBS_FORMATS[obs_format]
+        _native.check(_native.LIB.mg_set_obs_format(h, code), "mg_set_obs_format")
+        assert _native.LIB.mg_obs_bytes(h) == 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
+        self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
         self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
         self.done_u8 = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.gt = torch.zeros((N, max(self.gt_dim, 1)), dtype=torch.float32, device=dev)
@@ -163,6 +174,8 @@ class VecMemoryGym:
 
     def render(self):
         """rgb_array mode of the reference: fliplr(rot90(obs, 3)) == transpose to [y][x][c] (mortar_mayhem_grid.py:401-402)."""
+        if self.obs_format != "u8_xyc":
+            return (self.obs.permute(0, 2, 3, 1).float() * 255.0).round().to(torch.uint8)
         return self.obs.permute(0, 2, 1, 3)
 
     def state_dict(self):

@@ -62,13 +62,27 @@ const char* mg_info_name(const mg_env* env, int k);
  * auto-resets), for every instance of the handle. */
 int mg_set_option(mg_env* env, const char* key, const double* values, int n);
 
+/* Observation format written to obs_dev by mg_reset / mg_step (default MG_OBS_U8_XYC).
+ *   MG_OBS_U8_XYC   uint8   [num_envs][84 x][84 y][3]  -- the reference's observation: pygame.surfarray.array3d order
+ *                                                         (e.g. mortar_mayhem_grid.py:277,372), 21,168 B per instance
+ *   MG_OBS_F32_CYX  float32 [num_envs][3][84 y][84 x]  -- value / 255 in image (CHW) order, the tensor a trainer builds
+ *                                                         from the observation before its CNN; 84,672 B per instance
+ *   MG_OBS_F16_CYX  float16 [num_envs][3][84 y][84 x]  -- the float32 quotient rounded to nearest-even half
+ * The conversion is fused into the raster kernel's stream-out (no second pass over HBM).  mg_obs_bytes returns the
+ * bytes per instance of the current format. */
+#define MG_OBS_U8_XYC 0
+#define MG_OBS_F32_CYX 1
+#define MG_OBS_F16_CYX 2
+int mg_set_obs_format(mg_env* env, int format);
+size_t mg_obs_bytes(const mg_env* env);
+
 /* Env.reset(seed, options) (e.g. mortar_mayhem_grid.py:213-278) for all instances, or for those with
  * mask_dev[i] != 0.  seeds_dev: int64 [num_envs] -> instance i is re-seeded exactly like
  * gymnasium's reset(seed=s): Generator(PCG64(SeedSequence(s))); NULL -> keep each instance's stream
  * (reset(seed=None)).  Writes the first observation of every reset instance to obs_dev (others are
  * left untouched) and, if gt_dev != NULL and mg_gt_dim() > 0, info["ground_truth"] as float32
  * [num_envs][gt_dim]. */
-int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, uint8_t* obs_dev, float* gt_dev,
+int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, void* obs_dev, float* gt_dev,
              void* stream);
 
 /* Env.step(action) (e.g. mortar_mayhem_grid.py:280-375) for all instances.
@@ -78,7 +92,7 @@ int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, uin
  * autoreset != 0: an instance that reports done is reset in the same call with seed=None (its RNG
  * stream continues, exactly what `env.reset()` right after a terminal step does) and obs_dev/gt_dev
  * hold the first observation of the new episode; the finished episode's info is in `info`. */
-int mg_step(mg_env* env, const int32_t* actions_dev, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
+int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* reward_dev, uint8_t* done_dev,
             float* gt_dev, const mg_info_buffers* info, int autoreset, void* stream);
 
 /* Checkpoint hooks (the reference cannot serialise an env; SoA state makes it free).  Synchronous.

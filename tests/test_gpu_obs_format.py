@@ -1,0 +1,62 @@
+"""GPU (-m gpu): the fused float stream-out formats of the raster kernel (include/memgym.h MG_OBS_F32_CYX / F16_CYX).
+
+The uint8 [x][y][c] observation is what the oracle pins bit-exactly (test_gpu_{mortar,spot,mystery}.py); the float
+formats must equal `obs.astype(float32) / 255` transposed to [c][y][x] -- north_star's tolerance for float pixel
+observations is 1e-5, the conversion is in fact exact (correctly rounded float32 division; float16 = that quotient
+rounded to nearest even)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+CASES = [("MortarMayhem-Grid-v0", 4), ("MortarMayhem-v0", 3), ("Endless-MortarMayhem-v0", 3), ("MysteryPath-v0", 3),
+         ("Endless-MysteryPath-v0", 4), ("MysteryPath-Grid-v0", 4), ("SearingSpotlights-v0", 3),
+         ("Endless-SearingSpotlights-v0", 3)]
+
+
+@pytest.mark.parametrize("env_id,n_act", CASES)
+def test_float_formats_match_uint8(env_id, n_act):
+    import memory_gym_amd
+    import torch
+
+    n, steps = 96, 80
+    envs = {f: memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format=f) for f in ("u8_xyc", "f32_chw", "f16_chw")}
+    assert envs["f32_chw"].obs.shape == (n, 3, 84, 84) and envs["f32_chw"].obs.dtype == torch.float32
+    assert envs["f16_chw"].obs.shape == (n, 3, 84, 84) and envs["f16_chw"].obs.dtype == torch.float16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    obs = {f: e.reset(seed=11)[0] for f, e in envs.items()}
+    for t in range(steps + 1):
+        want = obs["u8_xyc"].cpu().numpy().transpose(0, 3, 2, 1).astype(np.float32) / np.float32(255)
+        got32 = obs["f32_chw"].cpu().numpy()
+        assert np.abs(got32 - want).max() <= TOL, "step %d" % t
+        assert np.array_equal(got32, want), "float32 stream-out is expected to be exact (step %d)" % t
+        assert np.array_equal(obs["f16_chw"].cpu().numpy(), want.astype(np.float16)), "step %d" % t
+        if envs["u8_xyc"].action_dim == 1:
+            a = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+        else:
+            a = torch.randint(0, n_act, (n, 2), device="cuda", generator=g, dtype=torch.int32)
+        outs = {f: e.step(a) for f, e in envs.items()}
+        obs = {f: o[0] for f, o in outs.items()}
+        assert torch.equal(outs["u8_xyc"][1], outs["f32_chw"][1]) and torch.equal(outs["u8_xyc"][2], outs["f16_chw"][2])
+    # rgb_array rendering is format independent
+    assert torch.equal(envs["u8_xyc"].render(), envs["f32_chw"].render())
+    for e in envs.values():
+        e.check_errors()
+        e.close()
+
+
+def test_masked_reset_leaves_other_frames():
+    """mg_reset with a mask writes only the reset instances' frames in the float format too."""
+    import memory_gym_amd
+    import torch
+
+    env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=8, device=0, obs_format="f32_chw")
+    env.reset(seed=0)
+    env.obs.fill_(-1.0)
+    mask = torch.tensor([1, 0, 0, 1, 0, 0, 0, 0], dtype=torch.uint8, device="cuda")
+    obs, _ = env.reset(seed=5, mask=mask)
+    o = obs.cpu().numpy()
+    assert (o[[1, 2, 4, 5, 6, 7]] == -1.0).all()
+    assert (o[[0, 3]] >= 0).all() and (o[[0, 3]] <= 1).all()
+    env.close()
