@@ -1,12 +1,13 @@
-// mg_atlas.hpp -- host-side container that uploads stamps / templates / tables for the raster kernel.
+// mg_atlas_v1.hpp (namespace mg::v1, pairs with mg_raster_v1.hpp) -- host-side container that uploads stamps / templates / tables for the raster kernel.
 #pragma once
 #include <vector>
 
 #include "mg_family.hpp"
-#include "mg_raster.hpp"
+#include "mg_raster_v1.hpp"
 #include "mg_stamps.hpp"
 
 namespace mg {
+namespace v1 {
 
 class Atlas {
    public:
@@ -18,51 +19,21 @@ class Atlas {
             {210, 210, 210}, {0, 0, 0},       {48, 141, 70},   {55, 55, 55},  {125, 177, 250}};
         for (int i = 0; i < (int)(sizeof(RGB) / 3); ++i) {
             tables_.palette[i] = (uint32_t)RGB[i][0] | ((uint32_t)RGB[i][1] << 8) | ((uint32_t)RGB[i][2] << 16);
-            tables_.border_of[i] = (uint32_t)i;
+            tables_.border_of[i] = (uint8_t)i;
         }
         tables_.border_of[C_WHITE] = C_GREY210;
         tables_.border_of[C_ICY] = C_GREY210;
     }
 
-    // stamp pixels are palette ids (0 = transparent); stored column-major [x][y] as RGBA words with the column
-    // stride padded to a power of two (pixel index p -> x = p >> sh, y = p & (stride - 1): no division in the kernel)
+    // stamp pixels are palette ids (0 = transparent); stored column-major [x][y]
     int add_stamp(const Stamp& s) {
         int id = n_stamps_++;
         if (id >= MAX_STAMPS) throw std::runtime_error("too many stamps");
-        int sh = 0;
-        while ((1 << sh) < s.h) ++sh;
         tables_.stamps[id].off = (uint32_t)data_.size();
         tables_.stamps[id].w = (uint16_t)s.w;
         tables_.stamps[id].h = (uint16_t)s.h;
-        tables_.stamps[id].sh = (uint16_t)sh;
-        tables_.stamps[id].pad = 0;
         for (int x = 0; x < s.w; ++x)
-            for (int y = 0; y < (1 << sh); ++y) data_.push_back(y < s.h ? rgba(s.get(x, y)) : 0u);
-        return id;
-    }
-    // single-colour stamp of at most 32 x 32 pixels (command glyphs) as one column bit-mask word per column (bit y set
-    // = opaque): a lane of the raster kernel keeps its column in ONE register instead of four RGBA pixels
-    int add_mono_stamp(const Stamp& s) {
-        if (s.w > 32 || s.h > 32) throw std::runtime_error("mono stamp larger than 32x32");
-        int id = n_stamps_++;
-        if (id >= MAX_STAMPS) throw std::runtime_error("too many stamps");
-        uint8_t colour = 0;
-        tables_.stamps[id].off = (uint32_t)data_.size();
-        tables_.stamps[id].w = (uint16_t)s.w;
-        tables_.stamps[id].h = (uint16_t)s.h;
-        tables_.stamps[id].sh = 5;
-        for (int x = 0; x < s.w; ++x) {
-            uint32_t bits = 0;
-            for (int y = 0; y < s.h; ++y) {
-                uint8_t c = s.get(x, y);
-                if (!c) continue;
-                if (colour && c != colour) throw std::runtime_error("mono stamp with more than one colour");
-                colour = c;
-                bits |= 1u << y;
-            }
-            data_.push_back(bits);
-        }
-        tables_.stamps[id].pad = colour;  // palette id of the opaque pixels
+            for (int y = 0; y < s.h; ++y) data_.push_back(rgba(s.get(x, y)));
         return id;
     }
     // palette id -> r | g<<8 | b<<16 | 0xFF<<24 (opaque); id 0 is the colour key -> 0 (transparent)
@@ -141,4 +112,5 @@ struct RngStore {
     }
 };
 
+}  // namespace v1
 }  // namespace mg

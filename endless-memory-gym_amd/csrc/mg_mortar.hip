@@ -15,13 +15,14 @@
 //                   template (selected by tiles-on / target tile) -> agent sprite stamp -> command glyph stamp.
 #include <memory>
 
-#include "mg_atlas.hpp"
+#include "mg_atlas_v1.hpp"
 #include "mg_device.hpp"
 #include "mg_family.hpp"
-#include "mg_raster.hpp"
+#include "mg_raster_v1.hpp"
 #include "mg_stamps.hpp"
 
 namespace mg {
+using namespace v1;  // raster generation 1 (see mg_raster_v1.hpp)
 
 enum { V_GRID = 0, V_FREE = 1, V_ENDLESS = 2 };
 

@@ -14,13 +14,14 @@
 //   raster_kernel<MysteryComposer> : black frame -> goal/origin or past-path tiles -> agent sprite -> fall-off cross.
 #include <memory>
 
-#include "mg_atlas.hpp"
+#include "mg_atlas_v1.hpp"
 #include "mg_device.hpp"
 #include "mg_family.hpp"
-#include "mg_raster.hpp"
+#include "mg_raster_v1.hpp"
 #include "mg_stamps.hpp"
 
 namespace mg {
+using namespace v1;  // raster generation 1 (see mg_raster_v1.hpp)
 
 constexpr int G = 7;             // grid_dim
 constexpr int SEG_STRIDE = 52;   // bytes per stored segment: [0] = length, [1..50] nodes

@@ -1,24 +1,25 @@
-// mg_raster.hpp -- the raster skeleton shared by every environment family (gfx950).
+// mg_raster.hpp -- raster skeleton, generation 2 (gfx950): the layered composer used by the spotlight family.
+// (The template-dominated families -- mortar, mystery -- stay on generation 1, mg_raster_v1.hpp; see the note there
+// and profiles/r01c_raster_generations.md for the side-by-side measurements behind that split.)
 //
-// raster_kernel<Composer>: PERSISTENT workgroups (256 lanes = 4 waves); each walks frames
+// raster_kernel<Composer, Format>: PERSISTENT workgroups (256 lanes = 4 waves); each walks frames
 // env = blockIdx.x, blockIdx.x + gridDim.x, ...  For one frame it
-//   1. reads the family's small per-instance frame descriptor (workgroup-uniform -> scalar loads),
-//   2. composes the 84x84x3 observation in 21,168 B of LDS with the helpers below, in the reference's blit order
-//      (its _draw_surfaces(), e.g. memory_gym/mortar_mayhem_grid.py:92-102,367-370,
-//      endless_searing_spotlights.py:464-479, endless_mystery_path.py:134-160),
-//   3. streams it to HBM as 1,323 x 16-byte stores, lane-contiguous (1 KiB per wave instruction).
-// The stores are fire-and-forget, so the workgroup composes its next frame while they drain; a
-// one-frame-per-workgroup launch keeps the LDS hostage until the stores are acknowledged (measured 322 us vs 264 us
-// per 65,536 frames; an interpreter over a generic display list measured 390-415 us: tools/microbench/raster_bench.hip).
+//   1. reads the family's per-instance frame descriptor and the atlas tables through the CONSTANT address space
+//      (workgroup-uniform -> scalar loads that do not queue behind the observation stores),
+//   2. prefetch(): issues every global read of the frame at once (template, stamp pixels, disc spans) into registers,
+//   3. compose(): builds the 84x84x3 observation in 21,168 B of LDS in the reference's blit order
+//      (endless_searing_spotlights.py:464-479, searing_spotlights.py:524-545) touching LDS only; the spotlight layer
+//      is not a pass of its own: the hole mask is built first and every layer below it is darkened while written,
+//   4. streams the frame to HBM as 1,323 x 16-byte non-temporal stores, lane-contiguous (1 KiB per wave instruction).
 // Roofline: HBM write bandwidth; algorithmic traffic per instance-step = 21,168 B written + sizeof(Desc) read.
 //
 // Helpers (all lanes of the workgroup call them together; callers place __syncthreads() between overlapping layers):
-//   fill_template  copy a pre-rendered full frame (mortar arena variants, chessboards) from the L2-resident atlas
-//   fill_clear     black frame
-//   stamp          colour-keyed blit of a palette-indexed stamp (agent sprites, glyphs, cross, coin, exit), clipped
-//   rect           filled rectangle with optional 1-px inset border (tiles, bars), clipped
-//   darken         the spotlight layer: pixels outside every hole disc blended towards black with SDL's
-//                  surface-alpha rule d - floor(d*alpha/255)
+//   templ_fetch / templ_apply_dark   background template, darkened outside the holes on the way into LDS
+//   stamp_fetch / stamp_apply_lit    colour-keyed RGBA stamp (agent sprites, coin, exit), clipped, darkened per pixel
+//   mono_fetch / mono_apply          single-colour stamps as column bit masks
+//   zero_mask / hole_fetch8 / hole_apply8 / hole_mask   the lit discs as an 84x84 bit mask
+//   darken2 / darken4                SDL's surface-alpha rule d - floor(d*alpha/255), two bytes per multiply
+//   rect, stamp, fill_clear, templ_fetch16 / templ_store16   plain layers
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,6 +29,19 @@
 #include "mg_device.hpp"
 
 namespace mg {
+
+// Pointers to data that no kernel of this library writes while the raster kernel runs (frame descriptors written by
+// the preceding logic kernel, atlas tables uploaded at creation) are viewed through the CONSTANT address space: the
+// compiler then reads workgroup-uniform fields with scalar loads (s_load, counted by lgkmcnt).  As plain global loads
+// they would be vector loads counted by vmcnt together with the observation stores, and every descriptor access
+// would wait for the previous frame's stores to drain.
+#define MG_CONST_AS __attribute__((address_space(4)))
+template <class T>
+using cptr = const T MG_CONST_AS*;
+template <class T>
+__device__ __forceinline__ cptr<T> as_const(const T* p) {
+    return (cptr<T>)p;  // NOLINT: address-space cast
+}
 
 constexpr int DISC_RMAX = 64;
 constexpr int MAX_STAMPS = 48;
@@ -39,13 +53,15 @@ constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
 
 struct StampInfo {
     uint32_t off;  // pixel offset into the stamp data, pixels stored [x][y] (column-major like the frame)
-    uint16_t w, h;
+    // 32-bit bit-fields / arrays only in anything the raster kernel reads with scalar loads (no sub-dword s_load)
+    uint32_t w : 16, h : 16;
+    uint32_t sh : 16, pad : 16;  // column stride = 1 << sh >= h (padding pixels are transparent); mono stamps: colour
 };
 
 struct AtlasTables {
     StampInfo stamps[MAX_STAMPS];
     uint32_t palette[PALETTE_SIZE];   // r | g<<8 | b<<16
-    uint8_t border_of[PALETTE_SIZE];  // palette id of the 1-px border drawn around a bordered rect of this fill colour
+    uint32_t border_of[PALETTE_SIZE];  // palette id of the 1-px border drawn around a bordered rect of this fill colour
 };
 
 // Everything the raster kernel samples (device pointers; small enough to sit in the scalar/L1/L2 caches).
@@ -66,7 +82,7 @@ enum : uint8_t {
 struct RasterCtx {
     uint8_t* frame;         // LDS, [x][y][c]
     uint32_t* mask;         // LDS, [84][MASK_WORDS] hole mask scratch
-    const AtlasTables* T;   // palette / stamp infos (global; indices are workgroup-uniform -> scalar loads)
+    cptr<AtlasTables> T;    // palette / stamp infos (indices are workgroup-uniform -> scalar loads)
     RasterAtlas A;
     int tid;
 };
@@ -78,16 +94,24 @@ __device__ __forceinline__ void put_rgb(uint8_t* frame, int x, int y, uint32_t r
     p[2] = (uint8_t)(rgb >> 16);
 }
 
-// all six 16-byte loads are issued before the first LDS write (one L2 round trip, not six)
-__device__ __forceinline__ void fill_template(const RasterCtx& R, int t) {
-    uint4* lds16 = reinterpret_cast<uint4*>(R.frame);
-    const uint4* src = reinterpret_cast<const uint4*>(R.A.templates + (size_t)t * FRAME_BYTES);
+// template copy split in two: the six 16-byte loads are issued in the composer's prefetch() (one L2 round trip, in
+// flight while the previous frame streams out), the LDS writes happen in compose()
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct
+struct TemplVec {                                             // (HIP's uint4 class members end up in scratch)
+    u32x4 a, b, c, d, e, f;
+};
+__device__ __forceinline__ void templ_fetch16(const RasterCtx& R, int t, TemplVec& V) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(R.A.templates + (size_t)t * FRAME_BYTES);
     const int tid = R.tid;
-    uint4 v0 = src[tid], v1 = src[tid + 256], v2 = src[tid + 512], v3 = src[tid + 768], v4 = src[tid + 1024];
-    uint4 v5 = make_uint4(0, 0, 0, 0);
-    if (tid < TAIL) v5 = src[tid + 1280];
-    lds16[tid] = v0; lds16[tid + 256] = v1; lds16[tid + 512] = v2; lds16[tid + 768] = v3; lds16[tid + 1024] = v4;
-    if (tid < TAIL) lds16[tid + 1280] = v5;
+    V.a = src[tid]; V.b = src[tid + 256]; V.c = src[tid + 512]; V.d = src[tid + 768]; V.e = src[tid + 1024];
+    V.f = (u32x4)(0u);
+    if (tid < TAIL) V.f = src[tid + 1280];
+}
+__device__ __forceinline__ void templ_store16(const RasterCtx& R, const TemplVec& V) {
+    u32x4* lds16 = reinterpret_cast<u32x4*>(R.frame);
+    const int tid = R.tid;
+    lds16[tid] = V.a; lds16[tid + 256] = V.b; lds16[tid + 512] = V.c; lds16[tid + 768] = V.d; lds16[tid + 1024] = V.e;
+    if (tid < TAIL) lds16[tid + 1280] = V.f;
 }
 
 __device__ __forceinline__ void fill_clear(const RasterCtx& R) {
@@ -96,62 +120,6 @@ __device__ __forceinline__ void fill_clear(const RasterCtx& R) {
     const int tid = R.tid;
     lds16[tid] = z; lds16[tid + 256] = z; lds16[tid + 512] = z; lds16[tid + 768] = z; lds16[tid + 1024] = z;
     if (tid < TAIL) lds16[tid + 1280] = z;
-}
-
-__device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
-    const StampInfo si = R.T->stamps[id];
-    const uint32_t* sp = R.A.stamp_data + si.off;
-    const int h = si.h, npx = si.w * h;
-    for (int p = R.tid; p < npx; p += 256) {
-        int px = p / h, py = p - px * h;
-        uint32_t c = sp[p];
-        int X = x + px, Y = y + py;
-        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
-    }
-}
-
-// The same blit split in two so that the stamp's pixels are requested from global memory EARLY (together with the
-// template loads) and applied later: one memory round trip per frame instead of one per layer.  K*256 >= w*h.
-template <int K>
-struct StampRegs {
-    uint32_t px[K];
-    int h;
-};
-template <int K>
-__device__ __forceinline__ StampRegs<K> stamp_fetch(const RasterCtx& R, int id) {
-    StampRegs<K> s;
-    const StampInfo si = R.T->stamps[id];
-    const uint32_t* sp = R.A.stamp_data + si.off;
-    s.h = si.h;
-    const int npx = si.w * si.h;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        int p = R.tid + k * 256;
-        s.px[k] = p < npx ? sp[p] : 0u;
-    }
-    return s;
-}
-template <int K>
-__device__ __forceinline__ void stamp_apply(const RasterCtx& R, const StampRegs<K>& s, int x, int y) {
-    const int h = s.h;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        int p = R.tid + k * 256;
-        int px = p / h, py = p - px * h;
-        int X = x + px, Y = y + py;
-        uint32_t c = s.px[k];
-        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
-    }
-}
-
-__device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, int h, int fill, bool bordered) {
-    const uint32_t cf = R.T->palette[fill], ce = R.T->palette[R.T->border_of[fill]];
-    for (int p = R.tid; p < w * h; p += 256) {
-        int px = p / h, py = p - px * h;
-        int X = x + px, Y = y + py;
-        bool on_edge = bordered && (px == 0 || py == 0 || px == w - 1 || py == h - 1);
-        if ((unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, on_edge ? ce : cf);
-    }
 }
 
 // d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black), two bytes at a time in
@@ -166,6 +134,102 @@ __device__ __forceinline__ uint32_t darken4(uint32_t v, uint32_t a) {
     return darken2(v & 0x00FF00FFu, a) | (darken2((v >> 8) & 0x00FF00FFu, a) << 8);
 }
 
+__device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
+    const uint32_t* sp = R.A.stamp_data + R.T->stamps[id].off;
+    const int sh = R.T->stamps[id].sh, npx = (int)R.T->stamps[id].w << sh, ym = (1 << sh) - 1;
+    for (int p = R.tid; p < npx; p += 256) {
+        int px = p >> sh, py = p & ym;
+        uint32_t c = sp[p];
+        int X = x + px, Y = y + py;
+        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
+    }
+}
+
+// The same blit split in two so that the stamp's pixels are requested from global memory EARLY (together with the
+// template loads) and applied later: one memory round trip per frame instead of one per layer.  K*256 >= w*h.
+template <int K>
+struct StampRegs {
+    uint32_t px[K];
+    const uint32_t* src;  // pixels beyond K*256 (option-scaled stamps) are read at apply time
+    int sh, npx;
+};
+template <int K>
+__device__ __forceinline__ void stamp_fetch(const RasterCtx& R, int id, StampRegs<K>& s) {
+    s.src = R.A.stamp_data + R.T->stamps[id].off;
+    s.sh = R.T->stamps[id].sh;
+    s.npx = (int)R.T->stamps[id].w << s.sh;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int p = R.tid + k * 256;
+        s.px[k] = p < s.npx ? s.src[p] : 0u;
+    }
+}
+template <int K>
+__device__ __forceinline__ void stamp_none(StampRegs<K>& s) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) s.px[k] = 0u;
+    s.src = nullptr;
+    s.sh = 0;
+    s.npx = 0;
+}
+__device__ __forceinline__ bool never_skip(int, int) { return false; }
+// alpha != 0: the pixel is blended towards black unless its hole-mask bit is set (the stamp is below the spotlight
+// layer); skip(X, Y): pixels owned by a later layer that is written in the same phase.
+template <int K, class Skip>
+__device__ __forceinline__ void stamp_apply_lit(const RasterCtx& R, const StampRegs<K>& s, int x, int y, uint32_t alpha, Skip skip) {
+    const int sh = s.sh, ym = (1 << sh) - 1;
+    auto one = [&](int p, uint32_t c) {
+        int px = p >> sh, py = p & ym;
+        int X = x + px, Y = y + py;
+        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN && !skip(X, Y)) {
+            if (alpha) {
+                uint32_t lit = (R.mask[X * MASK_WORDS + (Y >> 5)] >> (Y & 31)) & 1u;
+                if (!lit) c = alpha < 255u ? darken4(c, alpha) : 0u;
+            }
+            put_rgb(R.frame, X, Y, c);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < K; ++k) one(R.tid + k * 256, s.px[k]);
+    for (int p = R.tid + K * 256; p < s.npx; p += 256) one(p, s.src[p]);
+}
+template <int K>
+__device__ __forceinline__ void stamp_apply(const RasterCtx& R, const StampRegs<K>& s, int x, int y) {
+    stamp_apply_lit<K>(R, s, x, y, 0u, never_skip);
+}
+
+// Single-colour stamps (Atlas::add_mono_stamp): lane t owns 4 rows (t & 7) * 4 .. + 3 of column t >> 3.
+struct MonoRegs {
+    uint32_t bits;  // the lane's column mask (0 beyond the stamp's width / for "no stamp")
+    uint32_t rgb;
+};
+__device__ __forceinline__ void mono_fetch(const RasterCtx& R, int id, MonoRegs& M) {
+    const int col = R.tid >> 3;
+    const uint32_t* sp = R.A.stamp_data + R.T->stamps[id].off;
+    M.bits = col < (int)R.T->stamps[id].w ? sp[col] : 0u;
+    M.rgb = R.T->palette[R.T->stamps[id].pad];
+}
+__device__ __forceinline__ void mono_apply(const RasterCtx& R, const MonoRegs& M, int x, int y) {
+    const int X = x + (R.tid >> 3), r0 = (R.tid & 7) * 4;
+    const uint32_t four = (M.bits >> r0) & 0xFu;
+    if (!four || (unsigned)X >= (unsigned)SCREEN) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int Y = y + r0 + k;
+        if (((four >> k) & 1u) && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, M.rgb);
+    }
+}
+
+__device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, int h, int fill, bool bordered) {
+    const uint32_t cf = R.T->palette[fill], ce = R.T->palette[R.T->border_of[fill]];
+    for (int p = R.tid; p < w * h; p += 256) {
+        int px = p / h, py = p - px * h;
+        int X = x + px, Y = y + py;
+        bool on_edge = bordered && (px == 0 || py == 0 || px == w - 1 || py == h - 1);
+        if ((unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, on_edge ? ce : cf);
+    }
+}
+
 __device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
     return (uint32_t)(x + 128) | ((uint32_t)(y + 128) << 9) | ((uint32_t)r << 18);
 }
@@ -176,7 +240,7 @@ __device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
 __device__ __forceinline__ void zero_mask(const RasterCtx& R) {
     if (R.tid < SCREEN * MASK_WORDS) R.mask[R.tid] = 0u;
 }
-__device__ __forceinline__ void hole_mask(const RasterCtx& R, const uint32_t* holes, int nholes) {
+__device__ __forceinline__ void hole_mask(const RasterCtx& R, cptr<uint32_t> holes, int nholes) {
     const int sub = R.tid >> 6, col0 = R.tid & 63;
     for (int base = 0; base < nholes; base += 4) {
         int hI = base + sub;
@@ -203,23 +267,22 @@ __device__ __forceinline__ void hole_mask(const RasterCtx& R, const uint32_t* ho
         }
     }
 }
-// hole_mask split in two for radii <= 32 and <= 16 holes: the span-table bytes are requested up front (with the other
-// global reads of the frame), the LDS atomics happen after the mask has been zeroed.
-struct HoleRegs {
-    uint32_t v[4];  // per round: x | y0 << 8 | y1 << 16 | valid << 24 (column and clipped y range handled by this lane)
+// ---- fused form of the spotlight layer (<= 16 holes of radius <= 16, the reference's 7..13) --------------------
+// 8 holes x 32 columns per round, two rounds; a column's lit span is at most 32 rows -> at most two mask words.
+struct HoleRegs8 {
+    uint32_t v[2];  // x | y0 << 8 | y1 << 16 | valid << 24
 };
-__device__ __forceinline__ bool holes_prefetchable(const uint32_t* holes, int nholes) {
+__device__ __forceinline__ bool holes_small(cptr<uint32_t> holes, int nholes) {
     bool ok = nholes <= 16;
-    for (int h = 0; h < nholes; ++h) ok = ok && (int)(holes[h] >> 18) <= 32;
+    for (int h = 0; h < nholes; ++h) ok = ok && (int)(holes[h] >> 18) <= 16;
     return ok;
 }
-__device__ __forceinline__ HoleRegs hole_fetch(const RasterCtx& R, const uint32_t* holes, int nholes) {
-    HoleRegs H;
-    const int sub = R.tid >> 6, col = R.tid & 63;
+__device__ __forceinline__ void hole_fetch8(const RasterCtx& R, cptr<uint32_t> holes, int nholes, HoleRegs8& H) {
+    const int sub = R.tid >> 5, col = R.tid & 31;
 #pragma unroll
-    for (int rnd = 0; rnd < 4; ++rnd) {
+    for (int rnd = 0; rnd < 2; ++rnd) {
         H.v[rnd] = 0u;
-        int hI = rnd * 4 + sub;
+        int hI = rnd * 8 + sub;
         if (hI < nholes) {
             const uint32_t hv = holes[hI];
             const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
@@ -232,57 +295,85 @@ __device__ __forceinline__ HoleRegs hole_fetch(const RasterCtx& R, const uint32_
             }
         }
     }
-    return H;
 }
-__device__ __forceinline__ void hole_apply(const RasterCtx& R, const HoleRegs& H) {
+__device__ __forceinline__ void hole_apply8(const RasterCtx& R, const HoleRegs8& H) {
 #pragma unroll
-    for (int rnd = 0; rnd < 4; ++rnd) {
+    for (int rnd = 0; rnd < 2; ++rnd) {
         const uint32_t hv = H.v[rnd];
         if (!(hv >> 24)) continue;
-        int X = (int)(hv & 255u), y0 = (int)((hv >> 8) & 255u), y1 = (int)((hv >> 16) & 255u);
-        for (int wI = 0; wI < MASK_WORDS; ++wI) {
-            int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
-            a0 = a0 < 0 ? 0 : a0;
-            a1 = a1 > 31 ? 31 : a1;
-            if (a0 <= a1) {
-                uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
-                atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
-            }
+        const int X = (int)(hv & 255u), y0 = (int)((hv >> 8) & 255u), y1 = (int)((hv >> 16) & 255u);
+        const int w0 = y0 >> 5, w1 = y1 >> 5;
+        const uint32_t lo_bits = 0xFFFFFFFFu << (y0 & 31), hi_bits = 0xFFFFFFFFu >> (31 - (y1 & 31));
+        if (w0 == w1) {
+            atomicOr(&R.mask[X * MASK_WORDS + w0], lo_bits & hi_bits);
+        } else {
+            atomicOr(&R.mask[X * MASK_WORDS + w0], lo_bits);
+            atomicOr(&R.mask[X * MASK_WORDS + w1], hi_bits);
         }
     }
 }
 
-// in-place darkening of every pixel whose mask bit is clear; 4 pixels (12 bytes = 3 dwords) per task:
-// 84 columns x 21 segments.  The caller synchronises before (frame + mask complete) and after.
-__device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha) {
-    uint32_t* f32 = reinterpret_cast<uint32_t*>(R.frame);
-    for (int k = R.tid; k < SCREEN * 21; k += 256) {
-        int X = k / 21, seg = k - X * 21, y0 = seg * 4;
-        uint32_t lit = (R.mask[X * MASK_WORDS + (y0 >> 5)] >> (y0 & 31)) & 0xFu;
-        if (lit == 0xFu) continue;
-        uint32_t* p = f32 + X * (COL_BYTES / 4) + seg * 3;
-        uint32_t v0 = p[0], v1 = p[1], v2 = p[2];
-        uint32_t m0 = ((lit & 1u) ? 0x00FFFFFFu : 0u) | ((lit & 2u) ? 0xFF000000u : 0u);
-        uint32_t m1 = ((lit & 2u) ? 0x0000FFFFu : 0u) | ((lit & 4u) ? 0xFFFF0000u : 0u);
-        uint32_t m2 = ((lit & 4u) ? 0x000000FFu : 0u) | ((lit & 8u) ? 0xFFFFFF00u : 0u);
-        uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
-        if (alpha < 255u) {
-            d0 = darken4(v0, alpha);
-            d1 = darken4(v1, alpha);
-            d2 = darken4(v2, alpha);
+// Background template with the darkening applied on the way into LDS.  One task per lane: 28 pixels of one column
+// (a column is 252 B = 3 x 84 B, so lane t owns bytes [84t, 84t + 84) of the frame; 252 of the 256 lanes work).  The
+// 28 mask bits of the task come from at most two mask words; pixels are handled in groups of 4 = 3 dwords.
+struct TemplRegs {
+    uint32_t v[21];
+};
+__device__ __forceinline__ void templ_fetch(const RasterCtx& R, int t, TemplRegs& T) {
+    const int lane = R.tid < 252 ? R.tid : 251;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.A.templates + (size_t)t * FRAME_BYTES) + 21 * lane;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) T.v[i] = src[i];
+}
+__device__ __forceinline__ void templ_apply_dark(const RasterCtx& R, const TemplRegs& T, uint32_t alpha) {
+    if (R.tid >= 252) return;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(R.frame) + 21 * R.tid;
+    uint32_t lit = 0x0FFFFFFFu;
+    if (alpha) {
+        const int X = R.tid / 3, y0 = (R.tid - 3 * X) * 28;
+        const uint32_t* mw = R.mask + X * MASK_WORDS;
+        const int w = y0 >> 5;
+        const uint64_t two = (uint64_t)mw[w] | ((uint64_t)(w + 1 < MASK_WORDS ? mw[w + 1] : 0u) << 32);
+        lit = (uint32_t)(two >> (y0 & 31)) & 0x0FFFFFFFu;
+    }
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+        uint32_t v0 = T.v[3 * g], v1 = T.v[3 * g + 1], v2 = T.v[3 * g + 2];
+        if (alpha) {
+            // per-pixel 0 / ~0 from the four mask bits, then byte masks of the three dwords (RGBR GBRG BRGB)
+            const uint32_t s0 = 0u - ((lit >> (4 * g)) & 1u), s1 = 0u - ((lit >> (4 * g + 1)) & 1u);
+            const uint32_t s2 = 0u - ((lit >> (4 * g + 2)) & 1u), s3 = 0u - ((lit >> (4 * g + 3)) & 1u);
+            const uint32_t m0 = (s0 & 0x00FFFFFFu) | (s1 & 0xFF000000u);
+            const uint32_t m1 = (s1 & 0x0000FFFFu) | (s2 & 0xFFFF0000u);
+            const uint32_t m2 = (s2 & 0x000000FFu) | (s3 & 0xFFFFFF00u);
+            uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
+            if (alpha < 255u) {  // workgroup-uniform: only the dim ramp at the start of an episode
+                d0 = darken4(v0, alpha);
+                d1 = darken4(v1, alpha);
+                d2 = darken4(v2, alpha);
+            }
+            v0 = (v0 & m0) | (d0 & ~m0);
+            v1 = (v1 & m1) | (d1 & ~m1);
+            v2 = (v2 & m2) | (d2 & ~m2);
         }
-        p[0] = (v0 & m0) | (d0 & ~m0);
-        p[1] = (v1 & m1) | (d1 & ~m1);
-        p[2] = (v2 & m2) | (d2 & ~m2);
+        dst[3 * g] = v0;
+        dst[3 * g + 1] = v1;
+        dst[3 * g + 2] = v2;
     }
 }
 
 // Composer concept:
 //   struct Desc;                                   trivially copyable, sizeof % 16 == 0
-//   static __device__ bool skip(const Desc*);      true: leave the frame untouched (masked reset)
-//   static __device__ void compose(const Desc*, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
-// The descriptor is read through its (workgroup-uniform) global pointer, so every field access -- also array
-// elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
+//   struct Pre;                                    every global operand of one frame, in registers
+//   static __device__ bool skip(cptr<Desc>);       true: leave the frame untouched (masked reset)
+//   static __device__ void prefetch(cptr<Desc>, const RasterCtx&, Pre&);   issues the loads, no LDS access
+//   static __device__ void compose(cptr<Desc>, const Pre&, const RasterCtx&);   LDS only; leaves the frame complete
+// The descriptor is read through its (workgroup-uniform, constant address space) pointer, so every field access --
+// also array elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
+// compose() does not touch global memory (gfx9 counts loads and stores in one in-order counter, vmcnt: a load issued
+// inside compose() could only be consumed after the previous frame's stores had drained).  A software-pipelined loop
+// (frame i+1's prefetch issued before frame i's stores) was built and measured: no gain over this simple loop for the
+// spotlight frames, a loss for the mortar frames (profiles/r01c_raster_generations.md).
 // ---- frame stream-out ---------------------------------------------------------------------------------------
 // MG_OBS_U8_XYC: the reference's observation, pygame.surfarray.array3d order [x][y][c] uint8 (21,168 B = 1,323 x 16 B).
 // MG_OBS_F32_CYX / MG_OBS_F16_CYX: what a trainer builds from it before its CNN: value / 255 as
@@ -291,13 +382,18 @@ __device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha)
 template <int FMT>
 __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
     if constexpr (FMT == MG_OBS_U8_XYC) {
-        const uint4* lds16 = reinterpret_cast<const uint4*>(frame);
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
-        uint4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
-        uint4 v5 = make_uint4(0, 0, 0, 0);
+        const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
+        u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
+        u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
+        u32x4 v5 = (u32x4)(0u);
         if (tid < TAIL) v5 = lds16[tid + 1280];
-        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
-        if (tid < TAIL) dst[tid + 1280] = v5;
+        // non-temporal stores: the observation stream does not displace the logic kernel's state and descriptors
+        // from L2 (spotlight workloads: raster -4 %, logic kernel -9 %; for the mortar frames of generation 1 the
+        // same hint costs 40 %, profiles/r01c_raster_generations.md)
+        __builtin_nontemporal_store(v0, &dst[tid]); __builtin_nontemporal_store(v1, &dst[tid + 256]);
+        __builtin_nontemporal_store(v2, &dst[tid + 512]); __builtin_nontemporal_store(v3, &dst[tid + 768]);
+        __builtin_nontemporal_store(v4, &dst[tid + 1024]);
+        if (tid < TAIL) __builtin_nontemporal_store(v5, &dst[tid + 1280]);
     } else if constexpr (FMT == MG_OBS_F32_CYX) {
         float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
         constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame
@@ -339,13 +435,15 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     R.frame = smem;
     R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
     R.A = A;
-    R.T = A.tables;
+    R.T = as_const(A.tables);
     R.tid = threadIdx.x;
-    const int tid = threadIdx.x;
-    for (int env = blockIdx.x; env < n; env += gridDim.x) {
-        const typename Composer::Desc* d = descs + env;  // workgroup-uniform
-        if (Composer::skip(d)) continue;
-        Composer::compose(d, R);
+    const int tid = threadIdx.x, stride = gridDim.x;
+    const cptr<typename Composer::Desc> cdescs = as_const(descs);
+    for (int env = blockIdx.x; env < n; env += stride) {
+        if (Composer::skip(cdescs + env)) continue;
+        typename Composer::Pre P;
+        Composer::prefetch(cdescs + env, R, P);
+        Composer::compose(cdescs + env, P, R);
         __syncthreads();
         store_frame<FMT>(smem, obs, env, tid);
         __syncthreads();  // the LDS frame is reused by the next iteration
@@ -358,13 +456,17 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         const char* e = getenv("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : RASTER_GRID;
     }();
+    static const int lds = [] {  // MEMGYM_RASTER_LDS inflates the LDS request (fewer resident workgroups per CU; tuning only)
+        const char* e = getenv("MEMGYM_RASTER_LDS");
+        return e && atoi(e) > RASTER_LDS ? atoi(e) : RASTER_LDS;
+    }();
     const int grid = n < tuned ? n : tuned;
     if (fmt == MG_OBS_F32_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n);
     else if (fmt == MG_OBS_F16_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n);
     else
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n);
 }
 
 }  // namespace mg

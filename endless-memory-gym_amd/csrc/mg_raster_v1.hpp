@@ -1,0 +1,377 @@
+// mg_raster_v1.hpp -- raster skeleton, generation 1 (namespace mg::v1): used by the template-dominated families
+// (mortar, mystery).  The spotlight family uses generation 2 (mg_raster.hpp: constant-address-space descriptors,
+// register-prefetched layers, darkening fused into the template pass).  Measured side by side on the same MI355X
+// (profiles/r01c_raster_generations.md): generation 2 is 25-30 % faster for the spotlight frames and 8-11 % SLOWER
+// for the mortar frames, whose kernel time is set by how the HBM write stream is paced, not by instruction count.
+//
+//
+// raster_kernel<Composer>: PERSISTENT workgroups (256 lanes = 4 waves); each walks frames
+// env = blockIdx.x, blockIdx.x + gridDim.x, ...  For one frame it
+//   1. reads the family's small per-instance frame descriptor (workgroup-uniform -> scalar loads),
+//   2. composes the 84x84x3 observation in 21,168 B of LDS with the helpers below, in the reference's blit order
+//      (its _draw_surfaces(), e.g. memory_gym/mortar_mayhem_grid.py:92-102,367-370,
+//      endless_searing_spotlights.py:464-479, endless_mystery_path.py:134-160),
+//   3. streams it to HBM as 1,323 x 16-byte stores, lane-contiguous (1 KiB per wave instruction).
+// The stores are fire-and-forget, so the workgroup composes its next frame while they drain; a
+// one-frame-per-workgroup launch keeps the LDS hostage until the stores are acknowledged (measured 322 us vs 264 us
+// per 65,536 frames; an interpreter over a generic display list measured 390-415 us: tools/microbench/raster_bench.hip).
+// Roofline: HBM write bandwidth; algorithmic traffic per instance-step = 21,168 B written + sizeof(Desc) read.
+//
+// Helpers (all lanes of the workgroup call them together; callers place __syncthreads() between overlapping layers):
+//   fill_template  copy a pre-rendered full frame (mortar arena variants, chessboards) from the L2-resident atlas
+//   fill_clear     black frame
+//   stamp          colour-keyed blit of a palette-indexed stamp (agent sprites, glyphs, cross, coin, exit), clipped
+//   rect           filled rectangle with optional 1-px inset border (tiles, bars), clipped
+//   darken         the spotlight layer: pixels outside every hole disc blended towards black with SDL's
+//                  surface-alpha rule d - floor(d*alpha/255)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/memgym.h"
+#include "mg_device.hpp"
+
+namespace mg {
+namespace v1 {
+
+constexpr int DISC_RMAX = 64;
+constexpr int MAX_STAMPS = 48;
+constexpr int PALETTE_SIZE = 32;
+constexpr int MASK_WORDS = 3;                 // 84 bits per column
+constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
+constexpr int RASTER_GRID = 256 * 7 * 8;      // 7 workgroups fit one CU's 160 KiB of LDS; 8 rounds of persistent workgroups (bench sweep: best of 2..37)
+constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
+
+struct StampInfo {
+    uint32_t off;  // pixel offset into the stamp data, pixels stored [x][y] (column-major like the frame)
+    uint16_t w, h;
+};
+
+struct AtlasTables {
+    StampInfo stamps[MAX_STAMPS];
+    uint32_t palette[PALETTE_SIZE];   // r | g<<8 | b<<16
+    uint8_t border_of[PALETTE_SIZE];  // palette id of the 1-px border drawn around a bordered rect of this fill colour
+};
+
+// Everything the raster kernel samples (device pointers; small enough to sit in the scalar/L1/L2 caches).
+struct RasterAtlas {
+    const uint8_t* templates;   // [n_templates][84][84][3]
+    const uint32_t* stamp_data; // r | g<<8 | b<<16 | 0xFF<<24 per opaque pixel, 0 = transparent (colour key)
+    const int8_t* disc_span;    // [DISC_RMAX+1][2*DISC_RMAX][2]: per column i of a radius-r disc, (lo, hi) y offsets; lo > hi = empty
+    const AtlasTables* tables;
+};
+
+// Palette ids shared by all families
+enum : uint8_t {
+    C_KEY = 0, C_BODY = 1, C_HAND = 2, C_OUTLINE = 3, C_WHITE = 4, C_RED = 5, C_GREEN = 6, C_BLUE = 7, C_YELLOW = 8,
+    C_ORANGE = 9, C_GREY50 = 10, C_GREY120 = 11, C_PURPLE = 12, C_ACT_ORANGE = 13, C_GREY210 = 14, C_BLACK = 15,
+    C_EXIT_OPEN = 16, C_EXIT_CLOSED = 17, C_ICY = 18
+};
+
+struct RasterCtx {
+    uint8_t* frame;         // LDS, [x][y][c]
+    uint32_t* mask;         // LDS, [84][MASK_WORDS] hole mask scratch
+    const AtlasTables* T;   // palette / stamp infos (global; indices are workgroup-uniform -> scalar loads)
+    RasterAtlas A;
+    int tid;
+};
+
+__device__ __forceinline__ void put_rgb(uint8_t* frame, int x, int y, uint32_t rgb) {
+    uint8_t* p = frame + (x * SCREEN + y) * 3;
+    p[0] = (uint8_t)rgb;
+    p[1] = (uint8_t)(rgb >> 8);
+    p[2] = (uint8_t)(rgb >> 16);
+}
+
+// all six 16-byte loads are issued before the first LDS write (one L2 round trip, not six)
+__device__ __forceinline__ void fill_template(const RasterCtx& R, int t) {
+    uint4* lds16 = reinterpret_cast<uint4*>(R.frame);
+    const uint4* src = reinterpret_cast<const uint4*>(R.A.templates + (size_t)t * FRAME_BYTES);
+    const int tid = R.tid;
+    uint4 v0 = src[tid], v1 = src[tid + 256], v2 = src[tid + 512], v3 = src[tid + 768], v4 = src[tid + 1024];
+    uint4 v5 = make_uint4(0, 0, 0, 0);
+    if (tid < TAIL) v5 = src[tid + 1280];
+    lds16[tid] = v0; lds16[tid + 256] = v1; lds16[tid + 512] = v2; lds16[tid + 768] = v3; lds16[tid + 1024] = v4;
+    if (tid < TAIL) lds16[tid + 1280] = v5;
+}
+
+__device__ __forceinline__ void fill_clear(const RasterCtx& R) {
+    uint4* lds16 = reinterpret_cast<uint4*>(R.frame);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const int tid = R.tid;
+    lds16[tid] = z; lds16[tid + 256] = z; lds16[tid + 512] = z; lds16[tid + 768] = z; lds16[tid + 1024] = z;
+    if (tid < TAIL) lds16[tid + 1280] = z;
+}
+
+__device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
+    const StampInfo si = R.T->stamps[id];
+    const uint32_t* sp = R.A.stamp_data + si.off;
+    const int h = si.h, npx = si.w * h;
+    for (int p = R.tid; p < npx; p += 256) {
+        int px = p / h, py = p - px * h;
+        uint32_t c = sp[p];
+        int X = x + px, Y = y + py;
+        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
+    }
+}
+
+// The same blit split in two so that the stamp's pixels are requested from global memory EARLY (together with the
+// template loads) and applied later: one memory round trip per frame instead of one per layer.  K*256 >= w*h.
+template <int K>
+struct StampRegs {
+    uint32_t px[K];
+    int h;
+};
+template <int K>
+__device__ __forceinline__ StampRegs<K> stamp_fetch(const RasterCtx& R, int id) {
+    StampRegs<K> s;
+    const StampInfo si = R.T->stamps[id];
+    const uint32_t* sp = R.A.stamp_data + si.off;
+    s.h = si.h;
+    const int npx = si.w * si.h;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int p = R.tid + k * 256;
+        s.px[k] = p < npx ? sp[p] : 0u;
+    }
+    return s;
+}
+template <int K>
+__device__ __forceinline__ void stamp_apply(const RasterCtx& R, const StampRegs<K>& s, int x, int y) {
+    const int h = s.h;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int p = R.tid + k * 256;
+        int px = p / h, py = p - px * h;
+        int X = x + px, Y = y + py;
+        uint32_t c = s.px[k];
+        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
+    }
+}
+
+__device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, int h, int fill, bool bordered) {
+    const uint32_t cf = R.T->palette[fill], ce = R.T->palette[R.T->border_of[fill]];
+    for (int p = R.tid; p < w * h; p += 256) {
+        int px = p / h, py = p - px * h;
+        int X = x + px, Y = y + py;
+        bool on_edge = bordered && (px == 0 || py == 0 || px == w - 1 || py == h - 1);
+        if ((unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, on_edge ? ce : cf);
+    }
+}
+
+// d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black), two bytes at a time in
+// 16-bit lanes: t = d*a <= 65025 and t + 1 + (t >> 8) <= 65280 never carry into the neighbouring lane, and
+// (t + 1 + (t >> 8)) >> 8 == t / 255 for every t <= 65535.
+__device__ __forceinline__ uint32_t darken2(uint32_t x, uint32_t a) {  // x = 0x00dd00dd
+    uint32_t t = x * a;
+    uint32_t q = ((t + 0x00010001u + ((t >> 8) & 0x00FF00FFu)) >> 8) & 0x00FF00FFu;
+    return x - q;
+}
+__device__ __forceinline__ uint32_t darken4(uint32_t v, uint32_t a) {
+    return darken2(v & 0x00FF00FFu, a) | (darken2((v >> 8) & 0x00FF00FFu, a) << 8);
+}
+
+__device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
+    return (uint32_t)(x + 128) | ((uint32_t)(y + 128) << 9) | ((uint32_t)r << 18);
+}
+
+// holes[i] = pack_hole(x, y, r): filled discs (pygame's even-diameter midpoint disc) that stay lit.
+// hole_mask: union of the discs as an 84x84 bit mask in LDS; tasks = (hole, column), 4 holes x 64 columns per round,
+// so the span-table loads of all holes are in flight together.  The mask must have been zeroed (and synchronised).
+__device__ __forceinline__ void zero_mask(const RasterCtx& R) {
+    if (R.tid < SCREEN * MASK_WORDS) R.mask[R.tid] = 0u;
+}
+__device__ __forceinline__ void hole_mask(const RasterCtx& R, const uint32_t* holes, int nholes) {
+    const int sub = R.tid >> 6, col0 = R.tid & 63;
+    for (int base = 0; base < nholes; base += 4) {
+        int hI = base + sub;
+        if (hI >= nholes) continue;
+        const uint32_t hv = holes[hI];
+        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
+        for (int col = col0; col < 2 * r; col += 64) {
+            int X = hx - r + col;
+            int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
+            int y0 = hy + lo, y1 = hy + hi;
+            y0 = y0 < 0 ? 0 : y0;
+            y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
+            if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) {
+                for (int wI = 0; wI < MASK_WORDS; ++wI) {
+                    int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
+                    a0 = a0 < 0 ? 0 : a0;
+                    a1 = a1 > 31 ? 31 : a1;
+                    if (a0 <= a1) {
+                        uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
+                        atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
+                    }
+                }
+            }
+        }
+    }
+}
+// hole_mask split in two for radii <= 32 and <= 16 holes: the span-table bytes are requested up front (with the other
+// global reads of the frame), the LDS atomics happen after the mask has been zeroed.
+struct HoleRegs {
+    uint32_t v[4];  // per round: x | y0 << 8 | y1 << 16 | valid << 24 (column and clipped y range handled by this lane)
+};
+__device__ __forceinline__ bool holes_prefetchable(const uint32_t* holes, int nholes) {
+    bool ok = nholes <= 16;
+    for (int h = 0; h < nholes; ++h) ok = ok && (int)(holes[h] >> 18) <= 32;
+    return ok;
+}
+__device__ __forceinline__ HoleRegs hole_fetch(const RasterCtx& R, const uint32_t* holes, int nholes) {
+    HoleRegs H;
+    const int sub = R.tid >> 6, col = R.tid & 63;
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        H.v[rnd] = 0u;
+        int hI = rnd * 4 + sub;
+        if (hI < nholes) {
+            const uint32_t hv = holes[hI];
+            const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
+            if (col < 2 * r) {
+                int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
+                int X = hx - r + col, y0 = hy + lo, y1 = hy + hi;
+                y0 = y0 < 0 ? 0 : y0;
+                y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
+                if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) H.v[rnd] = (uint32_t)X | ((uint32_t)y0 << 8) | ((uint32_t)y1 << 16) | (1u << 24);
+            }
+        }
+    }
+    return H;
+}
+__device__ __forceinline__ void hole_apply(const RasterCtx& R, const HoleRegs& H) {
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        const uint32_t hv = H.v[rnd];
+        if (!(hv >> 24)) continue;
+        int X = (int)(hv & 255u), y0 = (int)((hv >> 8) & 255u), y1 = (int)((hv >> 16) & 255u);
+        for (int wI = 0; wI < MASK_WORDS; ++wI) {
+            int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
+            a0 = a0 < 0 ? 0 : a0;
+            a1 = a1 > 31 ? 31 : a1;
+            if (a0 <= a1) {
+                uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
+                atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
+            }
+        }
+    }
+}
+
+// in-place darkening of every pixel whose mask bit is clear; 4 pixels (12 bytes = 3 dwords) per task:
+// 84 columns x 21 segments.  The caller synchronises before (frame + mask complete) and after.
+__device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha) {
+    uint32_t* f32 = reinterpret_cast<uint32_t*>(R.frame);
+    for (int k = R.tid; k < SCREEN * 21; k += 256) {
+        int X = k / 21, seg = k - X * 21, y0 = seg * 4;
+        uint32_t lit = (R.mask[X * MASK_WORDS + (y0 >> 5)] >> (y0 & 31)) & 0xFu;
+        if (lit == 0xFu) continue;
+        uint32_t* p = f32 + X * (COL_BYTES / 4) + seg * 3;
+        uint32_t v0 = p[0], v1 = p[1], v2 = p[2];
+        uint32_t m0 = ((lit & 1u) ? 0x00FFFFFFu : 0u) | ((lit & 2u) ? 0xFF000000u : 0u);
+        uint32_t m1 = ((lit & 2u) ? 0x0000FFFFu : 0u) | ((lit & 4u) ? 0xFFFF0000u : 0u);
+        uint32_t m2 = ((lit & 4u) ? 0x000000FFu : 0u) | ((lit & 8u) ? 0xFFFFFF00u : 0u);
+        uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
+        if (alpha < 255u) {
+            d0 = darken4(v0, alpha);
+            d1 = darken4(v1, alpha);
+            d2 = darken4(v2, alpha);
+        }
+        p[0] = (v0 & m0) | (d0 & ~m0);
+        p[1] = (v1 & m1) | (d1 & ~m1);
+        p[2] = (v2 & m2) | (d2 & ~m2);
+    }
+}
+
+// Composer concept:
+//   struct Desc;                                   trivially copyable, sizeof % 16 == 0
+//   static __device__ bool skip(const Desc*);      true: leave the frame untouched (masked reset)
+//   static __device__ void compose(const Desc*, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
+// The descriptor is read through its (workgroup-uniform) global pointer, so every field access -- also array
+// elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
+// ---- frame stream-out ---------------------------------------------------------------------------------------
+// MG_OBS_U8_XYC: the reference's observation, pygame.surfarray.array3d order [x][y][c] uint8 (21,168 B = 1,323 x 16 B).
+// MG_OBS_F32_CYX / MG_OBS_F16_CYX: what a trainer builds from it before its CNN: value / 255 as
+// float32 / float16 in image order [c][y][x].  The transpose is done LDS-side (byte gathers, stride 252 B), the
+// global stores stay contiguous 16-B vectors.
+template <int FMT>
+__device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
+    if constexpr (FMT == MG_OBS_U8_XYC) {
+        const uint4* lds16 = reinterpret_cast<const uint4*>(frame);
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
+        uint4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
+        uint4 v5 = make_uint4(0, 0, 0, 0);
+        if (tid < TAIL) v5 = lds16[tid + 1280];
+        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
+        if (tid < TAIL) dst[tid + 1280] = v5;
+    } else if constexpr (FMT == MG_OBS_F32_CYX) {
+        float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame
+        for (int q = tid; q < TOTAL; q += 256) {
+            const int row = q / PER_ROW, x0 = (q - row * PER_ROW) * 4;
+            const int c = row / SCREEN, y = row - c * SCREEN;
+            const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+            float4 v;
+            v.x = (float)src[0] / 255.0f;
+            v.y = (float)src[COL_BYTES] / 255.0f;
+            v.z = (float)src[2 * COL_BYTES] / 255.0f;
+            v.w = (float)src[3 * COL_BYTES] / 255.0f;
+            dst[q] = v;
+        }
+    } else {
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<_Float16*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
+        for (int q = tid; q < TOTAL; q += 256) {
+            union { _Float16 h[8]; uint4 v; } u;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int qq = 2 * q + g;
+                const int row = qq / PER_ROW, x0 = (qq - row * PER_ROW) * 4;
+                const int c = row / SCREEN, y = row - c * SCREEN;
+                const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = (_Float16)((float)src[k * COL_BYTES] / 255.0f);
+            }
+            dst[q] = u.v;
+        }
+    }
+}
+
+template <class Composer, int FMT>
+__global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
+                                                     void* __restrict__ obs, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = A.tables;
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    for (int env = blockIdx.x; env < n; env += gridDim.x) {
+        const typename Composer::Desc* d = descs + env;  // workgroup-uniform
+        if (Composer::skip(d)) continue;
+        Composer::compose(d, R);
+        __syncthreads();
+        store_frame<FMT>(smem, obs, env, tid);
+        __syncthreads();  // the LDS frame is reused by the next iteration
+    }
+}
+
+template <class Composer>
+inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s) {
+    static const int tuned = [] {  // MEMGYM_RASTER_GRID overrides the persistent grid size (tuning experiments)
+        const char* e = getenv("MEMGYM_RASTER_GRID");
+        return e ? atoi(e) : RASTER_GRID;
+    }();
+    const int grid = n < tuned ? n : tuned;
+    if (fmt == MG_OBS_F32_CYX)
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+    else if (fmt == MG_OBS_F16_CYX)
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+    else
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n);
+}
+
+}  // namespace v1
+}  // namespace mg

@@ -36,7 +36,7 @@ struct SpotParams {
     int visual_feedback, dim_duration, dim_step, light_threshold;
     int coin_enabled, coin_show_duration, coins_visible, sample_agent_position, show_last_action, show_last_positive_reward;
     int r_lo, r_hi;                 // radius = integers(r_lo, r_hi)
-    int agent_radius, sprite_dim, coin_radius;
+    int agent_radius, sprite_half, coin_radius;
     int v_axis_i, v_diag_i;
     int spawn_clamp;                // _process_spawn_pos offset
     int bar_x, bar_w, quarter, bar_h, exit_half;
@@ -62,12 +62,13 @@ struct __attribute__((aligned(16))) SpotCore {
 static_assert(sizeof(SpotCore) == 80, "SpotCore must be 80 bytes");
 
 struct __attribute__((aligned(16))) SpotDesc {
-    uint8_t valid, bg, sprite, alpha;
-    int16_t sx, sy;
-    uint8_t n_holes, n_coins, coin_above, red_w;
-    uint8_t c_base, c_act0, c_act1, c_bar;
-    uint8_t bar_x, bar_w, quarter, exit_stamp;
-    int16_t exit_x, exit_y;
+    // 32-bit bit-fields: the raster kernel reads these with scalar dword loads (there is no sub-dword scalar load)
+    uint32_t valid : 8, bg : 8, sprite : 8, alpha : 8;
+    int32_t sx : 16, sy : 16;
+    uint32_t n_holes : 8, n_coins : 8, coin_above : 8, red_w : 8;
+    uint32_t c_base : 8, c_act0 : 8, c_act1 : 8, c_bar : 8;
+    uint32_t bar_x : 8, bar_w : 8, quarter : 8, exit_stamp : 8;
+    int32_t exit_x : 16, exit_y : 16;
     uint32_t pad[2];
     uint32_t coins[MAX_COINS];  // (x+128) | (y+128)<<16 : top-left of the coin stamp
     uint32_t holes[MAX_HOLES];
@@ -79,57 +80,81 @@ constexpr int BAR_H = 4;  // top bar height: int(16 * SCALE)
 
 struct SpotComposer {
     typedef SpotDesc Desc;
-    static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->valid == 0; }
-    static __device__ __forceinline__ void coins(const Desc& d, const RasterCtx& R, const StampRegs<1>& coin) {
-        for (int k = 0; k < d.n_coins; ++k)  // coins keep their distance from each other (sampler block radius): no overlap
-            stamp_apply<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128);
+    static __device__ __forceinline__ bool skip(cptr<Desc> dp) { return dp->valid == 0; }
+    // top bar (rows y < BAR_H of every column); priority reward bar > action rects > red > green > base.
+    // Returns false where no bar element covers column x (the scene shows through).
+    static __device__ __forceinline__ bool bar_colour(const Desc MG_CONST_AS& d, cptr<AtlasTables> T, int x, uint32_t* c) {
+        bool has = d.c_base != 0xFF;
+        uint8_t id = d.c_base;
+        if (x < 2 * d.quarter) { id = x < d.red_w ? (uint8_t)C_RED : (uint8_t)C_GREEN; has = true; }
+        else if (d.c_act0 != 0xFF) { id = x < 3 * d.quarter ? d.c_act0 : d.c_act1; has = true; }
+        if (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w) { id = d.c_bar; has = true; }
+        if (has) *c = T->palette[id];
+        return has;
     }
-    static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
-        const Desc& d = *dp;
-        // every global read of the frame is issued up front (sprite / coin / exit pixels and disc spans into registers,
-        // template -> LDS): one memory round trip per frame after the descriptor
-        const AtlasTables* T = R.T;
-        const uint32_t c_base = d.c_base != 0xFF ? T->palette[d.c_base] : 0u, c_green = T->palette[C_GREEN], c_red = T->palette[C_RED];
-        const uint32_t c_a0 = d.c_act0 != 0xFF ? T->palette[d.c_act0] : 0u, c_a1 = d.c_act1 != 0xFF ? T->palette[d.c_act1] : 0u;
-        const uint32_t c_bar = d.c_bar != 0xFF ? T->palette[d.c_bar] : 0u;
-        StampRegs<4> agent = stamp_fetch<4>(R, d.sprite);
-        StampRegs<1> coin, exitp;
-        coin.px[0] = exitp.px[0] = 0u;
-        coin.h = exitp.h = 1;
-        if (d.n_coins) coin = stamp_fetch<1>(R, ST_COIN);
-        if (d.exit_stamp != 0xFF) exitp = stamp_fetch<1>(R, d.exit_stamp);
-        const bool pre = d.alpha && holes_prefetchable(d.holes, d.n_holes);
-        HoleRegs H;
-        if (pre) H = hole_fetch(R, d.holes, d.n_holes);
-        fill_template(R, d.bg);
-        zero_mask(R);
-        __syncthreads();
-        if (d.alpha) {  // the mask words are disjoint from the frame bytes
-            if (pre) hole_apply(R, H);
-            else hole_mask(R, d.holes, d.n_holes);
-        }
-        if (!d.coin_above && d.n_coins) coins(d, R, coin);
-        if (d.exit_stamp != 0xFF) stamp_apply<1>(R, exitp, d.exit_x, d.exit_y);  // never overlaps a coin (sampler)
-        __syncthreads();
-        stamp_apply<4>(R, agent, d.sx, d.sy);
-        __syncthreads();
-        if (d.alpha) {
-            darken_apply(R, d.alpha);
+    static __device__ __forceinline__ bool bar_covers(const Desc MG_CONST_AS& d, int x) {
+        return d.c_base != 0xFF || x < 2 * d.quarter || d.c_act0 != 0xFF || (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w);
+    }
+    // Order of the reference's _draw_surfaces (endless_searing_spotlights.py:464-479, searing_spotlights.py:524-545):
+    // board, coins (unless drawn above), exit, agent, spotlight layer, coins above, top bar.  The spotlight layer is
+    // not a pass of its own: the hole mask is built first and every layer below it is darkened as it is written.
+    struct Pre {
+        TemplRegs bg;
+        StampRegs<1> agent, coin, exitp;
+        HoleRegs8 holes;
+    };
+    // every global read of the frame (template, sprite / coin / exit pixels, disc spans)
+    static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) {
+        const Desc MG_CONST_AS& d = *dp;
+        stamp_fetch<1>(R, d.sprite, P.agent);
+        if (d.n_coins) stamp_fetch<1>(R, ST_COIN, P.coin);
+        else stamp_none<1>(P.coin);
+        if (d.exit_stamp != 0xFF) stamp_fetch<1>(R, d.exit_stamp, P.exitp);
+        else stamp_none<1>(P.exitp);
+        P.holes.v[0] = P.holes.v[1] = 0u;
+        if (d.alpha && holes_small(d.holes, d.n_holes)) hole_fetch8(R, d.holes, d.n_holes, P.holes);
+        templ_fetch(R, d.bg, P.bg);
+    }
+    static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
+        const Desc MG_CONST_AS& d = *dp;
+        const cptr<AtlasTables> T = R.T;
+        const uint32_t alpha = d.alpha;
+        const StampRegs<1>&agent = P.agent, &coin = P.coin, &exitp = P.exitp;
+        if (alpha) {
+            zero_mask(R);
+            __syncthreads();
+            if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
+            else hole_mask(R, d.holes, d.n_holes);  // radii beyond the reference's range: span table read in place
             __syncthreads();
         }
-        if (d.coin_above && d.n_coins) {
-            coins(d, R, coin);
+        templ_apply_dark(R, P.bg, alpha);
+        __syncthreads();
+        auto under_bar = [&](int X, int Y) { return Y < BAR_H && bar_covers(d, X); };
+        if (!d.coin_above) {
+            // coins keep their distance from each other and from the exit (sampler block radius): no overlap
+            for (int k = 0; k < d.n_coins; ++k)
+                stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, alpha, never_skip);
+            if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
             __syncthreads();
+            stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, under_bar);
+        } else {
+            if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
+            __syncthreads();
+            stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, never_skip);
+            __syncthreads();
+            for (int k = 0; k < d.n_coins; ++k)
+                stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
         }
-        // top bar: rows y < 4 of every column; priority reward bar > action rects > red > green > base
-        for (int p = R.tid; p < SCREEN * BAR_H; p += 256) {
-            int x = p / BAR_H, y = p - x * BAR_H;
-            uint32_t c = c_base;
-            bool has = d.c_base != 0xFF;
-            if (x < 2 * d.quarter) { c = x < d.red_w ? c_red : c_green; has = true; }
-            else if (d.c_act0 != 0xFF) { c = x < 3 * d.quarter ? c_a0 : c_a1; has = true; }
-            if (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w) { c = c_bar; has = true; }
-            if (has) put_rgb(R.frame, x, y, c);
+        static_assert(BAR_H == 4, "one bar column = 4 pixels = 3 dwords");
+        if (R.tid < SCREEN) {
+            uint32_t c = 0u;
+            if (bar_colour(d, T, R.tid, &c)) {
+                const uint32_t r = c & 0xFFu, g = (c >> 8) & 0xFFu, b = (c >> 16) & 0xFFu;
+                uint32_t* p = reinterpret_cast<uint32_t*>(R.frame) + R.tid * (COL_BYTES / 4);
+                p[0] = r | (g << 8) | (b << 16) | (r << 24);
+                p[1] = g | (b << 8) | (r << 16) | (g << 24);
+                p[2] = b | (r << 8) | (g << 16) | (b << 24);
+            }
         }
     }
 };
@@ -354,8 +379,8 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls,
     d.valid = 1;
     d.bg = 0;
     d.sprite = 0;
-    d.sx = (int16_t)(ax - P.sprite_dim / 2);
-    d.sy = (int16_t)(ay - P.sprite_dim / 2);
+    d.sx = (int16_t)(ax - P.sprite_half);
+    d.sy = (int16_t)(ay - P.sprite_half);
     d.alpha = s.alpha;
     d.n_holes = 0;
     d.exit_stamp = 0xFF;
@@ -626,8 +651,8 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     } else {
         d.bg = s.bg_red;
         d.sprite = s.rot8;
-        d.sx = (int16_t)(ax - P.sprite_dim / 2);
-        d.sy = (int16_t)(ay - P.sprite_dim / 2);
+        d.sx = (int16_t)(ax - P.sprite_half);
+        d.sy = (int16_t)(ay - P.sprite_half);
         d.alpha = s.alpha;
         d.n_holes = (uint8_t)nh;
         d.exit_stamp = 0xFF;
@@ -835,7 +860,10 @@ class SpotFamily : public Family {
         int radius = 0;
         std::vector<Stamp> sprites = build_agent_sprites(agent_scale_, &radius);
         P_.agent_radius = radius;
-        P_.sprite_dim = sprites[0].w;
+        {
+            const int full = sprites[0].w;  // blit position of the un-cropped surface: centre - full / 2
+            P_.sprite_half = full / 2 - crop_common_margin(sprites);
+        }
         double inv = 1.0 / std::sqrt(2.0);
         P_.v_axis_i = (int)((1.0 / 1.0) * agent_speed_);
         P_.v_diag_i = (int)(inv * agent_speed_);

@@ -220,6 +220,24 @@ inline std::vector<Stamp> build_agent_sprites(double agent_scale, int* radius_ou
     return out;
 }
 
+// The sprite surfaces are mostly colour key (28x28 for a 12-px body): crop the transparent margin common to all
+// stamps of a set from the four sides; the caller moves the blit position by the returned margin.
+inline int crop_common_margin(std::vector<Stamp>& v) {
+    int m = v.empty() ? 0 : v[0].w;
+    for (const Stamp& s : v)
+        for (int y = 0; y < s.h; ++y)
+            for (int x = 0; x < s.w; ++x)
+                if (s.get(x, y)) m = std::min(m, std::min(std::min(x, y), std::min(s.w - 1 - x, s.h - 1 - y)));
+    if (m <= 0) return 0;
+    for (Stamp& s : v) {
+        Stamp c(s.w - 2 * m, s.h - 2 * m);
+        for (int y = 0; y < c.h; ++y)
+            for (int x = 0; x < c.w; ++x) c.at(x, y) = s.get(x + m, y + m);
+        s = c;
+    }
+    return m;
+}
+
 // 10 glyphs: Command.COMMANDS order right, down, left, up, stay, right_down, right_up, left_down, left_up; 9 = blank.
 inline std::vector<Stamp> build_glyphs(double scale) {
     static const int ANGLE[9] = {0, 270, 180, 90, 0, 315, 45, 225, 135};

@@ -5,10 +5,11 @@
 #include <cstdio>
 #include <random>
 
-#include "mg_atlas.hpp"
-#include "mg_raster.hpp"
+#include "mg_atlas_v1.hpp"
+#include "mg_raster_v1.hpp"
 
 namespace mg {
+using namespace v1;  // the structures compared here are those of raster generation 1 (mg_raster_v1.hpp)
 void set_error(const std::string&) {}
 
 // ---- variant: specialised 3-layer kernel of the first milestone (descriptor instead of display list) ----
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void old_persistent(const OldDesc* __restrict_
 }  // namespace mg
 
 using namespace mg;
+using namespace mg::v1;  // the structures compared here are those of raster generation 1
 
 template <typename F>
 static double time_it(const char* name, int n, F&& launch, int iters = 30) {
