@@ -282,15 +282,15 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, S
     io.sp_oy[k] = c + P.sin_tab[offset % 360] * R;
 }
 
-__device__ void fill_topbar(const SpotParams& P, const SpotCore& s, SpotDesc& d, bool reset_frame, int a0, int a1) {
-    d.c_base = P.endless ? C_BLACK : C_GREY50;
+template <bool EN>
+__device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore& s, SpotDesc& d, bool reset_frame, int a0, int a1) {
+    d.c_base = EN ? C_BLACK : C_GREY50;
     d.red_w = s.red_w;
     d.quarter = (uint8_t)P.quarter;
-    const uint8_t ACT[3] = {C_GREY120, C_PURPLE, C_ACT_ORANGE};
     d.c_act0 = d.c_act1 = 0xFF;
-    if (P.show_last_action) {
-        d.c_act0 = ACT[a0];
-        d.c_act1 = ACT[a1];
+    if (P.show_last_action) {  // 0 -> grey, 1 -> purple, 2 -> orange
+        d.c_act0 = a0 == 0 ? C_GREY120 : (a0 == 1 ? C_PURPLE : C_ACT_ORANGE);
+        d.c_act1 = a1 == 0 ? C_GREY120 : (a1 == 1 ? C_PURPLE : C_ACT_ORANGE);
     }
     d.c_bar = 0xFF;
     d.bar_x = (uint8_t)P.bar_x;
@@ -298,7 +298,10 @@ __device__ void fill_topbar(const SpotParams& P, const SpotCore& s, SpotDesc& d,
     if (!reset_frame && P.show_last_positive_reward) d.c_bar = s.last_pos ? C_YELLOW : C_GREY50;
 }
 
-__device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt) {
+// ENDLESS is a compile-time flag: the endless instantiation has no run-time indexed local arrays (coin lists), so the
+// descriptor and the state stay in registers -- with both variants in one kernel they lived in 176 B of scratch per lane.
+template <bool EN>
+__device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt) {
     s.t = 0;
     s.coin_t = 0;
     s.ep_sum = 0.0;
@@ -335,8 +338,8 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls,
     s.has_coin = 0;
     s.exit_open = 0;
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
-    uint32_t coin_pos[MAX_COINS];
-    if (P.endless) {
+    uint32_t coin_pos[MAX_COINS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EN) {
         if (P.coin_enabled) {  // _spawn_coin: the sampler is reset first, self.coin is None -> nothing blocked
             int cx, cy;
             sample_cell(g, bx, by, br, 0, &cx, &cy);
@@ -351,7 +354,9 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls,
     } else {
         int nc = P.num_coins.n > 0 ? choice(g, P.num_coins) : 0;
         s.num_coins = nc;
-        for (int k = 0; k < nc && k < MAX_COINS; ++k) {
+#pragma unroll
+        for (int k = 0; k < MAX_COINS; ++k) {
+            if (k >= nc) break;
             int cx, cy;
             sample_cell(g, bx, by, br, nb, &cx, &cy);
             bx[nb] = cx; by[nb] = cy; br[nb++] = 21;
@@ -384,22 +389,25 @@ __device__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls,
     d.alpha = s.alpha;
     d.n_holes = 0;
     d.exit_stamp = 0xFF;
-    if (P.endless) {
+    if constexpr (EN) {
         d.n_coins = s.n_coins;
         d.coin_above = (P.coins_visible || s.coin_t < P.coin_show_duration) ? 1 : 0;
         d.coins[0] = (uint32_t)(s.coin_x - P.coin_radius + 128) | ((uint32_t)(s.coin_y - P.coin_radius + 128) << 16);
     } else {
         d.n_coins = s.n_coins;
         d.coin_above = P.coins_visible ? 1 : 0;
-        for (int k = 0; k < s.n_coins; ++k) {
-            int cx = (int)(int16_t)(coin_pos[k] & 0xFFFF), cy = (int)(coin_pos[k] >> 16);
-            d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+#pragma unroll
+        for (int k = 0; k < MAX_COINS; ++k) {
+            if (k < s.n_coins) {
+                int cx = (int)(int16_t)(coin_pos[k] & 0xFFFF), cy = (int)(coin_pos[k] >> 16);
+                d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+            }
         }
         d.exit_stamp = ST_EXIT_CLOSED;
         d.exit_x = (int16_t)(s.exit_x - P.exit_half);
         d.exit_y = (int16_t)(s.exit_y - P.exit_half);
     }
-    fill_topbar(P, s, d, true, 0, 0);
+    fill_topbar<EN>(P, s, d, true, 0, 0);
     if (gt) {
         gt[0] = (float)((double)ax / SCREEN);
         gt[1] = (float)((double)ay / SCREEN);
@@ -416,14 +424,24 @@ __global__ __launch_bounds__(256) void spot_init_kernel(int n, SpotCore* core) {
     core[i] = s;
 }
 
-// the leader stores the descriptor's header + coin positions (first 64 bytes); hole words are written by the slot lanes
+// the leader stores the descriptor's header + coin positions (first 64 bytes); hole words are written by the slot
+// lanes.  Packed field by field (the layout of the bit-fields above) so that `d` never has to exist in memory.
 __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d) {
-    const uint4* src = reinterpret_cast<const uint4*>(&d);
     uint4* out = reinterpret_cast<uint4*>(dst);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = src[k];
+    const uint32_t w0 = (uint32_t)d.valid | ((uint32_t)d.bg << 8) | ((uint32_t)d.sprite << 16) | ((uint32_t)d.alpha << 24);
+    const uint32_t w1 = ((uint32_t)d.sx & 0xFFFFu) | ((uint32_t)d.sy << 16);
+    const uint32_t w2 = (uint32_t)d.n_holes | ((uint32_t)d.n_coins << 8) | ((uint32_t)d.coin_above << 16) | ((uint32_t)d.red_w << 24);
+    const uint32_t w3 = (uint32_t)d.c_base | ((uint32_t)d.c_act0 << 8) | ((uint32_t)d.c_act1 << 16) | ((uint32_t)d.c_bar << 24);
+    const uint32_t w4 = (uint32_t)d.bar_x | ((uint32_t)d.bar_w << 8) | ((uint32_t)d.quarter << 16) | ((uint32_t)d.exit_stamp << 24);
+    const uint32_t w5 = ((uint32_t)d.exit_x & 0xFFFFu) | ((uint32_t)d.exit_y << 16);
+    out[0] = make_uint4(w0, w1, w2, w3);
+    out[1] = make_uint4(w4, w5, 0u, 0u);
+    out[2] = make_uint4(d.coins[0], d.coins[1], d.coins[2], d.coins[3]);
+    out[3] = make_uint4(d.coins[4], d.coins[5], d.coins[6], d.coins[7]);
 }
+static_assert(MAX_COINS == 8, "store_desc_head packs eight coin words");
 
+template <bool EN>
 __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io, const int64_t* seeds, const uint8_t* mask,
                                                          float* gt) {
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     else g.load(io.rng, i);
     SpotCore s = io.core[i];
     SpotDesc d;
-    spot_reset(P, io, i, ls, s, g, d, (gt && P.endless && ls == 0) ? gt + 4 * i : nullptr);
+    spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr);
     if (ls == 0) {
         io.core[i] = s;
         g.store(io.rng, i);
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     }
 }
 
+template <bool EN>
 __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io, const int32_t* actions, float* reward_out,
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,7 +486,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     s.ay = (int16_t)ay;
     // the top bar shows the PREVIOUS action
     int shown0 = s.la0, shown1 = s.la1;
-    if (P.endless || P.show_last_action) {
+    if (EN || P.show_last_action) {
         s.la0 = (uint8_t)a0;
         s.la1 = (uint8_t)a1;
     }
@@ -485,7 +504,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     double reward = 0.0, r = 0.0;
     bool spot_done = false;
     s.spawn_timer++;
-    if (P.endless) {
+    if constexpr (EN) {
         if (s.spawn_timer >= P.spawn_interval) {
             new_spot(P, io, i, ls, s, g);
             s.spawn_timer = 0;
@@ -563,8 +582,8 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     // ---- coin / exit tasks ----
     bool done = false;
     int success = 0;
-    uint32_t coin_pos[MAX_COINS];
-    if (P.endless) {
+    uint32_t coin_pos[MAX_COINS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (EN) {
         if (P.coin_enabled) {
             double cr = 0.0;
             double ddx = (double)ax - (double)s.coin_x, ddy = (double)ay - (double)s.coin_y;
@@ -591,14 +610,19 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         if (s.t == P.max_steps) done = true;
     } else {
         bool coins_done;
+#pragma unroll
         for (int q = 0; q < MAX_COINS; ++q) coin_pos[q] = q < s.n_coins ? coins[q] : 0u;
         if (s.num_coins > 0) {
             double cr = 0.0;
-            for (int q = 0; q < s.n_coins; ++q) {  // remove-while-iterating: the coin after a collected one is skipped
+#pragma unroll
+            for (int q = 0; q < MAX_COINS; ++q) {  // remove-while-iterating: the coin after a collected one is skipped
+                if (q >= s.n_coins) break;
                 int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
                 double ddx = (double)ax - cx, ddy = (double)ay - cy;
                 if (sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius)) {
-                    for (int j = q; j < s.n_coins - 1; ++j) coin_pos[j] = coin_pos[j + 1];
+#pragma unroll
+                    for (int j = q; j < MAX_COINS - 1; ++j)
+                        if (j < s.n_coins - 1) coin_pos[j] = coin_pos[j + 1];
                     s.n_coins--;
                     cr += P.r_coin;
                     s.coins_collected++;
@@ -634,7 +658,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         if (info.ep_reward_dev) info.ep_reward_dev[i] = s.ep_sum;
         if (info.ep_length_dev) info.ep_length_dev[i] = s.ep_len;
         if (info.aux_dev[0]) info.aux_dev[0][i] = (float)(s.health / P.agent_health);
-        if (P.endless) {
+        if constexpr (EN) {
             if (info.aux_dev[1]) info.aux_dev[1][i] = (float)s.coins_collected;
         } else {
             if (info.aux_dev[1]) info.aux_dev[1][i] = (float)((double)s.coins_collected / (double)s.num_coins);
@@ -647,7 +671,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     }
 
     if (done && autoreset) {
-        spot_reset(P, io, i, ls, s, g, d, (gt && P.endless && leader) ? gt + 4 * i : nullptr);
+        spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr);
     } else {
         d.bg = s.bg_red;
         d.sprite = s.rot8;
@@ -656,17 +680,20 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         d.alpha = s.alpha;
         d.n_holes = (uint8_t)nh;
         d.exit_stamp = 0xFF;
-        if (P.endless) {
+        if constexpr (EN) {
             d.n_coins = P.coin_enabled ? 1 : 0;
             d.coin_above = (P.coins_visible || s.coin_t < P.coin_show_duration) ? 1 : 0;
             d.coins[0] = (uint32_t)(s.coin_x - P.coin_radius + 128) | ((uint32_t)(s.coin_y - P.coin_radius + 128) << 16);
         } else {
             d.n_coins = s.n_coins;
             d.coin_above = P.coins_visible ? 1 : 0;
-            for (int q = 0; q < s.n_coins; ++q) {
-                int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
-                d.coins[q] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
-                if (leader) coins[q] = coin_pos[q];
+#pragma unroll
+            for (int q = 0; q < MAX_COINS; ++q) {
+                if (q < s.n_coins) {
+                    int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
+                    d.coins[q] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
+                    if (leader) coins[q] = coin_pos[q];
+                }
             }
             d.exit_stamp = s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED;
             d.exit_x = (int16_t)(s.exit_x - P.exit_half);
@@ -674,8 +701,8 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         }
         SpotCore tb = s;
         tb.last_pos = shown_last_pos;  // the bar shows whether the PREVIOUS reward was positive
-        fill_topbar(P, tb, d, false, shown0, shown1);
-        if (gt && P.endless && leader) {
+        fill_topbar<EN>(P, tb, d, false, shown0, shown1);
+        if (gt && EN && leader) {
             gt[4 * i + 0] = (float)((double)ax / SCREEN);
             gt[4 * i + 1] = (float)((double)ay / SCREEN);
             gt[4 * i + 2] = (float)(P.coin_enabled ? (double)s.coin_x / SCREEN : 0.0);
@@ -809,7 +836,8 @@ class SpotFamily : public Family {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;
-        hipLaunchKernelGGL(spot_reset_kernel, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        if (P_.endless) hipLaunchKernelGGL(spot_reset_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        else hipLaunchKernelGGL(spot_reset_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
         raster(obs, s);
     }
 
@@ -820,7 +848,8 @@ class SpotFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        hipLaunchKernelGGL(spot_step_kernel, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
         prof.end(0, s);
         prof.begin(1, s);
         raster(obs, s);
