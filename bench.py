@@ -30,7 +30,7 @@ FRAME = 84 * 84 * 3
 RASTER_BYTES = {"default": FRAME + 16}
 STEP_BYTES = {"MortarMayhem-Grid-v0": 21305, "MortarMayhem-v0": 21309, "Endless-MortarMayhem-v0": 21821,
               "MysteryPath-v0": 21437, "Endless-SearingSpotlights-v0": 22205}
-DEFAULT_ENVS = {"MortarMayhem-Grid-v0": 65536, "MortarMayhem-v0": 65536, "Endless-MortarMayhem-v0": 32768,
+DEFAULT_ENVS = {"MortarMayhem-Grid-v0": 65536, "MortarMayhem-v0": 65536, "MortarMayhemB-Grid-v0": 65536, "MortarMayhemB-v0": 65536, "Endless-MortarMayhem-v0": 32768,
                 "MysteryPath-v0": 32768, "MysteryPath-Grid-v0": 32768, "Endless-MysteryPath-v0": 32768, "SearingSpotlights-v0": 16384,
                 "Endless-SearingSpotlights-v0": 16384}
 

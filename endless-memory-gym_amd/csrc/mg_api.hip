@@ -53,6 +53,8 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
         if (id == "MortarMayhem-Grid-v0") fam = mg::make_mortar(0, num_envs);
         else if (id == "MortarMayhem-v0") fam = mg::make_mortar(1, num_envs);
         else if (id == "Endless-MortarMayhem-v0") fam = mg::make_mortar(2, num_envs);
+        else if (id == "MortarMayhemB-Grid-v0") fam = mg::make_mortar(3, num_envs);
+        else if (id == "MortarMayhemB-v0") fam = mg::make_mortar(4, num_envs);
         else if (id == "Endless-SearingSpotlights-v0") fam = mg::make_spot(1, num_envs);
         else if (id == "SearingSpotlights-v0") fam = mg::make_spot(0, num_envs);
         else if (id == "MysteryPath-v0") fam = mg::make_mystery(0, num_envs);
@@ -85,6 +87,13 @@ void mg_destroy(mg_env* env) {
 int32_t mg_num_envs(const mg_env* env) { return env ? env->num_envs : 0; }
 int32_t mg_action_dim(const mg_env* env) { return env ? env->fam->action_dim() : 0; }
 int32_t mg_gt_dim(const mg_env* env) { return env ? env->fam->gt_dim() : 0; }
+int32_t mg_vec_dim(const mg_env* env) { return env ? env->fam->vec_dim() : 0; }
+int mg_bind_vector_obs(mg_env* env, float* vec_dev) {
+    return guarded(env, [&] {
+        if (env->fam->vec_dim() == 0 && vec_dev) throw std::runtime_error("mg_bind_vector_obs: this env id has no vector observation");
+        env->fam->bind_vector_obs(vec_dev);
+    });
+}
 const char* mg_info_name(const mg_env* env, int k) { return env ? env->fam->info_name(k) : nullptr; }
 
 int mg_set_option(mg_env* env, const char* key, const double* values, int n) {

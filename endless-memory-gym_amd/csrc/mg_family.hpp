@@ -97,6 +97,8 @@ class Family {
     virtual ~Family() {}
     virtual int action_dim() const = 0;
     virtual int gt_dim() const = 0;
+    virtual int vec_dim() const { return 0; }          // size of obs["vector_observation"] (MortarMayhemB*), else 0
+    virtual void bind_vector_obs(float* /*dev*/) {}    // caller buffer [num_envs][vec_dim], written at every reset
     virtual const char* info_name(int k) const = 0;
     virtual void set_option(const std::string& key, const double* v, int n) = 0;  // throws OptionError
     virtual void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) = 0;

@@ -28,6 +28,7 @@ enum { V_GRID = 0, V_FREE = 1, V_ENDLESS = 2 };
 
 struct MortarParams {
     int variant, N, allowed, visual_feedback, max_steps, initial_count;
+    int taskb;                   // MortarMayhemB*: no display phase, spawn offset for the free controller, vector obs
     int cmd_cap;                 // per-instance command list capacity
     int arena_x0, tile;          // arena top-left (x == y) and tile size in px
     int radius, sprite_dim;      // agent radius, sprite box
@@ -98,7 +99,11 @@ __device__ __forceinline__ int mod6(int a) { return ((a % 6) + 6) % 6; }
 __device__ __forceinline__ int round_haz(double v) { return v >= 0 ? (int)floor(v + 0.5) : -(int)floor(-v + 0.5); }
 
 // Env.reset body (RNG draw order: spawn tile, [offset x2], [command_count], commands, show dur/delay, explosion dur/delay)
-__device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint8_t* cmds, MortarDesc& d, float* gt) {
+// _encode_commands_one_hot (mortar_mayhem_b_grid.py:100-129): slot of a Command.COMMANDS id inside its block of 9
+__constant__ int8_t kCmdOneHot[9] = {1, 4, 2, 3, 0, 5, 6, 7, 8};
+constexpr int VEC_DIM = 180;  // max_num_commands (20) * 9
+
+__device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint8_t* cmds, MortarDesc& d, float* gt, float* vec) {
     // the frame keeps showing the previous agent's rect until the first execution step (Endless only can observe it)
     if (s.disp_sprite != 0xFF && s.disp_is_agent) {
         s.disp_x = s.ax;
@@ -109,7 +114,7 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
     int tile_id = g.integers(0, P.N * P.N);
     int cx = P.arena_x0 + P.tile * (tile_id / P.N) + half;
     int cy = P.arena_x0 + P.tile * (tile_id % P.N) + half;
-    if (P.variant == V_ENDLESS) {
+    if (P.variant == V_ENDLESS || (P.taskb && P.variant == V_FREE)) {  // mortar_mayhem_b.py:167
         cx += g.integers(P.off_lo, P.off_hi);
         cy += g.integers(P.off_lo, P.off_hi);
     }
@@ -143,8 +148,12 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
         }
     }
     s.num_cmds = (uint16_t)n;
-    s.show_dur = (uint8_t)choice(g, P.show_dur);
-    s.show_delay = (uint8_t)choice(g, P.show_delay);
+    if (P.taskb) {  // mortar_mayhem_b_grid.py:172 `_command_visualization = None`: nothing is drawn (no draws either)
+        s.show_dur = s.show_delay = 0;
+    } else {
+        s.show_dur = (uint8_t)choice(g, P.show_dur);
+        s.show_delay = (uint8_t)choice(g, P.show_delay);
+    }
     s.vis_len = (uint16_t)(n * (s.show_dur + s.show_delay));
     s.vis_base = 0;
     s.vis_pos = 1;  // reset pops the first entry for its own frame
@@ -178,6 +187,10 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
         gt[0] = (float)(s.tx / 5.0);
         gt[1] = (float)(s.ty / 5.0);
     }
+    if (vec) {  // obs["vector_observation"]: constant over the episode, written once per reset
+        for (int k = 0; k < VEC_DIM; ++k) vec[k] = 0.0f;
+        for (int c = 0; c < n && c < VEC_DIM / 9; ++c) vec[9 * c + kCmdOneHot[cmds[c]]] = 1.0f;
+    }
 }
 
 struct MortarIO {
@@ -185,6 +198,7 @@ struct MortarIO {
     uint8_t* cmds;
     RngSoA rng;
     MortarDesc* desc;
+    float* vec;  // [N][180] caller buffer bound with mg_bind_vector_obs (MortarMayhemB*), or NULL
 };
 
 __global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P, int n, MortarIO io, const int64_t* seeds,
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P, int n
     if (seeds) g.seed((uint64_t)seeds[i]);
     else g.load(io.rng, i);
     MortarState s = io.state[i];
-    mortar_reset(P, s, g, io.cmds + (size_t)i * P.cmd_cap, d, gt ? gt + 2 * i : nullptr);
+    mortar_reset(P, s, g, io.cmds + (size_t)i * P.cmd_cap, d, gt ? gt + 2 * i : nullptr, io.vec ? io.vec + (size_t)i * VEC_DIM : nullptr);
     io.state[i] = s;
     g.store(io.rng, i);
     io.desc[i] = d;
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     if (done && autoreset) {
         if (!rng_loaded) g.load(io.rng, i);
         rng_loaded = true;
-        mortar_reset(P, s, g, cmds, d, (gt && P.variant == V_ENDLESS) ? gt + 2 * i : nullptr);
+        mortar_reset(P, s, g, cmds, d, (gt && P.variant == V_ENDLESS) ? gt + 2 * i : nullptr, io.vec ? io.vec + (size_t)i * VEC_DIM : nullptr);
     } else {
         int cx = s.disp_is_agent ? s.ax : s.disp_x, cy = s.disp_is_agent ? s.ay : s.disp_y;
         d.sx = (int16_t)(cx - P.sprite_dim / 2);
@@ -428,9 +442,12 @@ static const double SCALE = 0.25;  // the reference's module constant (e.g. mort
 
 class MortarFamily : public Family {
    public:
-    MortarFamily(int variant, int n) : n_(n) {
+    // variant 3 / 4 = MortarMayhemB-Grid-v0 / MortarMayhemB-v0: the Grid / free machine with taskb set
+    MortarFamily(int variant_id, int n) : n_(n) {
         memset(&P_, 0, sizeof(P_));
+        const int variant = variant_id >= 3 ? variant_id - 3 : variant_id;
         P_.variant = variant;
+        P_.taskb = variant_id >= 3;
         agent_scale_ = 1.0 * SCALE;
         agent_speed_ = 12.0 * SCALE;
         P_.N = variant == V_ENDLESS ? 6 : 5;
@@ -459,6 +476,8 @@ class MortarFamily : public Family {
 
     int action_dim() const override { return P_.variant == V_GRID ? 1 : 2; }
     int gt_dim() const override { return P_.variant == V_ENDLESS ? 2 : 0; }
+    int vec_dim() const override { return P_.taskb ? VEC_DIM : 0; }
+    void bind_vector_obs(float* dev) override { vec_ = dev; }
     const char* info_name(int k) const override {
         if (P_.variant == V_ENDLESS) return k == 0 ? "commands_completed" : (k == 1 ? "max_command_sequence" : nullptr);
         return k == 0 ? "success" : (k == 1 ? "commands_completed" : nullptr);
@@ -482,8 +501,8 @@ class MortarFamily : public Family {
             if (a < 4 || a > 9) throw OptionError{-4, "assert 4 <= allowed_commands <= 9"};
             P_.allowed = a;
         }
-        else if (key == "command_show_duration") list(P_.show_dur, 1, 100);
-        else if (key == "command_show_delay") list(P_.show_delay, 0, 100);
+        else if (!P_.taskb && key == "command_show_duration") list(P_.show_dur, 1, 100);
+        else if (!P_.taskb && key == "command_show_delay") list(P_.show_delay, 0, 100);
         else if (key == "explosion_duration") list(P_.expl_dur, 1, 200);
         else if (key == "explosion_delay") list(P_.expl_delay, 1, 200);
         else if (key == "visual_feedback") P_.visual_feedback = v[0] != 0.0;
@@ -502,7 +521,7 @@ class MortarFamily : public Family {
             P_.N = a;
             dirty_ = true;
         }
-        else if (!endless && key == "command_count") list(P_.command_count, 1, P_.cmd_cap);
+        else if (!endless && key == "command_count") list(P_.command_count, 1, P_.taskb ? VEC_DIM / 9 : P_.cmd_cap);
         else if (!endless && key == "reward_episode_success") P_.r_ep_succ = v[0];
         else if (P_.variant != V_GRID && key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
         else throw OptionError{-2, "unknown reset parameter " + key};
@@ -551,6 +570,7 @@ class MortarFamily : public Family {
         o.cmds = cmds_.p;
         o.rng = rng_.view();
         o.desc = desc_.p;
+        o.vec = vec_;
         return o;
     }
 
@@ -590,6 +610,7 @@ class MortarFamily : public Family {
     std::unique_ptr<Atlas> atlas_;
     double agent_scale_, agent_speed_;
     bool dirty_ = true, seeded_ = false;
+    float* vec_ = nullptr;
     DevArray<MortarState> state_;
     DevArray<uint8_t> cmds_;
     DevArray<MortarDesc> desc_;

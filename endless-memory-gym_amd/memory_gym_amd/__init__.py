@@ -12,12 +12,9 @@ single-instance adapter), mirroring the reference's registration side effect on 
 from .reset_params import DEFAULTS, process_reset_params  # noqa: F401
 from .vec_env import ENV_IDS, MemoryGymEnv, VecMemoryGym  # noqa: F401
 
-NOT_IN_SCOPE = ["MortarMayhemB-v0", "MortarMayhemB-Grid-v0"]
 
 
 def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc"):
-    if env_id in NOT_IN_SCOPE:
-        raise NotImplementedError(env_id + " is outside the accelerated hot path (see DESIGN.md)")
     if num_envs is None:
         return MemoryGymEnv(env_id, device=device, render_mode=render_mode)
     return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode, obs_format=obs_format)

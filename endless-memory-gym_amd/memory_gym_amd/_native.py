@@ -36,6 +36,9 @@ def _load():
     L.mg_info_name.argtypes = [C.c_void_p, C.c_int]
     L.mg_info_name.restype = C.c_char_p
     L.mg_set_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]
+    L.mg_vec_dim.argtypes = [C.c_void_p]
+    L.mg_vec_dim.restype = C.c_int32
+    L.mg_bind_vector_obs.argtypes = [C.c_void_p, C.c_void_p]
     L.mg_set_obs_format.argtypes = [C.c_void_p, C.c_int]
     L.mg_obs_bytes.argtypes = [C.c_void_p]
     L.mg_obs_bytes.restype = C.c_size_t

@@ -3,6 +3,8 @@
   MortarMayhem-Grid-v0          memory_gym/mortar_mayhem_grid.py:21-53
   MortarMayhem-v0               memory_gym/mortar_mayhem.py:21-54
   Endless-MortarMayhem-v0       memory_gym/endless_mortar_mayhem.py:21-53
+  MortarMayhemB-Grid-v0         memory_gym/mortar_mayhem_b_grid.py:21-53
+  MortarMayhemB-v0              memory_gym/mortar_mayhem_b.py:21-54
   MysteryPath-v0                memory_gym/mystery_path.py:21-50
   MysteryPath-Grid-v0           memory_gym/mystery_path_grid.py:21-49
   Endless-MysteryPath-v0        memory_gym/endless_mystery_path.py:22-54
@@ -32,6 +34,16 @@ DEFAULTS = {
         "initial_command_count": 1, "command_show_duration": [3], "command_show_delay": [1],
         "explosion_duration": [6], "explosion_delay": [18], "visual_feedback": True, "reward_command_failure": 0.0,
         "reward_command_success": 0.1, "reward_new_command_success": 0.0,
+    },
+    "MortarMayhemB-Grid-v0": {
+        "agent_scale": 1.0 * SCALE, "arena_size": 5, "allowed_commands": 5, "command_count": [10],
+        "explosion_duration": [2], "explosion_delay": [6], "visual_feedback": True, "reward_command_failure": 0.0,
+        "reward_command_success": 0.1, "reward_episode_success": 0.0,
+    },
+    "MortarMayhemB-v0": {
+        "agent_scale": 1.0 * SCALE, "agent_speed": 12.0 * SCALE, "arena_size": 5, "allowed_commands": 9,
+        "command_count": [10], "explosion_duration": [6], "explosion_delay": [18], "visual_feedback": True,
+        "reward_command_failure": 0.0, "reward_command_success": 0.1, "reward_episode_success": 0.0,
     },
     "MysteryPath-v0": {
         "max_steps": 512, "agent_scale": 1.0 * SCALE, "agent_speed": 12.0 * SCALE,
@@ -84,6 +96,8 @@ def process_reset_params(env_id, reset_params):
         assert cloned["allowed_commands"] >= 4 and cloned["allowed_commands"] <= 9
     if "arena_size" in cloned:
         assert cloned["arena_size"] >= 2 and cloned["arena_size"] <= 6
+    if env_id.startswith("MortarMayhemB"):  # mortar_mayhem_b_grid.py:52
+        assert max(cloned["command_count"]) <= 20, "20 commands are allowed at maximum"
     return cloned
 
 

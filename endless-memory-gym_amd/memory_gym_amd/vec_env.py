@@ -33,16 +33,23 @@ class _Space:
         return "%s(%s)" % (self.kind, ", ".join("%s=%r" % kv for kv in self.__dict__.items() if kv[0] != "kind"))
 
 
-def _spaces(action_dim, gt_dim):
+def _spaces(action_dim, gt_dim, vec_dim=0):
     try:  # use real gymnasium spaces when the host has them
         from gymnasium import spaces
         act = spaces.Discrete(4) if action_dim == 1 else spaces.MultiDiscrete([3, 3])
         obs = spaces.Box(low=0, high=255, shape=[84, 84, 3], dtype=np.uint8)
+        if vec_dim:  # MortarMayhemB*: mortar_mayhem_b_grid.py:83-96
+            obs = spaces.Dict({"visual_observation": obs,
+                               "vector_observation": spaces.Box(low=np.zeros(vec_dim, np.float32), high=np.ones(vec_dim, np.float32),
+                                                                shape=(vec_dim,), dtype=np.float32)})
         gt = None if gt_dim == 0 else spaces.Box(low=np.zeros(gt_dim, np.float32), high=np.ones(gt_dim, np.float32),
                                                   shape=(gt_dim,), dtype=np.float32)
     except Exception:
         act = _Space("Discrete", n=4) if action_dim == 1 else _Space("MultiDiscrete", nvec=[3, 3])
         obs = _Space("Box", low=0, high=255, shape=[84, 84, 3], dtype=np.uint8)
+        if vec_dim:
+            obs = _Space("Dict", spaces={"visual_observation": obs, "vector_observation": _Space(
+                "Box", low=0.0, high=1.0, shape=(vec_dim,), dtype=np.float32)})
         gt = None if gt_dim == 0 else _Space("Box", low=0.0, high=1.0, shape=(gt_dim,), dtype=np.float32)
     return act, obs, gt
 
@@ -70,8 +77,9 @@ class VecMemoryGym:
         self._h = h
         self.action_dim = _native.LIB.mg_action_dim(h)
         self.gt_dim = _native.LIB.mg_gt_dim(h)
+        self.vec_dim = _native.LIB.mg_vec_dim(h)
         self.has_ground_truth_info = self.gt_dim > 0
-        self.action_space, self.observation_space, self.ground_truth_space = _spaces(self.action_dim, self.gt_dim)
+        self.action_space, self.observation_space, self.ground_truth_space = _spaces(self.action_dim, self.gt_dim, self.vec_dim)
         N, dev = self.num_envs, self.device
         # "u8_xyc" is the reference's observation; "f32_chw"/"f16_chw" are obs/255 in [c][y][x] order, converted inside
         # the raster kernel's stream-out (what a trainer would otherwise compute from the uint8 frame every step)
@@ -80,6 +88,11 @@ class VecMemoryGym:
         _native.check(_native.LIB.mg_set_obs_format(h, code), "mg_set_obs_format")
         assert _native.LIB.mg_obs_bytes(h) == 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
         self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
+        # MortarMayhemB*: obs is the reference's Dict; `vector_obs` is written by the library whenever an instance resets
+        self.vector_obs = None
+        if self.vec_dim:
+            self.vector_obs = torch.zeros((N, self.vec_dim), dtype=torch.float32, device=dev)
+            _native.check(_native.LIB.mg_bind_vector_obs(h, self.vector_obs.data_ptr()), "mg_bind_vector_obs")
         self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
         self.done_u8 = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.gt = torch.zeros((N, max(self.gt_dim, 1)), dtype=torch.float32, device=dev)
@@ -123,7 +136,10 @@ class VecMemoryGym:
                 raise NotImplementedError("reset parameter %s=%r: %s" % (k, v, _native.last_error()))
             self._applied[k] = v
         self.reset_params = params
-        if self.env_id in ("MortarMayhem-Grid-v0", "MortarMayhem-v0"):
+        if self.env_id in ("MortarMayhemB-Grid-v0", "MortarMayhemB-v0"):  # mortar_mayhem_b_grid.py:149-153
+            self.max_episode_steps = calc_max_episode_steps(
+                max(params["command_count"]), 0, 0, max(params["explosion_delay"]), max(params["explosion_duration"]))
+        elif self.env_id in ("MortarMayhem-Grid-v0", "MortarMayhem-v0"):
             self.max_episode_steps = calc_max_episode_steps(
                 max(params["command_count"]), max(params["command_show_duration"]), max(params["command_show_delay"]),
                 max(params["explosion_delay"]), max(params["explosion_duration"]))
@@ -154,7 +170,7 @@ class VecMemoryGym:
                                                None if m is None else m.data_ptr(), self.obs.data_ptr(),
                                                self.gt.data_ptr() if self.gt_dim else None, self._stream()), "mg_reset")
         info = {"ground_truth": self.gt} if self.gt_dim else {}
-        return self.obs, info
+        return self._obs(), info
 
     def step(self, actions):
         with torch.cuda.device(self.device):
@@ -170,7 +186,12 @@ class VecMemoryGym:
             info[nm] = t
         if self.gt_dim:
             info["ground_truth"] = self.gt
-        return self.obs, self.reward, done, self._truncated, info
+        return self._obs(), self.reward, done, self._truncated, info
+
+    def _obs(self):
+        if self.vector_obs is None:
+            return self.obs
+        return {"visual_observation": self.obs, "vector_observation": self.vector_obs}
 
     def render(self):
         """rgb_array mode of the reference: fliplr(rot90(obs, 3)) == transpose to [y][x][c] (mortar_mayhem_grid.py:401-402)."""
@@ -241,12 +262,18 @@ class MemoryGymEnv:
     def max_episode_steps(self):
         return self.vec.max_episode_steps
 
+    @staticmethod
+    def _first(obs):
+        if isinstance(obs, dict):  # MortarMayhemB*: the reference's Dict observation
+            return {k: v[0].cpu().numpy() for k, v in obs.items()}
+        return obs[0].cpu().numpy()
+
     def reset(self, seed=None, return_info=True, options=None):
         obs, info = self.vec.reset(seed=seed, options=options)
         out = {}
         if "ground_truth" in info:
             out["ground_truth"] = info["ground_truth"][0].double().cpu().numpy()
-        return obs[0].cpu().numpy(), out
+        return self._first(obs), out
 
     def step(self, action):
         a = np.atleast_1d(np.asarray(action)).reshape(1, -1)
@@ -260,7 +287,7 @@ class MemoryGymEnv:
                 out[nm] = float(info[nm][0].item())
         if "ground_truth" in info:
             out["ground_truth"] = info["ground_truth"][0].double().cpu().numpy()
-        return obs[0].cpu().numpy(), float(reward[0].item()), d, False, out
+        return self._first(obs), float(reward[0].item()), d, False, out
 
     def render(self):
         return self.vec.render()[0].cpu().numpy()

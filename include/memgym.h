@@ -52,6 +52,13 @@ const char* mg_last_error(void);
 int32_t mg_num_envs(const mg_env* env);
 int32_t mg_action_dim(const mg_env* env);
 int32_t mg_gt_dim(const mg_env* env);
+/* MortarMayhemB-Grid-v0 / MortarMayhemB-v0 return a Dict observation (mortar_mayhem_b_grid.py:83-96):
+ * "visual_observation" is the usual frame, "vector_observation" the one-hot command list float32[20 * 9]
+ * (_encode_commands_one_hot :100-129).  mg_vec_dim: 180 for those ids, else 0.  mg_bind_vector_obs registers the
+ * caller's device buffer float32 [num_envs][mg_vec_dim]; the library writes row i whenever instance i is reset
+ * (mg_reset and same-step auto-reset) -- the vector is constant within an episode.  NULL unbinds. */
+int32_t mg_vec_dim(const mg_env* env);
+int mg_bind_vector_obs(mg_env* env, float* vec_dev);
 /* name of aux slot k of mg_info_buffers for this env id, or NULL */
 const char* mg_info_name(const mg_env* env, int k);
 

@@ -20,6 +20,8 @@ mgo_env* mgo_create(const char* env_id, double scale) {
     if (!strcmp(env_id, "MortarMayhem-Grid-v0")) rc = mgo_mortar_create(e, 0);
     else if (!strcmp(env_id, "MortarMayhem-v0")) rc = mgo_mortar_create(e, 1);
     else if (!strcmp(env_id, "Endless-MortarMayhem-v0")) rc = mgo_mortar_create(e, 2);
+    else if (!strcmp(env_id, "MortarMayhemB-Grid-v0")) rc = mgo_mortar_create(e, 3);
+    else if (!strcmp(env_id, "MortarMayhemB-v0")) rc = mgo_mortar_create(e, 4);
     else if (!strcmp(env_id, "MysteryPath-v0")) rc = mgo_mystery_create(e, 0);
     else if (!strcmp(env_id, "Endless-MysteryPath-v0")) rc = mgo_mystery_create(e, 1);
     else if (!strcmp(env_id, "MysteryPath-Grid-v0")) rc = mgo_mystery_create(e, 2);

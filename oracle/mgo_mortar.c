@@ -4,13 +4,19 @@
  *   MortarMayhem-Grid-v0     memory_gym/mortar_mayhem_grid.py   reset :213-278  step :280-375
  *   MortarMayhem-v0          memory_gym/mortar_mayhem.py        reset :206-272  step :274-369
  *   Endless-MortarMayhem-v0  memory_gym/endless_mortar_mayhem.py reset :194-259 step :261-373
+ *   MortarMayhemB-Grid-v0    memory_gym/mortar_mayhem_b_grid.py reset :131-196  step :198-285  (no display phase; the
+ *   MortarMayhemB-v0         memory_gym/mortar_mayhem_b.py      reset :132-198  step :200-287   commands are a vector obs)
  * plus Command / MortarTile / MortarArena / calc_max_episode_steps (memory_gym/pygame_assets.py:241-436).
  * Pinned by tests/golden/logic_{MortarMayhem_Grid_v0,MortarMayhem_v0,Endless_MortarMayhem_v0}.npz
  * (logic, captured from the reference) and docs/assets/emm_0.gif (pixels, SCALE 1.0).
  */
 #include "mgo_env.h"
 
-enum { MM_GRID = 0, MM_FREE = 1, MM_ENDLESS = 2 };
+enum { MM_GRID = 0, MM_FREE = 1, MM_ENDLESS = 2, MM_B_GRID = 3, MM_B_FREE = 4 };
+#define MM_IS_B(v) ((v) == MM_B_GRID || (v) == MM_B_FREE)
+#define MM_IS_GRID(v) ((v) == MM_GRID || (v) == MM_B_GRID)
+/* _encode_commands_one_hot (mortar_mayhem_b_grid.py:100-129): slot of each Command.COMMANDS id inside a block of 9 */
+static const int CMD_ONE_HOT[9] = {1, 4, 2, 3, 0, 5, 6, 7, 8};
 #define MM_MAXLIST 8
 
 static const int CMD_DX[9] = {1, 0, -1, 0, 0, 1, 1, -1, -1}; /* Command.COMMANDS (pygame_assets.py:242-252) */
@@ -182,6 +188,7 @@ static void mm_reset(mgo_env* e) {
          * (mortar_mayhem_grid.py:229-233 -> pygame_assets.py:420-436) */
         int cc = (int)mm_max(m->command_count, m->n_command_count);
         int sd = (int)mm_max(m->show_duration, m->n_show_duration), sl = (int)mm_max(m->show_delay, m->n_show_delay);
+        if (MM_IS_B(m->variant)) sd = sl = 0; /* calc_max_episode_steps(cc, 0, 0, ...) (mortar_mayhem_b_grid.py:149-153) */
         int exec_duration = (int)mm_max(m->explosion_delay, m->n_explosion_delay);
         int exec_delay = (int)mm_max(m->explosion_duration, m->n_explosion_duration);
         int clue = (sd + sl) * cc, act = (exec_duration + exec_delay) * cc;
@@ -214,7 +221,7 @@ static void mm_reset(mgo_env* e) {
 
     double translate_x = mgo_rect_cx(&m->arena_rect) - m->local_cx + floor(m->tile_dim / 2);
     double translate_y = mgo_rect_cy(&m->arena_rect) - m->local_cy + floor(m->tile_dim / 2);
-    if (m->variant == MM_GRID) {
+    if (MM_IS_GRID(m->variant)) {
         int tile = (int)mgo_integers(&e->rng, 0, (int64_t)m->N * m->N);
         double sx = m->tile_dim * (tile / m->N), sy = m->tile_dim * (tile % m->N);
         double ax = sx + translate_x, ay = sy + translate_y;
@@ -266,10 +273,15 @@ static void mm_reset(mgo_env* e) {
             sy += CMD_DY[c];
         }
     }
-    m->show_dur = (int)mm_choice(e, m->show_duration, m->n_show_duration);
-    m->show_delay_v = (int)mm_choice(e, m->show_delay, m->n_show_delay);
-    mm_gen_vis(m, m->cmds, m->num_commands, m->show_dur, m->show_delay_v);
-    int glyph = mm_vis_pop(m);
+    int glyph = -1;
+    if (MM_IS_B(m->variant)) {
+        mm_vis_clear(m); /* _command_visualization = None: every command is observable through the vector obs */
+    } else {
+        m->show_dur = (int)mm_choice(e, m->show_duration, m->n_show_duration);
+        m->show_delay_v = (int)mm_choice(e, m->show_delay, m->n_show_delay);
+        mm_gen_vis(m, m->cmds, m->num_commands, m->show_dur, m->show_delay_v);
+        glyph = mm_vis_pop(m);
+    }
 
     if (m->variant == MM_ENDLESS) {
         m->tx = ((m->norm_x + CMD_DX[m->cmds[0]]) % 6 + 6) % 6;
@@ -307,9 +319,9 @@ static void mm_step(mgo_env* e, const int action[2]) {
             mm_set_disp(m, 0, 1); /* get_rotated_sprite(0) every display step (:297) */
         }
     } else {
-        if (m->variant == MM_GRID) {
+        if (MM_IS_GRID(m->variant)) {
             mgo_agent_step_grid(&m->agent, action[0]);
-        } else if (m->variant == MM_FREE) {
+        } else if (m->variant == MM_FREE || m->variant == MM_B_FREE) {
             mgo_agent_step(&m->agent, action, &m->arena_rect);
         } else {
             mgo_agent_step_wrap(&m->agent, action, &m->arena_rect);
@@ -424,7 +436,7 @@ static int mm_set_option(mgo_env* e, const char* k, const double* v, int n) {
         ISCALAR("arena_size", arena_size)
         LIST("command_count", command_count)
         SCALAR("reward_episode_success", reward_episode_success)
-        if (m->variant == MM_FREE) SCALAR("agent_speed", agent_speed)
+        if (m->variant == MM_FREE || m->variant == MM_B_FREE) SCALAR("agent_speed", agent_speed)
     }
 #undef SCALAR
 #undef ISCALAR
@@ -464,6 +476,12 @@ static int mm_get_list(mgo_env* e, const char* name, double* out, int cap) {
         for (int i = 0; i < n; i++) out[i] = m->cmds[i];
         return m->num_commands;
     }
+    if (!strcmp(name, "vec") && MM_IS_B(m->variant)) { /* obs["vector_observation"], float32[20 * 9] */
+        for (int i = 0; i < 180 && i < cap; i++) out[i] = 0.0;
+        for (int c = 0; c < m->num_commands && c < 20; c++)
+            if (9 * c + CMD_ONE_HOT[m->cmds[c]] < cap) out[9 * c + CMD_ONE_HOT[m->cmds[c]]] = 1.0;
+        return 180;
+    }
     return -1;
 }
 
@@ -478,10 +496,12 @@ static void mm_destroy(mgo_env* e) {
     free(m);
 }
 
-static const mgo_vtbl MM_VT[3] = {
+static const mgo_vtbl MM_VT[5] = {
     {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
     {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
     {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
+    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
+    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
 };
 
 int mgo_mortar_create(mgo_env* e, int variant) {
@@ -498,7 +518,7 @@ int mgo_mortar_create(mgo_env* e, int variant) {
     m->visual_feedback = 1;
     m->reward_command_failure = 0.0;
     m->reward_command_success = 0.1;
-    if (variant == MM_GRID) {
+    if (MM_IS_GRID(variant)) {
         m->arena_size = 5; m->allowed_commands = 5;
         m->command_count[0] = 10; m->n_command_count = 1;
         m->explosion_duration[0] = 2; m->n_explosion_duration = 1;

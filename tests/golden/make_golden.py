@@ -98,7 +98,7 @@ def snap_mm(env, info):
              disp_sprite=si, disp_x=dx, disp_y=dy, glyph=glyph_id(),
              cur_cmd=env._current_command, cmd_steps=env._command_steps, verify_step=env._command_verify_step,
              tiles_on=int(env.arena.tiles_on), tx=env._target_pos[0], ty=env._target_pos[1],
-             vis_len=len(env._command_visualization), num_commands=env.num_commands,
+             vis_len=len(env._command_visualization or []), num_commands=env.num_commands,
              nx=env.normalized_agent_position[0], ny=env.normalized_agent_position[1],
              expl_dur=env._explosion_duration, expl_delay=env._explosion_delay,
              max_episode_steps=env.max_episode_steps)
@@ -112,6 +112,8 @@ def snap_mm(env, info):
     if "ground_truth" in info:
         d["gt0"], d["gt1"] = [float(v) for v in info["ground_truth"]]
     lists = dict(cmds=[CMD_IDS[c] for c in env._commands])
+    if hasattr(env, "_commands_one_hot"):  # MortarMayhemB*: the vector observation
+        lists["vec"] = [float(v) for v in env._commands_one_hot]
     return d, lists
 
 
@@ -306,6 +308,8 @@ ENVS = {
     "MortarMayhem-Grid-v0": dict(snap=snap_mm, pol=pol_mm_grid, disc=True),
     "MortarMayhem-v0": dict(snap=snap_mm, pol=pol_mm_free, disc=False),
     "Endless-MortarMayhem-v0": dict(snap=snap_mm, pol=lambda e, p, s: pol_mm_free(e, p, s, True), disc=False),
+    "MortarMayhemB-Grid-v0": dict(snap=snap_mm, pol=pol_mm_grid, disc=True),
+    "MortarMayhemB-v0": dict(snap=snap_mm, pol=pol_mm_free, disc=False),
     "MysteryPath-v0": dict(snap=snap_mp, pol=pol_mp, disc=False),
     "MysteryPath-Grid-v0": dict(snap=snap_mp, pol=pol_mp_grid, disc=True),
     "Endless-MysteryPath-v0": dict(snap=snap_emp, pol=pol_emp, disc=True),
@@ -336,6 +340,18 @@ SESSIONS = {
                  command_show_delay=[0, 1], explosion_duration=[4, 6], explosion_delay=[12, 18],
                  reward_new_command_success=0.5, reward_command_failure=-0.25), 1.0, 900),
         (4, dict(initial_command_count=2, visual_feedback=False), 0.99, 600),
+    ],
+    "MortarMayhemB-Grid-v0": [
+        (0, None, 0.0, 200), (1, None, 1.0, 400), (2, None, 0.95, 500),
+        (3, dict(arena_size=6, allowed_commands=9, command_count=[3, 5, 20], explosion_duration=[2, 3], explosion_delay=[4, 6, 8],
+                 reward_command_failure=-0.1, reward_episode_success=1.0), 0.97, 800),
+        (4, dict(arena_size=3, allowed_commands=4, command_count=[4], visual_feedback=False), 0.95, 300),
+    ],
+    "MortarMayhemB-v0": [
+        (0, None, 0.0, 200), (1, None, 1.0, 600), (2, None, 0.97, 600),
+        (3, dict(arena_size=6, allowed_commands=5, command_count=[3, 6, 20], explosion_duration=[4, 6],
+                 explosion_delay=[12, 18], reward_command_failure=-0.5, reward_episode_success=2.0), 0.98, 800),
+        (4, dict(arena_size=3, command_count=[5], agent_speed=2.0, visual_feedback=False), 0.95, 400),
     ],
     "MysteryPath-v0": [
         (0, None, 0.0, 600), (1, None, 1.0, 300), (2, None, 0.93, 900), (3, None, 0.8, 700),

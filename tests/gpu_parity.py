@@ -2,6 +2,22 @@
 import numpy as np
 
 
+def _split(obs):
+    """MortarMayhemB* return the reference's Dict observation."""
+    if isinstance(obs, dict):
+        return obs["visual_observation"], obs["vector_observation"]
+    return obs, None
+
+
+def _check_vec(env_id, vec, ref, where):
+    if vec is None:
+        return
+    want = np.stack([e.get_list("vec") for e in ref.envs]).astype(np.float32)
+    got = vec.cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want), "%s: vector_observation differs %s: envs %s" % (
+        env_id, where, np.nonzero((got != want).any(1))[0][:8])
+
+
 def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1, seed0=3):
     import memory_gym_amd
     import oracle_lib
@@ -11,7 +27,9 @@ def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1
     disc = env.action_dim == 1
     seeds = np.arange(n, dtype=np.int64) * 7 + seed0
     obs, info = env.reset(seed=seeds, options=options)
+    obs, vec = _split(obs)
     o0 = ref.reset(seeds)
+    _check_vec(env_id, vec, ref, "after reset")
     got = obs.cpu().numpy()
     if not np.array_equal(got, o0):
         bad = np.nonzero((got != o0).reshape(n, -1).any(1))[0]
@@ -30,7 +48,9 @@ def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1
                 act = policy(ref.envs[i], prng)
                 a[i, :a.shape[1]] = act[:a.shape[1]]
         obs, rew, done, trunc, info = env.step(a[:, 0] if disc else a)
+        obs, vec = _split(obs)
         o2, r2, d2 = ref.step(a[:, 0] if disc else a, autoreset=True, want_obs=(t % check_every == 0))
+        _check_vec(env_id, vec, ref, "at step %d" % t)
         d = done.cpu().numpy()
         assert np.array_equal(d, d2.astype(bool)), "%s: done differs at step %d: envs %s" % (
             env_id, t, np.nonzero(d != d2.astype(bool))[0][:8])

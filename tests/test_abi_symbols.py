@@ -43,7 +43,11 @@ def test_reset_params_mirror_the_reference():
     rp = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rp)
     assert set(rp.DEFAULTS) == {"MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0", "MysteryPath-v0",
-                                "Endless-MysteryPath-v0", "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-Grid-v0"}
+                                "Endless-MysteryPath-v0", "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-Grid-v0",
+                                "MortarMayhemB-Grid-v0", "MortarMayhemB-v0"}  # all ten ids of memory_gym/__init__.py:13-61
+    with pytest.raises(AssertionError, match="20 commands are allowed at maximum"):
+        rp.process_reset_params("MortarMayhemB-v0", {"command_count": [5, 21]})
+    assert "command_show_duration" not in rp.DEFAULTS["MortarMayhemB-Grid-v0"]
     p = rp.process_reset_params("MortarMayhem-Grid-v0", {"arena_size": 6})
     assert p["arena_size"] == 6 and p["command_count"] == [10] and p["explosion_delay"] == [6]
     with pytest.raises(AssertionError, match=r"Provided reset parameter \(agent_speeed\) is not valid. Check spelling."):

@@ -11,7 +11,8 @@ import oracle_lib
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_IDS = ["MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0", "MysteryPath-v0",
-           "Endless-MysteryPath-v0", "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-Grid-v0"]
+           "Endless-MysteryPath-v0", "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-Grid-v0",
+           "MortarMayhemB-Grid-v0", "MortarMayhemB-v0"]
 
 
 def load(env_id):
