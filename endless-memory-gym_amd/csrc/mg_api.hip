@@ -128,7 +128,17 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
             const mg_info_buffers* info, int autoreset, void* stream) {
     return guarded(env, [&] {
         if (!actions_dev || !obs_dev || !reward_dev || !done_dev) throw std::runtime_error("mg_step: NULL buffer");
-        env->fam->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, info, autoreset, (hipStream_t)stream);
+        hipStream_t st = (hipStream_t)stream;
+        if (autoreset && info && info->final_obs_dev) {
+            // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
+            // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
+            // consumption and frames as the fused path (tests/test_gpu_vector_api.py)
+            env->fam->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, info, 0, st);
+            env->fam->raster_only(info->final_obs_dev, done_dev, st);
+            env->fam->reset(nullptr, done_dev, obs_dev, gt_dev, st);
+        } else {
+            env->fam->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, info, autoreset, st);
+        }
     });
 }
 

@@ -104,6 +104,8 @@ class Family {
     virtual void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) = 0;
     virtual void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt,
                       const mg_info_buffers* info, int autoreset, hipStream_t s) = 0;
+    // rasterise the CURRENT frame descriptors of the instances with only[i] != 0 into `obs` (others untouched)
+    virtual void raster_only(void* obs, const uint8_t* only, hipStream_t s) = 0;
     // checkpoint: list of (device pointer, bytes) making up the state
     virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;
     virtual void debug_rng(int i, uint64_t out[6]) = 0;

@@ -600,6 +600,11 @@ class MortarFamily : public Family {
         dirty_ = false;
     }
 
+    void raster_only(void* obs, const uint8_t* only, hipStream_t s) override {
+        launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
+        MG_HIP(hipGetLastError());
+    }
+
     void raster(void* obs, hipStream_t s) {
         launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s);
         MG_HIP(hipGetLastError());

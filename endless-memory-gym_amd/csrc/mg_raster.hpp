@@ -429,7 +429,7 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
 
 template <class Composer, int FMT>
 __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
-                                                     void* __restrict__ obs, int n) {
+                                                     void* __restrict__ obs, int n, const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     RasterCtx R;
     R.frame = smem;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     const int tid = threadIdx.x, stride = gridDim.x;
     const cptr<typename Composer::Desc> cdescs = as_const(descs);
     for (int env = blockIdx.x; env < n; env += stride) {
-        if (Composer::skip(cdescs + env)) continue;
+        if (Composer::skip(cdescs + env) || (only && !only[env])) continue;  // `only`: per-frame filter (final observations)
         typename Composer::Pre P;
         Composer::prefetch(cdescs + env, R, P);
         Composer::compose(cdescs + env, P, R);
@@ -451,7 +451,8 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
 }
 
 template <class Composer>
-inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s) {
+inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s,
+                          const uint8_t* only = nullptr) {
     static const int tuned = [] {  // MEMGYM_RASTER_GRID overrides the persistent grid size (tuning experiments)
         const char* e = getenv("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : RASTER_GRID;
@@ -462,11 +463,11 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
     }();
     const int grid = n < tuned ? n : tuned;
     if (fmt == MG_OBS_F32_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else if (fmt == MG_OBS_F16_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
 }
 
 }  // namespace mg

@@ -11,13 +11,15 @@ single-instance adapter), mirroring the reference's registration side effect on 
 """
 from .reset_params import DEFAULTS, process_reset_params  # noqa: F401
 from .vec_env import ENV_IDS, MemoryGymEnv, VecMemoryGym  # noqa: F401
+from .vector import GymnasiumVectorEnv  # noqa: F401
 
 
 
-def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc"):
+def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False):
     if num_envs is None:
         return MemoryGymEnv(env_id, device=device, render_mode=render_mode)
-    return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode, obs_format=obs_format)
+    return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode, obs_format=obs_format,
+                        final_observation=final_observation)
 
 
 def _register_with_gymnasium():

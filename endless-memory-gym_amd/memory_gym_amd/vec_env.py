@@ -60,7 +60,7 @@ class VecMemoryGym:
     OBS_FORMATS = {"u8_xyc": (0, torch.uint8, (84, 84, 3)), "f32_chw": (1, torch.float32, (3, 84, 84)),
                    "f16_chw": (2, torch.float16, (3, 84, 84))}
 
-    def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc"):
+    def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -88,6 +88,8 @@ class VecMemoryGym:
         _native.check(_native.LIB.mg_set_obs_format(h, code), "mg_set_obs_format")
         assert _native.LIB.mg_obs_bytes(h) == 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
         self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
+        # gymnasium-0.29 vector convention: keep the terminal frame of instances that finish (and auto-reset) in a step
+        self.final_obs = torch.zeros((N,) + shape, dtype=dt, device=dev) if final_observation else None
         # MortarMayhemB*: obs is the reference's Dict; `vector_obs` is written by the library whenever an instance resets
         self.vector_obs = None
         if self.vec_dim:
@@ -110,6 +112,7 @@ class VecMemoryGym:
         self._info.ep_length_dev = self.ep_length.data_ptr()
         for k, t in enumerate(self.aux):
             self._info.aux_dev[k] = t.data_ptr()
+        self._info.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
         self.reset_params = process_reset_params(env_id, None)
         self._applied = dict(DEFAULTS[env_id])
         self.max_episode_steps = None
@@ -186,6 +189,8 @@ class VecMemoryGym:
             info[nm] = t
         if self.gt_dim:
             info["ground_truth"] = self.gt
+        if self.final_obs is not None and self.autoreset:  # rows valid where done_mask is set
+            info["final_observation"] = self.final_obs
         return self._obs(), self.reward, done, self._truncated, info
 
     def _obs(self):

@@ -35,6 +35,11 @@ typedef struct mg_info_buffers {
     double* ep_reward_dev;         /* "reward": Python sum() of the step rewards, in double        */
     int32_t* ep_length_dev;        /* "length"                                                      */
     float* aux_dev[MG_INFO_SLOTS]; /* "success", "commands_completed", "num_fails", ... per env id */
+    /* Optional (gymnasium 0.29 VectorEnv convention, info["final_observation"]): with autoreset != 0 and this pointer
+     * set, mg_step also writes the TERMINAL observation of every instance that finished in this call to row i of this
+     * buffer (same format and shape as obs_dev; rows of other instances are left untouched) while obs_dev row i holds
+     * the first observation of the new episode.  Costs one masked reset launch and two masked raster launches. */
+    void* final_obs_dev;
 } mg_info_buffers;
 
 /* gymnasium.make(id) + Env.__init__  (memory_gym/__init__.py:13-61; e.g. mortar_mayhem_grid.py:55-90).
