@@ -196,52 +196,65 @@ __device__ __forceinline__ u128m row_mask(const int* dx, const int* dy, const in
 }
 __device__ __forceinline__ int popc128(u128m m) { return __popcll((unsigned long long)m) + __popcll((unsigned long long)(m >> 64)); }
 
-__device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, int nd, int* ox, int* oy) {
+// Cooperative form: the 16 lanes of an instance call this together (same arguments, same RNG state in every lane).
+// Lane ls owns the six rows [6 ls, 6 ls + 6) (lanes 14, 15 idle); free-cell counts are reduced / scanned across the
+// group with shuffles, every lane performs the identical draw, and the lane whose rows contain the k-th free cell
+// locates it.  A single lane walking all 84 rows twice took ~40 us (the tail of the whole step kernel whenever any
+// instance re-spawned its coin).
+constexpr int ROWS_PER_LANE = 6;
+static_assert(ROWS_PER_LANE * 14 == SCREEN, "14 lanes x 6 rows cover the sampler grid");
+__device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, int nd, int ls, int* ox, int* oy) {
     if (nd == 0) {  // empty mask: cell k itself
         int k = g.integers(0, SCREEN * SCREEN);
         *oy = k / SCREEN;
         *ox = k - *oy * SCREEN;
         return SCREEN * SCREEN;
     }
-    // only rows within reach of a disc can have blocked cells
-    int ylo = SCREEN, yhi = -1;
-    for (int d = 0; d < nd; ++d) {
-        int a = dy[d] - dr[d] + 1, b = dy[d] + dr[d] - 1;
-        ylo = a < ylo ? a : ylo;
-        yhi = b > yhi ? b : yhi;
+    const int y0 = ls * ROWS_PER_LANE;
+    int local_free = 0;
+    if (ls < 14) {
+        for (int j = 0; j < ROWS_PER_LANE; ++j) local_free += SCREEN - popc128(row_mask(dx, dy, dr, nd, y0 + j));
     }
-    ylo = ylo < 0 ? 0 : ylo;
-    yhi = yhi > SCREEN - 1 ? SCREEN - 1 : yhi;
-    int blocked = 0;
-    for (int y = ylo; y <= yhi; ++y) blocked += popc128(row_mask(dx, dy, dr, nd, y));
-    const int free_total = SCREEN * SCREEN - blocked;
-    int k = g.integers(0, free_total);
-    // rows above the first affected row are completely free
-    if (k < ylo * SCREEN) {
-        *oy = k / SCREEN;
-        *ox = k - *oy * SCREEN;
-        return free_total;
+    // inclusive scan over the 16 lanes of the group (width-16 shuffles stay inside the instance's lanes)
+    int incl = local_free;
+    for (int off = 1; off < 16; off <<= 1) {
+        int v = __shfl_up(incl, off, 16);
+        if (ls >= off) incl += v;
     }
-    k -= ylo * SCREEN;
-    for (int y = ylo; y <= yhi; ++y) {
-        u128m m = row_mask(dx, dy, dr, nd, y);
-        int fr = SCREEN - popc128(m);
-        if (k < fr) {
-            for (int x = 0; x < SCREEN; ++x) {
-                if (!((m >> x) & 1)) {
-                    if (k == 0) {
-                        *ox = x;
-                        *oy = y;
-                        return free_total;
-                    }
-                    --k;
+    const int free_total = __shfl(incl, 15, 16);
+    int k = g.integers(0, free_total);  // identical in all 16 lanes
+    const int excl = incl - local_free;
+    int fx = -1, fy = -1;
+    if (k >= excl && k < incl) {  // exactly one lane
+        int kk = k - excl;
+        for (int j = 0; j < ROWS_PER_LANE; ++j) {
+            u128m m = row_mask(dx, dy, dr, nd, y0 + j);
+            int fr = SCREEN - popc128(m);
+            if (kk < fr) {
+                // kk-th free cell of this row: skip whole bytes, then single bits
+                int x = 0;
+                for (;; x += 8) {
+                    int zb = 8 - __popc((unsigned)(m >> x) & 0xFFu);
+                    if (x + 8 > SCREEN) zb -= x + 8 - SCREEN;  // bits beyond the grid are not cells
+                    if (kk < zb) break;
+                    kk -= zb;
                 }
+                for (;; ++x) {
+                    if (!((m >> x) & 1)) {
+                        if (kk == 0) break;
+                        --kk;
+                    }
+                }
+                fx = x;
+                fy = y0 + j;
+                break;
             }
+            kk -= fr;
         }
-        k -= fr;
     }
-    *oy = yhi + 1 + k / SCREEN;  // rows below the last affected row are completely free
-    *ox = k - (k / SCREEN) * SCREEN;
+    const int owner = __ffs((unsigned)(__ballot(fx >= 0) >> ((threadIdx.x & 63) & 48)) & 0xFFFFu) - 1;
+    *ox = __shfl(fx, owner, 16);
+    *oy = __shfl(fy, owner, 16);
     return free_total;
 }
 
@@ -312,7 +325,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     int ax, ay;
     if (P.sample_agent_position) {
         int cx, cy;
-        sample_cell(g, bx, by, br, 0, &cx, &cy);
+        sample_cell(g, bx, by, br, 0, ls, &cx, &cy);
         bx[nb] = cx; by[nb] = cy; br[nb++] = 28;
         ax = cx + g.integers(2, 4);
         ay = cy + g.integers(2, 4);
@@ -342,7 +355,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     if constexpr (EN) {
         if (P.coin_enabled) {  // _spawn_coin: the sampler is reset first, self.coin is None -> nothing blocked
             int cx, cy;
-            sample_cell(g, bx, by, br, 0, &cx, &cy);
+            sample_cell(g, bx, by, br, 0, ls, &cx, &cy);
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
             clamp_spawn(P, cx, cy);
@@ -358,7 +371,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         for (int k = 0; k < MAX_COINS; ++k) {
             if (k >= nc) break;
             int cx, cy;
-            sample_cell(g, bx, by, br, nb, &cx, &cy);
+            sample_cell(g, bx, by, br, nb, ls, &cx, &cy);
             bx[nb] = cx; by[nb] = cy; br[nb++] = 21;
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
@@ -368,7 +381,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
             s.n_coins++;
         }
         int ex, ey;
-        sample_cell(g, bx, by, br, nb, &ex, &ey);
+        sample_cell(g, bx, by, br, nb, ls, &ex, &ey);
         ex += g.integers(2, 4);
         ey += g.integers(2, 4);
         clamp_spawn(P, ex, ey);
@@ -476,6 +489,15 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     Pcg g;
     g.load(io.rng, i);
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
+    // lane ls looks after slot ls.  Its slot record is requested NOW, together with the core / RNG / action loads (one
+    // memory round trip for the whole step instead of core -> sp_done -> ballot -> slot fields in sequence); the
+    // addresses are valid whether or not the slot is in use.
+    const size_t k = (size_t)i * SLOTS + ls;
+    double p_t = io.sp_t[k], p_speed = io.sp_speed[k];
+    double p_sx = io.sp_sx[k], p_sy = io.sp_sy[k], p_tx = io.sp_tx[k], p_ty = io.sp_ty[k], p_ox = io.sp_ox[k], p_oy = io.sp_oy[k];
+    int p_r = io.sp_r[k];
+    bool p_done = io.sp_done[k] != 0;
+    const uint32_t free_before = s.free_mask;
 
     // CharacterController.step(action, walkable_rect = (0, 4, 84, 80))
     int a0 = actions[2 * i], a1 = actions[2 * i + 1];
@@ -516,10 +538,14 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
             s.spawn_timer = 0;
         }
     }
-    // lane ls looks after slot ls
-    const size_t k = (size_t)i * SLOTS + ls;
+    if (((free_before >> ls) & 1u) && !((s.free_mask >> ls) & 1u)) {  // spawned into my slot just now (rare): re-read it
+        p_t = io.sp_t[k]; p_speed = io.sp_speed[k];
+        p_sx = io.sp_sx[k]; p_sy = io.sp_sy[k]; p_tx = io.sp_tx[k]; p_ty = io.sp_ty[k]; p_ox = io.sp_ox[k]; p_oy = io.sp_oy[k];
+        p_r = io.sp_r[k];
+        p_done = io.sp_done[k] != 0;
+    }
     const bool used = !((s.free_mask >> ls) & 1u);
-    const bool my_done = used && io.sp_done[k] != 0;
+    const bool my_done = used && p_done;
     const uint32_t done_mask = (uint32_t)(__ballot(my_done) >> group_shift) & 0xFFFFu;
     // `for spot in self.spotlights: if spot.done: self.spotlights.remove(spot) else: draw + hit test`:
     // removing while iterating skips the element that follows a removed one (it stays in the list untouched)
@@ -547,13 +573,13 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     }
     bool my_hit = false;
     if ((processed >> ls) & 1u) {
-        double t = io.sp_t[k];
-        double lx = io.sp_tx[k] * (1 - t) + io.sp_ox[k] * t, ly = io.sp_ty[k] * (1 - t) + io.sp_oy[k] * t;
-        double cx = io.sp_sx[k] * (1 - t) + lx * t, cy = io.sp_sy[k] * (1 - t) + ly * t;
-        int radius = io.sp_r[k];
+        double t = p_t;
+        double lx = p_tx * (1 - t) + p_ox * t, ly = p_ty * (1 - t) + p_oy * t;
+        double cx = p_sx * (1 - t) + lx * t, cy = p_sy * (1 - t) + ly * t;
+        int radius = p_r;
         int rank = __popc(processed & ((1u << ls) - 1u));
         io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius);
-        t += io.sp_speed[k];
+        t += p_speed;
         if (t >= 1.0) {
             t = 1.0;
             io.sp_done[k] = 1;
@@ -594,7 +620,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
                 // _spawn_coin: sampler reset, previous coin blocked with r = 28
                 int bx[1] = {s.coin_x}, by[1] = {s.coin_y}, br[1] = {28};
                 int cx, cy;
-                sample_cell(g, bx, by, br, 1, &cx, &cy);
+                sample_cell(g, bx, by, br, 1, ls, &cx, &cy);
                 cx += g.integers(2, 4);
                 cy += g.integers(2, 4);
                 clamp_spawn(P, cx, cy);
