@@ -180,13 +180,29 @@ __device__ __forceinline__ int isqrt_floor(int v) {
 // Each row's blocked set is a union of intervals [cx - hw, cx + hw] with hw = isqrt(r^2 - dy^2 - 1); rows are
 // 84-bit masks built with shifts (no per-cell loops), free cells counted with popcounts.
 typedef unsigned __int128 u128m;
-__device__ __forceinline__ u128m row_mask(const int* dx, const int* dy, const int* dr, int nd, int y) {
+// The blocked discs (agent, coins, exit; at most 1 + MAX_COINS + 1).  Register resident: every access uses a
+// compile-time index under a predicate, so that loops over the discs / over the coins need not be unrolled around the
+// sampler (an unrolled coin loop made the finite step kernel 30,000 instructions long).
+constexpr int MAX_DISCS = 1 + MAX_COINS + 1;
+struct Discs {
+    int x[MAX_DISCS], y[MAX_DISCS], r[MAX_DISCS];
+    int n;
+    __device__ __forceinline__ void push(int X, int Y, int R) {
+#pragma unroll
+        for (int q = 0; q < MAX_DISCS; ++q)
+            if (q == n) { x[q] = X; y[q] = Y; r[q] = R; }
+        ++n;
+    }
+};
+__device__ __forceinline__ u128m row_mask(const Discs& D, int y) {
     u128m m = 0;
-    for (int d = 0; d < nd; ++d) {
-        int ddy = y - dy[d], rem = dr[d] * dr[d] - ddy * ddy - 1;
+#pragma unroll
+    for (int d = 0; d < MAX_DISCS; ++d) {
+        if (d >= D.n) break;
+        int ddy = y - D.y[d], rem = D.r[d] * D.r[d] - ddy * ddy - 1;
         if (rem < 0) continue;
         int hw = isqrt_floor(rem);
-        int a = dx[d] - hw, b = dx[d] + hw;
+        int a = D.x[d] - hw, b = D.x[d] + hw;
         a = a < 0 ? 0 : a;
         b = b > SCREEN - 1 ? SCREEN - 1 : b;
         if (a > b) continue;
@@ -203,8 +219,8 @@ __device__ __forceinline__ int popc128(u128m m) { return __popcll((unsigned long
 // instance re-spawned its coin).
 constexpr int ROWS_PER_LANE = 6;
 static_assert(ROWS_PER_LANE * 14 == SCREEN, "14 lanes x 6 rows cover the sampler grid");
-__device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, int nd, int ls, int* ox, int* oy) {
-    if (nd == 0) {  // empty mask: cell k itself
+__device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, int ls, int* ox, int* oy) {
+    if (D.n == 0) {  // empty mask: cell k itself
         int k = g.integers(0, SCREEN * SCREEN);
         *oy = k / SCREEN;
         *ox = k - *oy * SCREEN;
@@ -213,7 +229,7 @@ __device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, 
     const int y0 = ls * ROWS_PER_LANE;
     int local_free = 0;
     if (ls < 14) {
-        for (int j = 0; j < ROWS_PER_LANE; ++j) local_free += SCREEN - popc128(row_mask(dx, dy, dr, nd, y0 + j));
+        for (int j = 0; j < ROWS_PER_LANE; ++j) local_free += SCREEN - popc128(row_mask(D, y0 + j));
     }
     // inclusive scan over the 16 lanes of the group (width-16 shuffles stay inside the instance's lanes)
     int incl = local_free;
@@ -228,7 +244,7 @@ __device__ int sample_cell(Pcg& g, const int* dx, const int* dy, const int* dr, 
     if (k >= excl && k < incl) {  // exactly one lane
         int kk = k - excl;
         for (int j = 0; j < ROWS_PER_LANE; ++j) {
-            u128m m = row_mask(dx, dy, dr, nd, y0 + j);
+            u128m m = row_mask(D, y0 + j);
             int fr = SCREEN - popc128(m);
             if (kk < fr) {
                 // kk-th free cell of this row: skip whole bytes, then single bits
@@ -321,18 +337,19 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.ep_len = 0;
     s.la0 = s.la1 = 0;
     s.rot8 = (uint8_t)g.integers(0, 8);  // choice([0, 45, ..., 315])
-    int bx[1 + MAX_COINS + 1], by[1 + MAX_COINS + 1], br[1 + MAX_COINS + 1], nb = 0;
+    Discs D;
+    D.n = 0;
     int ax, ay;
     if (P.sample_agent_position) {
-        int cx, cy;
-        sample_cell(g, bx, by, br, 0, ls, &cx, &cy);
-        bx[nb] = cx; by[nb] = cy; br[nb++] = 28;
+        int k = g.integers(0, SCREEN * SCREEN);  // sampler with an empty mask: cell k itself
+        int cy = k / SCREEN, cx = k - cy * SCREEN;
+        D.push(cx, cy, 28);
         ax = cx + g.integers(2, 4);
         ay = cy + g.integers(2, 4);
     } else {
         ax = SCREEN / 2;
         ay = SCREEN / 2;
-        bx[nb] = ax; by[nb] = ay; br[nb++] = 21;
+        D.push(ax, ay, 21);
     }
     s.ax = (int16_t)ax;
     s.ay = (int16_t)ay;
@@ -354,8 +371,8 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     uint32_t coin_pos[MAX_COINS] = {0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (EN) {
         if (P.coin_enabled) {  // _spawn_coin: the sampler is reset first, self.coin is None -> nothing blocked
-            int cx, cy;
-            sample_cell(g, bx, by, br, 0, ls, &cx, &cy);
+            int k = g.integers(0, SCREEN * SCREEN);
+            int cy = k / SCREEN, cx = k - cy * SCREEN;
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
             clamp_spawn(P, cx, cy);
@@ -367,21 +384,22 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     } else {
         int nc = P.num_coins.n > 0 ? choice(g, P.num_coins) : 0;
         s.num_coins = nc;
-#pragma unroll
-        for (int k = 0; k < MAX_COINS; ++k) {
-            if (k >= nc) break;
+        for (int k = 0; k < nc && k < MAX_COINS; ++k) {  // deliberately not unrolled (code size)
             int cx, cy;
-            sample_cell(g, bx, by, br, nb, ls, &cx, &cy);
-            bx[nb] = cx; by[nb] = cy; br[nb++] = 21;
+            sample_cell(g, D, ls, &cx, &cy);
+            D.push(cx, cy, 21);
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
             clamp_spawn(P, cx, cy);
-            if (ls == 0) coins[k] = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
-            coin_pos[k] = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
+            const uint32_t w = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
+            if (ls == 0) coins[k] = w;
+#pragma unroll
+            for (int q = 0; q < MAX_COINS; ++q)
+                if (q == k) coin_pos[q] = w;
             s.n_coins++;
         }
         int ex, ey;
-        sample_cell(g, bx, by, br, nb, ls, &ex, &ey);
+        sample_cell(g, D, ls, &ex, &ey);
         ex += g.integers(2, 4);
         ey += g.integers(2, 4);
         clamp_spawn(P, ex, ey);
@@ -527,12 +545,12 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     bool spot_done = false;
     s.spawn_timer++;
     if constexpr (EN) {
-        if (s.spawn_timer >= P.spawn_interval) {
+        if (__builtin_expect(s.spawn_timer >= P.spawn_interval, 0)) {
             new_spot(P, io, i, ls, s, g);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
-        if (s.spawn_timer >= P.interval0) {
+        if (__builtin_expect(s.spawn_timer >= P.interval0, 0)) {
             new_spot(P, io, i, ls, s, g);
             s.n_intervals--;
             s.spawn_timer = 0;
@@ -613,14 +631,16 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         if (P.coin_enabled) {
             double cr = 0.0;
             double ddx = (double)ax - (double)s.coin_x, ddy = (double)ay - (double)s.coin_y;
-            if (sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius)) {
+            if (__builtin_expect(sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius), 0)) {
                 cr += P.r_coin;
                 s.coins_collected++;
                 s.coin_t = 0;
                 // _spawn_coin: sampler reset, previous coin blocked with r = 28
-                int bx[1] = {s.coin_x}, by[1] = {s.coin_y}, br[1] = {28};
+                Discs D;
+                D.n = 0;
+                D.push(s.coin_x, s.coin_y, 28);
                 int cx, cy;
-                sample_cell(g, bx, by, br, 1, ls, &cx, &cy);
+                sample_cell(g, D, ls, &cx, &cy);
                 cx += g.integers(2, 4);
                 cy += g.integers(2, 4);
                 clamp_spawn(P, cx, cy);
@@ -636,8 +656,12 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         if (s.t == P.max_steps) done = true;
     } else {
         bool coins_done;
+        {  // the instance's coin list as two 16-byte loads (eight predicated dword loads were issued one after another)
+            const uint4 c0 = reinterpret_cast<const uint4*>(coins)[0], c1 = reinterpret_cast<const uint4*>(coins)[1];
+            const uint32_t cw[MAX_COINS] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (int q = 0; q < MAX_COINS; ++q) coin_pos[q] = q < s.n_coins ? coins[q] : 0u;
+            for (int q = 0; q < MAX_COINS; ++q) coin_pos[q] = q < s.n_coins ? cw[q] : 0u;
+        }
         if (s.num_coins > 0) {
             double cr = 0.0;
 #pragma unroll
@@ -696,7 +720,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         done_out[i] = done ? 1 : 0;
     }
 
-    if (done && autoreset) {
+    if (__builtin_expect(done && autoreset, 0)) {  // cold: keep the reset code out of the hot instruction stream
         spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr);
     } else {
         d.bg = s.bg_red;
@@ -718,8 +742,11 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
                 if (q < s.n_coins) {
                     int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
                     d.coins[q] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
-                    if (leader) coins[q] = coin_pos[q];
                 }
+            }
+            if (leader) {  // entries beyond n_coins are dead; written as two 16-byte stores
+                reinterpret_cast<uint4*>(coins)[0] = make_uint4(coin_pos[0], coin_pos[1], coin_pos[2], coin_pos[3]);
+                reinterpret_cast<uint4*>(coins)[1] = make_uint4(coin_pos[4], coin_pos[5], coin_pos[6], coin_pos[7]);
             }
             d.exit_stamp = s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED;
             d.exit_x = (int16_t)(s.exit_x - P.exit_half);
