@@ -132,27 +132,25 @@ __device__ __forceinline__ int diag_of(int idx, int k) {
     return (x > 0 && y < G - 1) ? idx - G + 1 : -1;
 }
 
-// Per-lane A* workspace in LDS (the path generator's arrays are indexed with run-time values; in private memory they
-// would live in scratch, i.e. a global-memory round trip per access).  Planes are interleaved by lane:
-// element k of lane t sits at plane[k * 256 + t].
-constexpr int WS_G = 0;                          // uint16 g_cost[49]
-constexpr int WS_PREV = WS_G + 49 * 2 * 256;     // int8  previous_node[49]
-constexpr int WS_OPEN = WS_PREV + 49 * 256;      // uint8 open_set[49] (ordered list)
-constexpr int WS_OUTER = WS_OPEN + 49 * 256;     // uint8 outer_nodes[28]
-constexpr int WS_OUT = WS_OPEN;                  // uint8 path out[49]: reuses the open-set plane (traced back once the search is over)
-constexpr int WS_SQRT = WS_OUTER + 28 * 256;     // double sqrt_tab[80] shared by the block (heuristic values)
-constexpr int WS_BYTES = WS_SQRT + 80 * 8;
-static_assert(WS_SQRT % 8 == 0 && WS_BYTES <= 65536, "A* workspace layout");
+// ---- Wave-cooperative path generation -------------------------------------------------------------------------
+// The environments are stepped one LANE per instance, but generating a path (walls + noisy A*) is a long serial job:
+// run by the single lane that happens to reset it took 70-300 us and was the tail of every launch in which any
+// instance reset.  Instead, instances that need a path are served one at a time by their whole WAVE at a converged
+// point of the kernel (serve_*): the requesting lane's inputs and RNG state are broadcast, all 64 lanes execute the
+// same (uniform) control flow with node n's A* record living in lane n's registers and the ordered open list living
+// one position per lane, so that the reference's list operations are O(1):
+//   selection  "first index i >= 1 with f(open[i]) < f(open[0]) else 0"  = one shuffle of f + one ballot
+//   removal    list.pop(i)                                                = one shuffle down
+//   membership / closed / walls                                           = uniform 64-bit masks
+// LDS: the heuristic table sqrt(0..79) for the block and 64 staging bytes per wave for the finished path.
+constexpr int WS_SQRT = 0;                        // double sqrt_tab[80]
+constexpr int WS_STAGE = 80 * 8;                  // uint8 stage[4 waves][64]
+constexpr int WS_BYTES = WS_STAGE + 4 * 64;
 
 struct PathWS {
     uint8_t* base;
-    int tid;
-    __device__ __forceinline__ uint16_t& g(int k) const { return reinterpret_cast<uint16_t*>(base + WS_G)[k * 256 + tid]; }
-    __device__ __forceinline__ int8_t& prev(int k) const { return reinterpret_cast<int8_t*>(base + WS_PREV)[k * 256 + tid]; }
-    __device__ __forceinline__ uint8_t& open(int k) const { return (base + WS_OPEN)[k * 256 + tid]; }
-    __device__ __forceinline__ uint8_t& outer(int k) const { return (base + WS_OUTER)[k * 256 + tid]; }
-    __device__ __forceinline__ uint8_t& out(int k) const { return (base + WS_OUT)[k * 256 + tid]; }
     __device__ __forceinline__ double h(int d2) const { return reinterpret_cast<const double*>(base + WS_SQRT)[d2]; }
+    __device__ __forceinline__ uint8_t* stage() const { return base + WS_STAGE + (threadIdx.x >> 6) * 64; }
 };
 
 __device__ __forceinline__ void path_ws_init(uint8_t* smem) {  // all threads of the block, before any path is generated
@@ -160,98 +158,117 @@ __device__ __forceinline__ void path_ws_init(uint8_t* smem) {  // all threads of
     __syncthreads();
 }
 
-// f_cost of a node that has entered the open set: the reference stores g_cost + h_cost whenever it (re)computes f, and
-// its `neighbor.g = g` typo means g_cost never changes afterwards -> f is always g_cost + h, no separate array needed.
-__device__ __forceinline__ double f_of(const PathWS& W, int node, int ex, int ey) {
-    int ax = node / G, ay = node - ax * G;
-    int ddx = ax - ex, ddy = ay - ey;
-    return (double)W.g(node) + W.h(ddx * ddx + ddy * ddy);
+__device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ Pcg bcast(const Pcg& g, int lane) {
+    Pcg b;
+    uint32_t w[9] = {(uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)(g.state >> 64), (uint32_t)(g.state >> 96),
+                     (uint32_t)g.inc,   (uint32_t)(g.inc >> 32),   (uint32_t)(g.inc >> 64),   (uint32_t)(g.inc >> 96), g.buf};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = (uint32_t)__builtin_amdgcn_readlane((int)w[k], lane);
+    b.state = ((u128)w[3] << 96) | ((u128)w[2] << 64) | ((u128)w[1] << 32) | w[0];
+    b.inc = ((u128)w[7] << 96) | ((u128)w[6] << 64) | ((u128)w[5] << 32) | w[4];
+    b.buf = w[8];
+    b.has = __builtin_amdgcn_readlane(g.has ? 1 : 0, lane) != 0;
+    return b;
 }
 
-__device__ __noinline__ int generate_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey) {
+// MysteryPath.__init__ (pygame_assets.py:606-724) + Node (:438-493), every argument wave-uniform, called by all 64
+// lanes.  Returns the path length (-1 = "No valid path found"); lane k < len receives the k-th path node (flat index
+// x*7+y, END FIRST like the reference's list) in out_node, path_mask has one bit per path node.
+__device__ int coop_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey, int& out_node, uint64_t& path_mask) {
+    const int lane = threadIdx.x & 63;
     uint64_t wall = 0, closed = 0, in_open = 0;
-    for (int i = 0; i < G * G; ++i) {
-        W.g(i) = 0;
-        W.prev(i) = -1;
-    }
     for (int i = 0; i < G; ++i)
         for (int j = 0; j < G; ++j)
             if (i > 0 && i < G - 2 && j > 0 && j < G - 2)
                 if (g.integers(0, 100) < 33) wall |= 1ull << (i * G + j);
     const int start = sx * G + sy, end = ex * G + ey;
-    int n_outer = 0;
-    for (int i = 0; i < G; ++i)
-        for (int j = 0; j < G; ++j) {
-            if (!(i == 0 || i == G - 1 || j == 0 || j == G - 1)) continue;
-            int idx = i * G + j;
-            if (idx == start || idx == end) continue;
-            bool near = false;
-            for (int k = 0; k < 4; ++k) near = near || nb_of(start, k) == idx || nb_of(end, k) == idx;
-            if (near) continue;
-            bool adj = false;
-            for (int k = 0; k < 4; ++k) {
-                int q = nb_of(idx, k);
-                if (q >= 0 && ((wall >> q) & 1ull)) adj = true;
-                q = diag_of(idx, k);
-                if (q >= 0 && ((wall >> q) & 1ull)) adj = true;
-            }
-            if (!adj) W.outer(n_outer++) = (uint8_t)idx;
+    // outer wall candidates, in the reference's (i, j) order == increasing flat index: one node per lane
+    uint64_t outer;
+    {
+        const int idx = lane < G * G ? lane : 0;
+        const int i = idx / G, j = idx - i * G;
+        bool ok = lane < G * G && (i == 0 || i == G - 1 || j == 0 || j == G - 1) && idx != start && idx != end;
+        for (int k = 0; k < 4; ++k) ok = ok && nb_of(start, k) != idx && nb_of(end, k) != idx;
+        for (int k = 0; k < 4; ++k) {
+            int q = nb_of(idx, k);
+            if (q >= 0 && ((wall >> q) & 1ull)) ok = false;
+            q = diag_of(idx, k);
+            if (q >= 0 && ((wall >> q) & 1ull)) ok = false;
         }
-    int n_iter = g.integers(0, 2) == 0 ? 4 : 8;  // rng.choice([4, 8])
+        outer = __ballot(ok);
+    }
+    int n_outer = __popcll(outer);
+    const int n_iter = g.integers(0, 2) == 0 ? 4 : 8;  // rng.choice([4, 8])
     for (int it = 0; it < n_iter; ++it) {
         if (n_outer > 0) {
             int k = g.integers(0, n_outer);
-            int idx = W.outer(k);
+            uint64_t m = outer;
+            for (int q = 0; q < k; ++q) m &= m - 1;  // k-th remaining candidate (list order)
+            const int idx = __ffsll((unsigned long long)m) - 1;
             wall |= 1ull << idx;
-            for (int q = k; q < n_outer - 1; ++q) W.outer(q) = W.outer(q + 1);
+            outer &= ~(1ull << idx);
             --n_outer;
         }
     }
-    int n_open = 0;
-    W.open(n_open++) = (uint8_t)start;
+    // per-node record in lane n; f = g_cost + h is only ever evaluated for nodes in the open set, and the reference's
+    // `neighbor.g = g` typo means g_cost never changes once a node has entered it
+    int gval = 0, prev = -1;
+    double hval = 0.0;
+    {
+        const int idx = lane < G * G ? lane : 0;
+        const int ax = idx / G, ay = idx - ax * G;
+        hval = W.h((ax - ex) * (ax - ex) + (ay - ey) * (ay - ey));
+    }
+    int lst = 0, n_open = 0;  // lane p: node at position p of the ordered open list
+    if (lane == 0) lst = start;
+    n_open = 1;
     in_open |= 1ull << start;
     for (;;) {
         if (n_open == 0) return -1;
-        int w = 0;
-        {
-            const double f0 = f_of(W, W.open(0), ex, ey);
-            for (int i = 1; i < n_open; ++i)
-                if (f_of(W, W.open(i), ex, ey) < f0) {  // first strictly better than open[0], then break
-                    w = i;
-                    break;
-                }
-        }
-        int cur = W.open(w);
+        const double fnode = (double)gval + hval;
+        const double f_at = __shfl(fnode, lst & 63);
+        const double f0 = __shfl(f_at, 0);
+        const uint64_t better = __ballot(lane >= 1 && lane < n_open && f_at < f0);
+        const int w = better ? __ffsll((unsigned long long)better) - 1 : 0;  // first strictly better than open[0]
+        const int cur = bcast(lst, w);
         if (cur == end) {
-            int len = 0, t = cur;  // the open set is dead from here on: its plane receives the path
-            W.out(len++) = (uint8_t)end;
-            while (W.prev(t) >= 0) {
-                int pv = W.prev(t);
-                W.out(len++) = (uint8_t)pv;
+            int len = 0, t = cur;
+            path_mask = 0;
+            for (;;) {
+                if (lane == len) out_node = t;
+                path_mask |= 1ull << t;
+                ++len;
+                const int pv = bcast(prev, t);
+                if (pv < 0) break;
                 t = pv;
             }
             return len;
         }
-        for (int q = w; q < n_open - 1; ++q) W.open(q) = W.open(q + 1);
-        --n_open;
+        {  // open_set.remove(current)
+            const int nxt = __shfl_down(lst, 1);
+            if (lane >= w) lst = nxt;
+            --n_open;
+        }
         in_open &= ~(1ull << cur);
         closed |= 1ull << cur;
-        const int gcur = W.g(cur);
+        const int gcur = bcast(gval, cur);
         for (int k = 0; k < 4; ++k) {
-            int nb = nb_of(cur, k);
+            const int nb = nb_of(cur, k);
             if (nb < 0) continue;
             if (((closed >> nb) & 1ull) || ((wall >> nb) & 1ull)) continue;
-            int gg = gcur + g.integers(1, 9);
+            const int gg = gcur + g.integers(1, 9);
             bool new_path = false;
             if ((in_open >> nb) & 1ull) {
-                if (gg < (int)W.g(nb)) new_path = true;  // `neighbor.g = g` typo: g_cost is NOT updated
+                if (gg < bcast(gval, nb)) new_path = true;  // `neighbor.g = g` typo: g_cost is NOT updated
             } else {
-                W.g(nb) = (uint16_t)gg;
+                if (lane == nb) gval = gg;
                 new_path = true;
-                W.open(n_open++) = (uint8_t)nb;
+                if (lane == n_open) lst = nb;
+                ++n_open;
                 in_open |= 1ull << nb;
             }
-            if (new_path) W.prev(nb) = (int8_t)cur;
+            if (new_path && lane == nb) prev = cur;
         }
     }
 }
@@ -271,23 +288,27 @@ __device__ __forceinline__ void move_agent(const MysteryParams& P, MysteryCore& 
 }
 
 // ============================================ finite ============================================
-__device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, const PathWS& W, MysteryCore& s, Pcg& g, MysteryDesc& d) {
+// MysteryPathEnv.reset (mystery_path.py:130-200) in two halves around the path generation, which is served by the
+// whole wave (serve_mp): the draws before it, the bookkeeping after it.
+struct PathReq {
+    int need;            // this lane wants a path
+    int sx, sy, ex, ey;  // start / end tile
+};
+__device__ __forceinline__ PathReq mp_pre_reset(const MysteryParams& P, MysteryCore& s, Pcg& g) {
     s.t = 0;
     s.ep_sum = 0.0;
     s.ep_len = 0;
     int cardinal = choice(g, P.cardinal);
-    int sx, sy, ex, ey;
-    if (cardinal == 0) { sx = 0; sy = g.integers(0, G); ex = G - 1; ey = g.integers(0, G); }
-    else if (cardinal == 1) { sx = G - 1; sy = g.integers(0, G); ex = 0; ey = g.integers(0, G); }
-    else if (cardinal == 2) { sx = g.integers(0, G); sy = 0; ex = g.integers(0, G); ey = G - 1; }
-    else { sx = g.integers(0, G); sy = G - 1; ex = g.integers(0, G); ey = 0; }
-    int len = generate_path(g, W, sx, sy, ex, ey);
-    if (len < 0) {
-        atomicOr(io.err, 2);
-        len = 0;
-    }
-    uint64_t pm = 0;
-    for (int k = 0; k < len; ++k) pm |= 1ull << W.out(k);
+    PathReq r;
+    r.need = 1;
+    if (cardinal == 0) { r.sx = 0; r.sy = g.integers(0, G); r.ex = G - 1; r.ey = g.integers(0, G); }
+    else if (cardinal == 1) { r.sx = G - 1; r.sy = g.integers(0, G); r.ex = 0; r.ey = g.integers(0, G); }
+    else if (cardinal == 2) { r.sx = g.integers(0, G); r.sy = 0; r.ex = g.integers(0, G); r.ey = G - 1; }
+    else { r.sx = g.integers(0, G); r.sy = G - 1; r.ex = g.integers(0, G); r.ey = 0; }
+    return r;
+}
+__device__ __forceinline__ void mp_post_reset(const MysteryParams& P, MysteryCore& s, const PathReq& r, int len, uint64_t pm, MysteryDesc& d) {
+    const int sx = r.sx, sy = r.sy, ex = r.ex, ey = r.ey;
     s.path_mask = pm;
     s.visited_mask = 0;
     s.path_len = (uint8_t)len;
@@ -309,10 +330,35 @@ __device__ void mp_reset(const MysteryParams& P, const MysteryIO& io, const Path
     d.goal_on = P.show_goal ? 1 : 0; d.goal_x = (uint8_t)ex; d.goal_y = (uint8_t)ey;
     d.origin_on = P.show_origin ? 1 : 0; d.origin_x = (uint8_t)sx; d.origin_y = (uint8_t)sy;
 }
+// All 64 lanes, converged: one path per requesting lane, generated by the whole wave on a broadcast copy of that
+// lane's RNG stream; the requester receives the stream back together with the path mask and length.
+__device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, int& len_out, uint64_t& pm_out) {
+    const int lane = threadIdx.x & 63;
+    uint64_t todo = __ballot(req.need != 0);
+    while (todo) {
+        const int L = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        Pcg bg = bcast(g, L);
+        int node = 0;
+        uint64_t pm = 0;
+        int len = coop_path(bg, W, bcast(req.sx, L), bcast(req.sy, L), bcast(req.ex, L), bcast(req.ey, L), node, pm);
+        if (len < 0) {
+            if (lane == 0) atomicOr(err, 2);
+            len = 0;
+            pm = 0;
+        }
+        if (lane == L) {
+            g = bg;
+            len_out = len;
+            pm_out = pm;
+        }
+    }
+}
 
-__device__ void mp_step(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
-                        const int32_t* actions, float* reward_out, uint8_t* done_out, const mg_info_buffers& info,
-                        int autoreset, MysteryDesc& d) {
+// MysteryPathEnv.step (mystery_path.py:202-276).  Returns true if the instance finished and is to be reset in this call
+// (the caller then runs mp_pre_reset / serve_mp / mp_post_reset); otherwise the frame descriptor is filled here.
+__device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, const int32_t* actions, float* reward_out,
+                        uint8_t* done_out, const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
     double reward = 0.0;
     bool done = false;
     int success = 0;
@@ -379,21 +425,18 @@ __device__ void mp_step(const MysteryParams& P, const MysteryIO& io, const PathW
     }
     reward_out[i] = (float)reward;
     done_out[i] = done ? 1 : 0;
-    if (done && autoreset) {
-        mp_reset(P, io, W, s, g, d);
-        rng_dirty = true;
-    } else {
-        memset(&d, 0, sizeof(d));
-        d.valid = 1;
-        d.sprite = s.rot8;
-        d.sx = (int16_t)(s.ax - P.sprite_dim / 2);
-        d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
-        d.cross_on = s.cross_on;
-        d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
-        d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
-        d.goal_on = P.show_goal ? 1 : 0; d.goal_x = s.ex; d.goal_y = s.ey;
-        d.origin_on = P.show_origin ? 1 : 0; d.origin_x = s.sx; d.origin_y = s.sy;
-    }
+    if (done && autoreset) return true;
+    memset(&d, 0, sizeof(d));
+    d.valid = 1;
+    d.sprite = s.rot8;
+    d.sx = (int16_t)(s.ax - P.sprite_dim / 2);
+    d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
+    d.cross_on = s.cross_on;
+    d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
+    d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
+    d.goal_on = P.show_goal ? 1 : 0; d.goal_x = s.ex; d.goal_y = s.ey;
+    d.origin_on = P.show_origin ? 1 : 0; d.origin_x = s.sx; d.origin_y = s.sy;
+    return false;
 }
 
 // ============================================ endless ============================================
@@ -403,36 +446,48 @@ __device__ __forceinline__ uint8_t* seg_ptr(const MysteryIO& io, int i, int seg)
 __device__ __forceinline__ int node_x(int seg, uint8_t b) { return seg * (G + 1) + (b & 7); }
 __device__ __forceinline__ int node_y(uint8_t b) { return (b >> 3) & 7; }
 
-// EndlessMysteryPath.add_path_segment
-__device__ void emp_add_segment(const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g) {
-    int sy;
-    if (!s.have_start) {
-        sy = g.integers(0, G);
-        s.have_start = 1;
-    } else {
-        sy = s.end_y;
+// EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604), served by the whole wave: every lane passes the number
+// of segments its instance still needs (3 at reset, 1 when the agent enters the last-but-one segment, else 0).  All 64
+// lanes, converged.  The finished path is staged in LDS and written to the instance's segment store by the requester.
+__device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want, MysteryCore& s, Pcg& g) {
+    const int lane = threadIdx.x & 63;
+    int todo_n = want;
+    for (;;) {
+        const uint64_t todo = __ballot(todo_n > 0);
+        if (!todo) break;
+        const int L = __ffsll((unsigned long long)todo) - 1;
+        Pcg bg = bcast(g, L);
+        const int have = bcast((int)s.have_start, L), endy = bcast((int)s.end_y, L);
+        const int sy = have ? endy : bg.integers(0, G);
+        const int ey = bg.integers(0, G);
+        int node = 0;
+        uint64_t pm = 0;
+        int len = coop_path(bg, W, 0, sy, G - 1, ey, node, pm);
+        if (len < 0) {
+            if (lane == 0) atomicOr(io.err, 2);
+            len = 0;
+        }
+        uint8_t* stage = W.stage();
+        if (lane < len) {  // reference order: start first; our list is END first
+            const int x = node / G, y = node - x * G;
+            stage[len - 1 - lane] = (uint8_t)(x | (y << 3));
+        }
+        if (lane == L) {
+            g = bg;
+            s.have_start = 1;
+            s.end_y = (int8_t)ey;
+            if (s.num_seg >= MAX_SEG) {
+                atomicOr(io.err, 4);
+            } else {
+                uint8_t* sp = seg_ptr(io, i, s.num_seg);
+                for (int k = 0; k < len; ++k) sp[1 + k] = stage[k];
+                sp[1 + len] = (uint8_t)(7 | (ey << 3));  // transition node at x = 8*seg + 7
+                sp[0] = (uint8_t)(len + 1);
+                s.num_seg++;
+            }
+            todo_n--;
+        }
     }
-    int ey = g.integers(0, G);
-    s.end_y = (int8_t)ey;
-    int len = generate_path(g, W, 0, sy, G - 1, ey);
-    if (len < 0) {
-        atomicOr(io.err, 2);
-        len = 0;
-    }
-    if (s.num_seg >= MAX_SEG) {
-        atomicOr(io.err, 4);
-        return;
-    }
-    uint8_t* sp = seg_ptr(io, i, s.num_seg);
-    int n = 0;
-    for (int k = len - 1; k >= 0; --k) {
-        int pk = W.out(k);
-        int x = pk / G, y = pk - x * G;
-        sp[1 + n++] = (uint8_t)(x | (y << 3));
-    }
-    sp[1 + n++] = (uint8_t)(7 | (ey << 3));  // transition node at x = 8*seg + 7
-    sp[0] = (uint8_t)n;
-    s.num_seg++;
 }
 
 __device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float* gt) {
@@ -500,13 +555,15 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
     }
 }
 
-__device__ void emp_reset(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g, MysteryDesc& d, float* gt) {
+// EndlessMysteryPathEnv.reset (endless_mystery_path.py:195-280) around the three initial segments (serve_emp)
+__device__ __forceinline__ void emp_pre_reset(MysteryCore& s) {
     s.t = 0;
     s.ep_sum = 0.0;
     s.ep_len = 0;
     s.num_seg = 0;
     s.have_start = 0;
-    for (int k = 0; k < 3; ++k) emp_add_segment(io, W, i, s, g);
+}
+__device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, MysteryDesc& d, float* gt) {
     uint8_t* s0 = seg_ptr(io, i, 0);
     s0[1] |= 1u << 6;  // the first node of the path shall not yield any reward
     s.sx = (uint8_t)node_x(0, s0[1]);
@@ -532,13 +589,11 @@ __device__ void emp_reset(const MysteryParams& P, const MysteryIO& io, const Pat
     if (P.show_stamina) d.stamina_red = 0;
 }
 
-__device__ void emp_step(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int i, MysteryCore& s, Pcg& g, bool& rng_dirty,
-                         const int32_t* actions, float* reward_out, uint8_t* done_out, float* gt,
-                         const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
+// EndlessMysteryPathEnv.step (endless_mystery_path.py:282-444), first part: move; returns 1 if a new segment is due
+// (`current_segment > num_segments - 2`, :333-335), which the wave then generates before the second part runs.
+__device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, const int32_t* actions, int& nx, int& ny) {
     int a = actions[i];
     int a0 = a == 1 ? 2 : 0, a1 = a == 2 ? 1 : (a == 3 ? 2 : 0);
-    double reward = 0.0;
-    bool done = false;
     if (!s.off) {
         int before = s.ax;
         move_agent(P, s, a0, a1, false);
@@ -549,13 +604,17 @@ __device__ void emp_step(const MysteryParams& P, const MysteryIO& io, const Path
         move_agent(P, s, 0, 0, false);
         s.camera_x = P.camera_offset;
     }
-    int nx = floordiv_pos(s.ax, P.tile), ny = floordiv_pos(s.ay, P.tile);
+    nx = floordiv_pos(s.ax, P.tile);
+    ny = floordiv_pos(s.ay, P.tile);
     s.cur_seg = nx / (G + 1);
-    int seg = s.cur_seg;
-    if (s.cur_seg > s.num_seg - 2) {
-        emp_add_segment(io, W, i, s, g);
-        rng_dirty = true;
-    }
+    return s.cur_seg > s.num_seg - 2 ? 1 : 0;
+}
+// second part; returns true if the instance finished and is to be reset in this call
+__device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
+                           uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
+    double reward = 0.0;
+    bool done = false;
+    const int seg = s.cur_seg;
     bool on_path = false;
     if (seg < s.num_seg) {
         uint8_t* sp = seg_ptr(io, i, seg);
@@ -634,12 +693,9 @@ __device__ void emp_step(const MysteryParams& P, const MysteryIO& io, const Path
     }
     reward_out[i] = (float)reward;
     done_out[i] = done ? 1 : 0;
-    if (done && autoreset) {
-        emp_reset(P, io, W, i, s, g, d, gt);
-        rng_dirty = true;
-    } else {
-        emp_fill_desc(P, io, i, s, d, nx);
-    }
+    if (done && autoreset) return true;
+    emp_fill_desc(P, io, i, s, d, nx);
+    return false;
 }
 
 __global__ __launch_bounds__(256) void mystery_init_kernel(int n, MysteryCore* core) {
@@ -650,47 +706,105 @@ __global__ __launch_bounds__(256) void mystery_init_kernel(int n, MysteryCore* c
     core[i] = s;
 }
 
+// Both kernels keep every lane of a wave alive to the end (lanes beyond n or masked out simply request nothing):
+// the path service needs converged waves.
+// Instance -> lane mapping: only the first `lpw` lanes of a wave carry instances (lpw = 64, 32, ..., 4), the others are
+// pure helpers of the path service.  A wave serves its requests one after another, so a workload whose instances
+// reset often (Endless Mystery Path under a random policy: ~2.4 resets x 3 segments per 64 instances and step) is
+// spread over more, shorter-lived waves; 32,768 instances are only 512 full waves on 1,024 SIMDs anyway.
+__device__ __forceinline__ int instance_of_lane(int lpw, bool& worker) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    worker = lane < lpw;
+    return wave * lpw + lane;
+}
+
 __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds,
-                                                            const uint8_t* mask, float* gt) {
+                                                            const uint8_t* mask, float* gt, int lpw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem, (int)threadIdx.x};
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    if (mask && !mask[i]) {
-        io.desc[i].valid = 0;
-        return;
-    }
+    const PathWS W{smem};
+    bool worker;
+    const int i = instance_of_lane(lpw, worker);
+    const bool in_range = worker && i < P.n;
+    const bool active = in_range && !(mask && !mask[i]);
+    if (in_range && !active) io.desc[i].valid = 0;
+    const int ii = in_range ? i : 0;
     Pcg g;
-    if (seeds) g.seed((uint64_t)seeds[i]);
-    else g.load(io.rng, i);
-    MysteryCore s = io.core[i];
+    MysteryCore s;
     MysteryDesc d;
-    if (P.endless) emp_reset(P, io, W, i, s, g, d, gt ? gt + 3 * i : nullptr);
-    else mp_reset(P, io, W, s, g, d);
-    io.core[i] = s;
-    g.store(io.rng, i);
-    io.desc[i] = d;
+    if (active) {
+        if (seeds) g.seed((uint64_t)seeds[i]);
+        else g.load(io.rng, i);
+        s = io.core[i];
+    } else {
+        g.state = g.inc = 0; g.buf = 0; g.has = false;
+        memset(&s, 0, sizeof(s));
+    }
+    if (P.endless) {
+        if (active) emp_pre_reset(s);
+        serve_emp(io, W, ii, active ? 3 : 0, s, g);
+        if (active) emp_post_reset(P, io, i, s, d, gt ? gt + 3 * i : nullptr);
+    } else {
+        PathReq req;
+        req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
+        if (active) req = mp_pre_reset(P, s, g);
+        int len = 0;
+        uint64_t pm = 0;
+        serve_mp(W, req, g, io.err, len, pm);
+        if (active) mp_post_reset(P, s, req, len, pm, d);
+    }
+    if (active) {
+        io.core[i] = s;
+        g.store(io.rng, i);
+        io.desc[i] = d;
+    }
 }
 
 __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions,
                                                            float* reward_out, uint8_t* done_out, float* gt,
-                                                           mg_info_buffers info, int autoreset) {
+                                                           mg_info_buffers info, int autoreset, int lpw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem, (int)threadIdx.x};
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    MysteryCore s = io.core[i];
+    const PathWS W{smem};
+    bool worker;
+    const int i = instance_of_lane(lpw, worker);
+    const bool active = worker && i < P.n;
+    const int ii = active ? i : 0;
+    MysteryCore s;
     Pcg g;
-    g.load(io.rng, i);
-    bool rng_dirty = false;
     MysteryDesc d;
-    if (P.endless) emp_step(P, io, W, i, s, g, rng_dirty, actions, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
-    else mp_step(P, io, W, i, s, g, rng_dirty, actions, reward_out, done_out, info, autoreset, d);
-    if (rng_dirty) g.store(io.rng, i);
-    io.core[i] = s;
-    io.desc[i] = d;
+    if (active) {
+        s = io.core[i];
+        g.load(io.rng, i);
+    } else {
+        memset(&s, 0, sizeof(s));
+        g.state = g.inc = 0; g.buf = 0; g.has = false;
+    }
+    bool reset_me = false;
+    if (P.endless) {
+        int nx = 0, ny = 0, want = 0;
+        if (active) want = emp_step_a(P, i, s, actions, nx, ny);
+        serve_emp(io, W, ii, want, s, g);
+        if (active) reset_me = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+        if (reset_me) emp_pre_reset(s);
+        serve_emp(io, W, ii, reset_me ? 3 : 0, s, g);
+        if (reset_me) emp_post_reset(P, io, i, s, d, gt ? gt + 3 * i : nullptr);
+    } else {
+        if (active) reset_me = mp_step(P, i, s, actions, reward_out, done_out, info, autoreset, d);
+        PathReq req;
+        req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
+        if (reset_me) req = mp_pre_reset(P, s, g);
+        int len = 0;
+        uint64_t pm = 0;
+        serve_mp(W, req, g, io.err, len, pm);
+        if (reset_me) mp_post_reset(P, s, req, len, pm, d);
+    }
+    if (active) {
+        g.store(io.rng, i);  // unchanged streams are rewritten with the same words
+        io.core[i] = s;
+        io.desc[i] = d;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -773,7 +887,7 @@ class MysteryFamily : public Family {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;
-        hipLaunchKernelGGL(mystery_reset_kernel, dim3((n_ + 255) / 256), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, gt_dim() ? gt : nullptr);
+        hipLaunchKernelGGL(mystery_reset_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, gt_dim() ? gt : nullptr, lpw());
         raster(obs, s);
     }
 
@@ -784,8 +898,8 @@ class MysteryFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        hipLaunchKernelGGL(mystery_step_kernel, dim3((n_ + 255) / 256), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
-                           gt_dim() ? gt : nullptr, ib, autoreset);
+        hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
+                           gt_dim() ? gt : nullptr, ib, autoreset, lpw());
         prof.end(0, s);
         prof.begin(1, s);
         raster(obs, s);
@@ -806,6 +920,16 @@ class MysteryFamily : public Family {
     }
 
    private:
+    // instance-carrying lanes per wave (see instance_of_lane); MEMGYM_MYSTERY_LPW overrides for tuning
+    int lpw() const {
+        static const int forced = [] {
+            const char* e = getenv("MEMGYM_MYSTERY_LPW");
+            return e ? atoi(e) : 0;
+        }();
+        if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+        return P_.endless ? 8 : 16;  // measured: profiles/r01e_logic_tails.md
+    }
+    int blocks() const { const int per_block = 4 * lpw(); return (n_ + per_block - 1) / per_block; }
     MysteryIO io() {
         MysteryIO o;
         o.core = core_.p;
