@@ -262,6 +262,30 @@ class MemoryGymEnv:
             self.ground_truth_space = self.vec.ground_truth_space
         self.metadata = self.vec.metadata
         self.render_mode = render_mode
+        # one device->host round trip per call: pinned staging buffers, asynchronous copies, a single stream sync
+        self._h_obs = torch.empty(self.vec.obs.shape[1:], dtype=self.vec.obs.dtype).pin_memory()
+        self._h_rd = torch.empty(2, dtype=torch.float32).pin_memory()
+        self._h_gt = torch.empty(max(self.vec.gt_dim, 1), dtype=torch.float32).pin_memory()
+        self._h_vec = torch.empty(self.vec.vec_dim, dtype=torch.float32).pin_memory() if self.vec.vec_dim else None
+        self._d_rd = torch.empty(2, dtype=torch.float32, device=self.vec.device)
+
+    def _fetch(self, obs, reward=None, done=None):
+        """Copies obs (+ reward, done, ground truth) of the single instance to the host with one synchronisation."""
+        vis = obs["visual_observation"] if isinstance(obs, dict) else obs
+        self._h_obs.copy_(vis[0], non_blocking=True)
+        if self._h_vec is not None:
+            self._h_vec.copy_(obs["vector_observation"][0], non_blocking=True)
+        if reward is not None:
+            self._d_rd[0] = reward[0]
+            self._d_rd[1] = done[0]
+            self._h_rd.copy_(self._d_rd, non_blocking=True)
+        if self.vec.gt_dim:
+            self._h_gt.copy_(self.vec.gt[0], non_blocking=True)
+        torch.cuda.current_stream(self.vec.device).synchronize()
+        o = self._h_obs.numpy().copy()
+        if self._h_vec is not None:
+            o = {"visual_observation": o, "vector_observation": self._h_vec.numpy().copy()}
+        return o
 
     @property
     def max_episode_steps(self):
@@ -275,24 +299,26 @@ class MemoryGymEnv:
 
     def reset(self, seed=None, return_info=True, options=None):
         obs, info = self.vec.reset(seed=seed, options=options)
+        o = self._fetch(obs)
         out = {}
         if "ground_truth" in info:
-            out["ground_truth"] = info["ground_truth"][0].double().cpu().numpy()
-        return self._first(obs), out
+            out["ground_truth"] = self._h_gt.numpy().astype(np.float64)
+        return o, out
 
     def step(self, action):
         a = np.atleast_1d(np.asarray(action)).reshape(1, -1)
         obs, reward, done, _, info = self.vec.step(a)
-        d = bool(done[0].item())
+        o = self._fetch(obs, reward, done)
+        r, d = float(self._h_rd[0]), bool(self._h_rd[1] != 0)
         out = {}
-        if d:
+        if d:  # end of episode (rare): the reference's terminal info dict
             out["reward"] = float(info["reward"][0].item())
             out["length"] = int(info["length"][0].item())
             for nm in self.vec.info_names:
                 out[nm] = float(info[nm][0].item())
         if "ground_truth" in info:
-            out["ground_truth"] = info["ground_truth"][0].double().cpu().numpy()
-        return self._first(obs), float(reward[0].item()), d, False, out
+            out["ground_truth"] = self._h_gt.numpy().astype(np.float64)
+        return o, r, d, False, out
 
     def render(self):
         return self.vec.render()[0].cpu().numpy()
