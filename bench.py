@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--env", default="MortarMayhem-Grid-v0")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
-    ap.add_argument("--obs-format", default="u8_xyc", choices=["u8_xyc", "f32_chw", "f16_chw"],
+    ap.add_argument("--obs-format", default="u8_xyc", choices=["u8_xyc", "f32_chw", "f16_chw", "bf16_chw"],
                     help="raster stream-out format; the BASELINE.json metric is quoted on the default (the reference's uint8 obs)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of obs/reward/done to rank 0 every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +126,7 @@ def main():
     n_local = args.envs_per_gpu or DEFAULT_ENVS[env_id]
     n_total = n_local * world
     env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank, obs_format=args.obs_format)
-    obs_elem = {"u8_xyc": 1, "f32_chw": 4, "f16_chw": 2}[args.obs_format]
+    obs_elem = {"u8_xyc": 1, "f32_chw": 4, "f16_chw": 2, "bf16_chw": 2}[args.obs_format]
     # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
     from memory_gym_amd.dist import gather_to_rank0, shard_seeds
     seeds = shard_seeds(n_total, rank, world, base_seed=0, device=dev)

@@ -105,7 +105,7 @@ int mg_set_option(mg_env* env, const char* key, const double* values, int n) {
 
 int mg_set_obs_format(mg_env* env, int format) {
     return guarded(env, [&] {
-        if (format != MG_OBS_U8_XYC && format != MG_OBS_F32_CYX && format != MG_OBS_F16_CYX)
+        if (format != MG_OBS_U8_XYC && format != MG_OBS_F32_CYX && format != MG_OBS_F16_CYX && format != MG_OBS_BF16_CYX)
             throw mg::OptionError{-3, "mg_set_obs_format: unknown format"};
         env->fam->obs_format = format;
     });
@@ -113,7 +113,8 @@ int mg_set_obs_format(mg_env* env, int format) {
 
 size_t mg_obs_bytes(const mg_env* env) {
     if (!env) return 0;
-    const size_t elem = env->fam->obs_format == MG_OBS_F32_CYX ? 4 : (env->fam->obs_format == MG_OBS_F16_CYX ? 2 : 1);
+    const int f = env->fam->obs_format;
+    const size_t elem = f == MG_OBS_F32_CYX ? 4 : ((f == MG_OBS_F16_CYX || f == MG_OBS_BF16_CYX) ? 2 : 1);
     return elem * 84 * 84 * 3;
 }
 

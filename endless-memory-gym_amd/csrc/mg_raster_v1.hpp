@@ -294,6 +294,19 @@ __device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha)
 // MG_OBS_F32_CYX / MG_OBS_F16_CYX: what a trainer builds from it before its CNN: value / 255 as
 // float32 / float16 in image order [c][y][x].  The transpose is done LDS-side (byte gathers, stride 252 B), the
 // global stores stay contiguous 16-B vectors.
+// 16-bit element of the half formats: IEEE half, or bfloat16 = the float32 quotient rounded to nearest even
+template <int FMT>
+__device__ __forceinline__ uint16_t to_half16(float q) {
+    if constexpr (FMT == MG_OBS_BF16_CYX) {
+        const uint32_t b = __float_as_uint(q);
+        return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+    } else {
+        union { _Float16 h; uint16_t u; } c;
+        c.h = (_Float16)q;
+        return c.u;
+    }
+}
+
 template <int FMT>
 __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
     if constexpr (FMT == MG_OBS_U8_XYC) {
@@ -319,10 +332,10 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
             dst[q] = v;
         }
     } else {
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<_Float16*>(obs) + (size_t)env * FRAME_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint16_t*>(obs) + (size_t)env * FRAME_BYTES);
         constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
         for (int q = tid; q < TOTAL; q += 256) {
-            union { _Float16 h[8]; uint4 v; } u;
+            union { uint16_t h[8]; uint4 v; } u;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int qq = 2 * q + g;
@@ -330,7 +343,7 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
                 const int c = row / SCREEN, y = row - c * SCREEN;
                 const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = (_Float16)((float)src[k * COL_BYTES] / 255.0f);
+                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = to_half16<FMT>((float)src[k * COL_BYTES] / 255.0f);
             }
             dst[q] = u.v;
         }
@@ -368,6 +381,8 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
     const int grid = n < tuned ? n : tuned;
     if (fmt == MG_OBS_F32_CYX)
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else if (fmt == MG_OBS_BF16_CYX)
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
     else if (fmt == MG_OBS_F16_CYX)
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
     else

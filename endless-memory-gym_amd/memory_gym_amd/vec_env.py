@@ -58,7 +58,7 @@ class VecMemoryGym:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
 
     OBS_FORMATS = {"u8_xyc": (0, torch.uint8, (84, 84, 3)), "f32_chw": (1, torch.float32, (3, 84, 84)),
-                   "f16_chw": (2, torch.float16, (3, 84, 84))}
+                   "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
     def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False):
         if env_id not in DEFAULTS:

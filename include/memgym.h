@@ -80,11 +80,13 @@ int mg_set_option(mg_env* env, const char* key, const double* values, int n);
  *   MG_OBS_F32_CYX  float32 [num_envs][3][84 y][84 x]  -- value / 255 in image (CHW) order, the tensor a trainer builds
  *                                                         from the observation before its CNN; 84,672 B per instance
  *   MG_OBS_F16_CYX  float16 [num_envs][3][84 y][84 x]  -- the float32 quotient rounded to nearest-even half
+ *   MG_OBS_BF16_CYX bfloat16 [num_envs][3][84 y][84 x] -- the float32 quotient rounded to nearest-even bfloat16
  * The conversion is fused into the raster kernel's stream-out (no second pass over HBM).  mg_obs_bytes returns the
  * bytes per instance of the current format. */
 #define MG_OBS_U8_XYC 0
 #define MG_OBS_F32_CYX 1
 #define MG_OBS_F16_CYX 2
+#define MG_OBS_BF16_CYX 3
 int mg_set_obs_format(mg_env* env, int format);
 size_t mg_obs_bytes(const mg_env* env);
 

@@ -21,7 +21,7 @@ def test_float_formats_match_uint8(env_id, n_act):
     import torch
 
     n, steps = 96, 80
-    envs = {f: memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format=f) for f in ("u8_xyc", "f32_chw", "f16_chw")}
+    envs = {f: memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format=f) for f in ("u8_xyc", "f32_chw", "f16_chw", "bf16_chw")}
     assert envs["f32_chw"].obs.shape == (n, 3, 84, 84) and envs["f32_chw"].obs.dtype == torch.float32
     assert envs["f16_chw"].obs.shape == (n, 3, 84, 84) and envs["f16_chw"].obs.dtype == torch.float16
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -32,6 +32,7 @@ def test_float_formats_match_uint8(env_id, n_act):
         assert np.abs(got32 - want).max() <= TOL, "step %d" % t
         assert np.array_equal(got32, want), "float32 stream-out is expected to be exact (step %d)" % t
         assert np.array_equal(obs["f16_chw"].cpu().numpy(), want.astype(np.float16)), "step %d" % t
+        assert torch.equal(obs["bf16_chw"].cpu(), torch.from_numpy(want).to(torch.bfloat16)), "bfloat16, step %d" % t
         if envs["u8_xyc"].action_dim == 1:
             a = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
         else:
