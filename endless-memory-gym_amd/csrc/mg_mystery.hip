@@ -25,7 +25,6 @@ using namespace v1;  // raster generation 1 (see mg_raster_v1.hpp)
 
 constexpr int G = 7;             // grid_dim
 constexpr int SEG_STRIDE = 52;   // bytes per stored segment: [0] = length, [1..50] nodes
-constexpr int SEG_NODES = 50;
 constexpr int MAX_SEG = 128;
 constexpr int MAX_FALL = 128;
 constexpr int ST_CROSS = 8;
