@@ -76,6 +76,66 @@ __global__ __launch_bounds__(256) void v_gather_copy(u32x4* out, size_t nvec, co
     const unsigned t = desc[4 * f + 1] & 31u;
     out[v] = templ[(size_t)t * FRAME_VEC + k];
 }
+// the same without the descriptor: every frame copies template 0 (one L2-resident 21 KB block, no dependent load chain)
+__global__ __launch_bounds__(256) void v_gather_copy_t0(u32x4* out, size_t nvec, const u32x4* templ) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const unsigned k = (unsigned)(v % FRAME_VEC);
+    out[v] = templ[k];
+}
+// descriptor and a speculative template-0 vector requested together; the real template only if it differs (25 %)
+__global__ __launch_bounds__(256) void v_gather_copy_spec(u32x4* out, size_t nvec, const unsigned* desc, const u32x4* templ) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const unsigned f = (unsigned)(v / FRAME_VEC), k = (unsigned)(v - (size_t)f * FRAME_VEC);
+    const unsigned t = desc[4 * f + 1] & 31u;
+    u32x4 val = templ[k];
+    if (t >= 19) val = templ[(size_t)t * FRAME_VEC + k];
+    out[v] = val;
+}
+// descriptor through the scalar cache: the wave's first frame index is uniform, lanes past a frame boundary use f0 + 1
+typedef const unsigned __attribute__((address_space(4))) * cuptr;
+__global__ __launch_bounds__(256) void v_gather_copy_scalar(u32x4* out, size_t nvec, const unsigned* desc, const u32x4* templ, int nframes) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const unsigned f = (unsigned)(v / FRAME_VEC), k = (unsigned)(v - (size_t)f * FRAME_VEC);
+    const unsigned f0 = __builtin_amdgcn_readfirstlane(f);
+    cuptr d = (cuptr)desc;
+    const unsigned t0 = d[4 * f0 + 1] & 31u, t1 = d[4 * (f0 + 1 < (unsigned)nframes ? f0 + 1 : f0) + 1] & 31u;
+    const unsigned t = f == f0 ? t0 : t1;
+    out[v] = templ[(size_t)t * FRAME_VEC + k];
+}
+// linear, K ADJACENT vectors per thread (thread writes 16 K contiguous bytes, workgroup K x 4 KB)
+template <int K>
+__global__ __launch_bounds__(256) void v_linear_adj(u32x4* out, size_t nvec) {
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (base + j < nvec) out[base + j] = (u32x4)(0x01020304u);
+}
+// gather copy with K adjacent vectors per thread and the descriptor through scalar loads
+template <int K>
+__global__ __launch_bounds__(256) void v_gather_adj(u32x4* out, size_t nvec, const unsigned* desc, const u32x4* templ, int nframes) {
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * K;
+    if (base >= nvec) return;
+    const unsigned f = (unsigned)(base / FRAME_VEC);
+    const unsigned f0 = __builtin_amdgcn_readfirstlane(f);
+    cuptr d = (cuptr)desc;
+    unsigned tt[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tt[q] = d[4 * (f0 + q < (unsigned)nframes ? f0 + q : f0) + 1] & 31u;
+    u32x4 val[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const size_t v = base + j < nvec ? base + j : nvec - 1;
+        const unsigned fj = (unsigned)(v / FRAME_VEC), k = (unsigned)(v - (size_t)fj * FRAME_VEC);
+        const unsigned t = fj == f0 ? tt[0] : (fj == f0 + 1 ? tt[1] : tt[2]);
+        val[j] = templ[(size_t)t * FRAME_VEC + k];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (base + j < nvec) out[base + j] = val[j];
+}
 // alignment probe: the same 1,323 vectors per frame, frames placed at a stride of STRIDE_VEC vectors
 template <int STRIDE_VEC>
 __global__ __launch_bounds__(256) void v_frames_stride(u32x4* out, int n) {
@@ -145,8 +205,16 @@ int main(int argc, char** argv) {
         for (int i = 0; i < n; ++i) { h[4 * i] = i; h[4 * i + 1] = (unsigned)((i * 2654435761u) >> 20) % 26; h[4 * i + 2] = h[4 * i + 3] = 0; }
         CK(hipMemcpy(desc, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemset(templ, 7, (size_t)26 * FRAME_VEC * 16));
+        run("gather copy of template 0, no descriptor", [&] { hipLaunchKernelGGL(v_gather_copy_t0, dim3((nvec + 255) / 256), dim3(256), 0, 0, out, nvec, templ); }, bytes);
+        run("gather copy, speculative template 0 + descriptor in parallel", [&] { hipLaunchKernelGGL(v_gather_copy_spec, dim3((nvec + 255) / 256), dim3(256), 0, 0, out, nvec, desc, templ); }, bytes);
+        run("gather copy, scalar descriptor, 2 adjacent vectors/thread", [&] { hipLaunchKernelGGL(v_gather_adj<2>, dim3((nvec / 2 + 255) / 256), dim3(256), 0, 0, out, nvec, desc, templ, n); }, bytes);
+        run("gather copy, scalar descriptor, 4 adjacent vectors/thread", [&] { hipLaunchKernelGGL(v_gather_adj<4>, dim3((nvec / 4 + 255) / 256), dim3(256), 0, 0, out, nvec, desc, templ, n); }, bytes);
+        run("gather copy, descriptor via scalar loads (constant AS)", [&] { hipLaunchKernelGGL(v_gather_copy_scalar, dim3((nvec + 255) / 256), dim3(256), 0, 0, out, nvec, desc, templ, n); }, bytes);
         run("gather copy: descriptor + template vector -> 1 store/thread", [&] { hipLaunchKernelGGL(v_gather_copy, dim3((nvec + 255) / 256), dim3(256), 0, 0, out, nvec, desc, templ); }, bytes);
     }
+    run("linear, 2 ADJACENT vectors/thread", [&] { hipLaunchKernelGGL(v_linear_adj<2>, dim3((nvec / 2 + 255) / 256), dim3(256), 0, 0, out, nvec); }, bytes);
+    run("linear, 4 ADJACENT vectors/thread", [&] { hipLaunchKernelGGL(v_linear_adj<4>, dim3((nvec / 4 + 255) / 256), dim3(256), 0, 0, out, nvec); }, bytes);
+    run("linear, 8 ADJACENT vectors/thread", [&] { hipLaunchKernelGGL(v_linear_adj<8>, dim3((nvec / 8 + 255) / 256), dim3(256), 0, 0, out, nvec); }, bytes);
     run("linear, 2 vectors/thread", [&] { hipLaunchKernelGGL(v_linear_k<2>, dim3((nvec + 511) / 512), dim3(256), 0, 0, out, nvec); }, bytes);
     run("linear, 3 vectors/thread", [&] { hipLaunchKernelGGL(v_linear_k<3>, dim3((nvec + 767) / 768), dim3(256), 0, 0, out, nvec); }, bytes);
     run("linear, 4 vectors/thread", [&] { hipLaunchKernelGGL(v_linear_k<4>, dim3((nvec + 1023) / 1024), dim3(256), 0, 0, out, nvec); }, bytes);
