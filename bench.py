@@ -88,6 +88,41 @@ def pygame_baseline(env_id, episodes=30):
             "sample": "%d episodes of %s, PyGame reference, 1 process" % (episodes, env_id)}
 
 
+def secondary_workloads(primary, device_index, steps=200, warmup=30):
+    """The other single-GPU BASELINE configs (C3, C4, the per-GPU shard of C5), measured the same way after the headline
+    run so that one bench line carries them; informational (the contract's `value` is the headline workload's)."""
+    import torch
+
+    import memory_gym_amd
+
+    out = []
+    for env_id, label in (("MysteryPath-v0", "C3"), ("Endless-SearingSpotlights-v0", "C4"), ("Endless-MortarMayhem-v0", "C5 per-GPU shard")):
+        if env_id == primary:
+            continue
+        n = DEFAULT_ENVS[env_id]
+        env = memory_gym_amd.make(env_id, num_envs=n, device=device_index)
+        env.reset(seed=0)
+        g = torch.Generator(device="cuda").manual_seed(99)
+        shape, hi = ((n,), 4) if env.action_dim == 1 else ((n, 2), 3)
+        acts = [torch.randint(0, hi, shape, device="cuda", generator=g, dtype=torch.int32) for _ in range(32)]
+        for k in range(warmup):
+            env.step(acts[k % 32])
+        env.set_profiling(8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            env.step(acts[k % 32])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rm, rn = env.get_profile(1)
+        lm, ln = env.get_profile(0)
+        env.close()
+        out.append({"config": label, "workload": "%s, %d envs" % (env_id, n), "value": n * steps / dt, "unit": "env steps/s",
+                    "ms_per_step": dt / steps * 1e3, "raster_avg_ms": rm / rn if rn else None, "logic_avg_ms": lm / ln if ln else None,
+                    "raster_GBps": (FRAME + 16) * n / (rm / rn * 1e-3) / 1e9 if rn else None})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +134,7 @@ def main():
                     help="raster stream-out format; the BASELINE.json metric is quoted on the default (the reference's uint8 obs)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of obs/reward/done to rank 0 every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5-shard measurements (N = 1 only)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every N-th step with HIP events (each bracketed step costs ~15 us)")
     args = ap.parse_args()
@@ -214,8 +250,14 @@ def main():
                                        "sample": "unavailable: %s" % e}
         if world == 1 and not args.no_cpu_baseline:
             out["pygame_baseline"] = pygame_baseline(env_id)
-        print(json.dumps(out))
     env.close()
+    if rank == 0:
+        if world == 1 and not args.no_secondary and args.obs_format == "u8_xyc":
+            try:
+                out["secondary_workloads"] = secondary_workloads(env_id, local_rank)
+            except Exception as e:
+                out["secondary_workloads"] = "failed: %s" % e
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
