@@ -9,9 +9,9 @@ cd $R
 mkdir -p gpurun_out
 for E in MortarMayhem-Grid-v0 MysteryPath-v0 Endless-SearingSpotlights-v0 Endless-MortarMayhem-v0; do
   S=$(echo $E | tr -d '-' | tr 'A-Z' 'a-z')
-  rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_${S}_kt -o kt -- python bench.py --env $E --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/${TAG}_${S}_kt.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/${TAG}_${S}_w -o w -- python bench.py --env $E --steps 30 --warmup 5 --no-cpu-baseline --no-events > gpurun_out/${TAG}_${S}_w.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/${TAG}_${S}_r -o r -- python bench.py --env $E --steps 30 --warmup 5 --no-cpu-baseline --no-events > gpurun_out/${TAG}_${S}_r.log 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_${S}_kt -o kt -- python bench.py --env $E --steps 200 --warmup 30 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_${S}_kt.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/${TAG}_${S}_w -o w -- python bench.py --env $E --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-events > gpurun_out/${TAG}_${S}_w.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/${TAG}_${S}_r -o r -- python bench.py --env $E --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-events > gpurun_out/${TAG}_${S}_r.log 2>&1
   {
     echo "# ${TAG} — $E (bench.py default size, 1x MI355X)"; echo
     echo "bench.py line of the kernel-trace run:"; echo '```'; grep '^{' gpurun_out/${TAG}_${S}_kt.log; echo '```'; echo
