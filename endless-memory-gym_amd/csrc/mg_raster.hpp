@@ -368,6 +368,7 @@ __device__ __forceinline__ void templ_apply_dark(const RasterCtx& R, const Templ
 //   static __device__ bool skip(cptr<Desc>);       true: leave the frame untouched (masked reset)
 //   static __device__ void prefetch(cptr<Desc>, const RasterCtx&, Pre&);   issues the loads, no LDS access
 //   static __device__ void compose(cptr<Desc>, const Pre&, const RasterCtx&);   LDS only; leaves the frame complete
+//   static __device__ void recycle(const RasterCtx&);   re-initialise per-frame LDS scratch (not the frame) after compose()
 // The descriptor is read through its (workgroup-uniform, constant address space) pointer, so every field access --
 // also array elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
 // compose() does not touch global memory (gfx9 counts loads and stores in one in-order counter, vmcnt: a load issued
@@ -452,12 +453,15 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     R.tid = threadIdx.x;
     const int tid = threadIdx.x, stride = gridDim.x;
     const cptr<typename Composer::Desc> cdescs = as_const(descs);
+    Composer::recycle(R);  // scratch state compose() expects (e.g. a zeroed hole mask); published by the barriers below
+    __syncthreads();
     for (int env = blockIdx.x; env < n; env += stride) {
         if (Composer::skip(cdescs + env) || (only && !only[env])) continue;  // `only`: per-frame filter (final observations)
         typename Composer::Pre P;
         Composer::prefetch(cdescs + env, R, P);
         Composer::compose(cdescs + env, P, R);
         __syncthreads();
+        Composer::recycle(R);  // overlaps the stream-out, saves a barrier at the start of the next compose()
         store_frame<FMT>(smem, obs, env, tid);
         __syncthreads();  // the LDS frame is reused by the next iteration
     }

@@ -115,14 +115,13 @@ struct SpotComposer {
         if (d.alpha && holes_small(d.holes, d.n_holes)) hole_fetch8(R, d.holes, d.n_holes, P.holes);
         templ_fetch(R, d.bg, P.bg);
     }
+    static __device__ __forceinline__ void recycle(const RasterCtx& R) { zero_mask(R); }
     static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
         const Desc MG_CONST_AS& d = *dp;
         const cptr<AtlasTables> T = R.T;
         const uint32_t alpha = d.alpha;
         const StampRegs<1>&agent = P.agent, &coin = P.coin, &exitp = P.exitp;
-        if (alpha) {
-            zero_mask(R);
-            __syncthreads();
+        if (alpha) {  // the hole mask is zero on entry (recycle())
             if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
             else hole_mask(R, d.holes, d.n_holes);  // radii beyond the reference's range: span table read in place
             __syncthreads();
