@@ -7,10 +7,12 @@
 //   memory_gym/pygame_assets.py         Node :438-493  EndlessMysteryPath :495-604  MysteryPath (noisy A*) :606-736
 //   memory_gym/character_controller.py  CharacterController.step :89-146
 //
-//   mystery_step_kernel : one LANE per instance.  Path following / fall-off logic; the procedural path generator
+//   mystery_step_kernel : one LANE per instance for the path following / fall-off logic.  The procedural path generator
 //                         (33 % inner walls, 4 or 8 outer walls, A* with integers(1,9) noise on every relaxation,
 //                         Python-list open/closed-set semantics incl. the reference's tie-breaking and its
-//                         `neighbor.g = g` typo) runs in the same kernel for instances that (auto-)reset.
+//                         `neighbor.g = g` typo) runs in the same kernel for instances that (auto-)reset, but
+//                         COOPERATIVELY: requests are served one at a time by the whole wave (coop_path, serve_*),
+//                         and only the first 16 (endless: 8) lanes of a wave carry instances (instance_of_lane).
 //   raster_kernel<MysteryComposer> : black frame -> goal/origin or past-path tiles -> agent sprite -> fall-off cross.
 #include <memory>
 

@@ -10,12 +10,13 @@
 //   spot_step_kernel : SIXTEEN LANES per instance (4 instances per wave).  Lane s owns spotlight slot s: float64
 //                      trajectory (lerp of lerp, un-fused multiply-add: the library is built with
 //                      -ffp-contract=off) and hit test; wave ballots collect the 16 done / hit flags of an instance.
-//                      The instance-level logic (agent, coin/exit, grid sampler, RNG, list bookkeeping) is executed
-//                      redundantly by the 16 lanes -- free under SIMD -- and stored by lane 0.  Slot arrays are
+//                      The instance-level logic (agent, coin/exit, RNG, list bookkeeping) is executed redundantly by
+//                      the 16 lanes -- free under SIMD -- and stored by lane 0; the grid sampler splits its 84 rows
+//                      over them (sample_cell).  Kernels are templated on ENDLESS.  Slot arrays are
 //                      [N][16] so the 16 lanes of an instance read one contiguous 128-byte row per field; the
 //                      Python list semantics (append / remove-while-iterating) live in a 16-nibble order word.
-//   raster_kernel<SpotComposer> : chessboard template -> coin(s)/exit -> agent -> darken(alpha, holes) -> coin(s)
-//                      shown above the dark layer -> top bar.
+//   raster_kernel<SpotComposer> (generation 2, mg_raster.hpp): hole mask -> chessboard template, coin(s)/exit, agent, each
+//                      darkened outside the holes while written -> coin(s) shown above the dark layer -> top bar.
 #include <memory>
 
 #include "mg_atlas.hpp"
