@@ -4,9 +4,9 @@ instance, reset(seed=1), 1000 random-action episodes with reset() inside the tim
 per-episode steps/s and the mean success.  Actions come from the fixed stream Generator(PCG64(12345)) so that every
 backend sees the same episode sequence.
 
-    python tools/c1_loop.py --backend oracle      # CPU restatement (any host)
-    python tools/c1_loop.py --backend hip         # single-instance adapter over libmemgym_hip.so (MI355X; latency-bound)
-    python tools/c1_loop.py --backend reference   # the PyGame reference, only if memory-gym is installed on the host
+    python tests/c1_loop.py --backend oracle      # CPU restatement (any host)
+    python tests/c1_loop.py --backend hip         # single-instance adapter over libmemgym_hip.so (MI355X; latency-bound)
+    python tests/c1_loop.py --backend reference   # the PyGame reference, only if memory-gym is installed on the host
 """
 import argparse
 import os
@@ -15,9 +15,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, os.path.join(ROOT, "endless-memory-gym_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def make(backend, env_id):
