@@ -447,6 +447,27 @@ __device__ __forceinline__ uint8_t* seg_ptr(const MysteryIO& io, int i, int seg)
 __device__ __forceinline__ int node_x(int seg, uint8_t b) { return seg * (G + 1) + (b & 7); }
 __device__ __forceinline__ int node_y(uint8_t b) { return (b >> 3) & 7; }
 
+// One 52-byte segment record in registers.  The segment store is cold in every step (the observation stream evicts
+// it), so walking it byte by byte made each access a dependent ~1 us global round trip; a record is fetched with 13
+// dword loads in flight together and then indexed in registers.
+struct SegRec {
+    uint32_t w[SEG_STRIDE / 4];
+    int seg;  // -1: nothing loaded
+    __device__ __forceinline__ void load(const MysteryIO& io, int i, int sg) {
+        if (sg == seg) return;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(seg_ptr(io, i, sg));
+#pragma unroll
+        for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = p[j];
+        seg = sg;
+    }
+    __device__ __forceinline__ uint8_t byte(int p) const {  // p = 0: node count, 1..: nodes
+        uint32_t v = w[0];
+#pragma unroll
+        for (int j = 1; j < SEG_STRIDE / 4; ++j) v = (p >> 2) == j ? w[j] : v;
+        return (uint8_t)(v >> (8 * (p & 3)));
+    }
+};
+
 // EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604), served by the whole wave: every lane passes the number
 // of segments its instance still needs (3 at reset, 1 when the agent enters the last-but-one segment, else 0).  All 64
 // lanes, converged.  The finished path is staged in LDS and written to the instance's segment store by the requester.
@@ -491,17 +512,23 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
     }
 }
 
-__device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float* gt) {
-    const uint8_t* sp = seg_ptr(io, i, s.cur_node_seg);
-    int cx = node_x(s.cur_node_seg, sp[1 + s.cur_node_idx]), cy = node_y(sp[1 + s.cur_node_idx]);
+__device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float* gt, SegRec& R) {
+    R.load(io, i, s.cur_node_seg);
+    const uint8_t cb = R.byte(1 + s.cur_node_idx);
+    int cx = node_x(s.cur_node_seg, cb), cy = node_y(cb);
     int nseg = s.cur_node_seg, nidx = s.cur_node_idx + 1;
-    if (nidx >= sp[0]) {
+    if (nidx >= R.byte(0)) {
         nseg++;
         nidx = 0;
     }
     if (nseg < s.num_seg) {
-        const uint8_t* np = seg_ptr(io, i, nseg);
-        int x = node_x(nseg, np[1 + nidx]) - cx, y = node_y(np[1 + nidx]) - cy;
+        uint8_t nb;
+        if (nseg == R.seg) {
+            nb = R.byte(1 + nidx);
+        } else {  // first node of the following segment (keeps R on the current one for the past-path walk)
+            nb = seg_ptr(io, i, nseg)[1 + nidx];
+        }
+        int x = node_x(nseg, nb) - cx, y = node_y(nb) - cy;
         if (x == 1) { s.td[0] = 1; s.td[1] = 0; s.td[2] = 0; }
         else if (y == -1) { s.td[0] = 0; s.td[1] = 1; s.td[2] = 0; }
         else if (y == 1) { s.td[0] = 0; s.td[1] = 0; s.td[2] = 1; }
@@ -513,7 +540,7 @@ __device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float*
     }
 }
 
-__device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx) {
+__device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx, SegRec& R) {
     memset(&d, 0, sizeof(d));
     d.valid = 1;
     d.sprite = s.rot8;
@@ -537,9 +564,11 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
                 if (idx < 0) {
                     seg--;
                     if (seg < 0) break;
-                    idx = seg_ptr(io, i, seg)[0] - 1;
+                    R.load(io, i, seg);
+                    idx = R.byte(0) - 1;
                 }
-                uint8_t b = seg_ptr(io, i, seg)[1 + idx];
+                R.load(io, i, seg);
+                uint8_t b = R.byte(1 + idx);
                 x = node_x(seg, b);
                 int y = node_y(b);
                 int col = x - past_x;
@@ -575,17 +604,21 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
     s.rot8 = 6;  // 270 degrees
     s.cur_node_seg = 0;
     s.cur_node_idx = 0;
-    emp_direction(io, i, s, gt);
+    SegRec R;
+    R.seg = -1;
+    emp_direction(io, i, s, gt, R);
     s.off = 0;
     s.cross_on = 0;
     s.cross_x = s.cross_y = 0;
     s.cur_seg = 0;
     s.fails = 0;
     s.n_falloff = 0;
+    s.gx = 255;  // endless: [gx, gy] = range of segments that may hold stamina flags (empty)
+    s.gy = 0;
     s.stamina = P.stamina_level;
     s.max_x = 0;
     s.tiles_visited = 0;
-    emp_fill_desc(P, io, i, s, d, s.ax / P.tile);
+    emp_fill_desc(P, io, i, s, d, s.ax / P.tile, R);
     d.cross_on = 0;
     if (P.show_stamina) d.stamina_red = 0;
 }
@@ -616,30 +649,46 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     double reward = 0.0;
     bool done = false;
     const int seg = s.cur_seg;
+    SegRec R;
+    R.seg = -1;
     bool on_path = false;
     if (seg < s.num_seg) {
         uint8_t* sp = seg_ptr(io, i, seg);
-        int n = sp[0];
-        for (int k = 0; k < n; ++k) {
-            uint8_t b = sp[1 + k];
-            if (node_x(seg, b) == nx && node_y(b) == ny) {
-                on_path = true;
-                s.cur_node_seg = seg;
-                s.cur_node_idx = k;
-                bool is_start = nx == s.sx && ny == s.sy;
-                if (!(b & 0x40) && !is_start) {
-                    reward += P.r_progress;
-                    s.tiles_visited++;
-                    b |= 0x40;
-                }
-                if (!(b & 0x80) && !is_start) {
-                    reward += P.r_dense;
-                    s.stamina = P.stamina_level;
-                    b |= 0x80;
-                }
-                sp[1 + k] = b;
-                break;
+        R.load(io, i, seg);
+        const uint32_t* w = R.w;
+        const int n = (int)(w[0] & 0xFFu);
+        const int dx = nx - seg * (G + 1);
+        const bool addressable = (unsigned)dx < 8u && (unsigned)ny < 8u;  // node bytes hold x_rel and y in 3 bits each
+        const uint32_t target = (uint32_t)(dx & 7) | ((uint32_t)(ny & 7) << 3);
+        int hit = 0;
+        uint32_t hb = 0;
+#pragma unroll
+        for (int p = 1; p < SEG_STRIDE; ++p) {  // first node (list order) on the agent's tile
+            const uint32_t b = (w[p >> 2] >> (8 * (p & 3))) & 0xFFu;
+            if (hit == 0 && p <= n && addressable && (b & 0x3Fu) == target) {
+                hit = p;
+                hb = b;
             }
+        }
+        if (hit) {
+            uint8_t b = (uint8_t)hb;
+            on_path = true;
+            s.cur_node_seg = seg;
+            s.cur_node_idx = hit - 1;
+            bool is_start = nx == s.sx && ny == s.sy;
+            if (!(b & 0x40) && !is_start) {
+                reward += P.r_progress;
+                s.tiles_visited++;
+                b |= 0x40;
+            }
+            if (!(b & 0x80) && !is_start) {
+                reward += P.r_dense;
+                s.stamina = P.stamina_level;
+                b |= 0x80;
+                s.gx = seg < s.gx ? (uint8_t)seg : s.gx;  // segments that may hold stamina flags
+                s.gy = seg > s.gy ? (uint8_t)seg : s.gy;
+            }
+            sp[hit] = b;
         }
     }
     if (!on_path) {
@@ -653,22 +702,30 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
             uint32_t* fl = io.falloff + (size_t)i * MAX_FALL;
             uint32_t key = (uint32_t)(nx & 0xFFFF) | ((uint32_t)(ny + 1024) << 16);
             bool found = false;
-            for (int k = 0; k < s.n_falloff; ++k)
-                if (fl[k] == key) {
-                    done = true;
-                    found = true;
-                    break;
-                }
+            for (int k = 0; k < s.n_falloff; k += 4) {  // four entries per load; slots >= n_falloff hold stale keys
+                const uint4 v = reinterpret_cast<const uint4*>(fl)[k >> 2];
+                found = found || v.x == key || (k + 1 < s.n_falloff && v.y == key) || (k + 2 < s.n_falloff && v.z == key) ||
+                        (k + 3 < s.n_falloff && v.w == key);
+            }
+            if (found) done = true;
             if (!found) {
                 if (s.n_falloff < MAX_FALL) fl[s.n_falloff++] = key;
                 else atomicOr(io.err, 8);
             }
         }
-        for (int q = 0; q < s.num_seg; ++q) {  // reset all stamina flags
-            uint8_t* sp = seg_ptr(io, i, q);
-            int n = sp[0];
-            for (int k = 0; k < n; ++k) sp[1 + k] &= 0x7F;
+        // reset all stamina flags -- only segments visited since the last reset can hold any; whole records at a time
+        // (bytes past the node count are unused)
+        for (int q = s.gx; q <= (int)s.gy && q < s.num_seg; ++q) {
+            uint32_t* wp = reinterpret_cast<uint32_t*>(seg_ptr(io, i, q));
+            uint32_t w[SEG_STRIDE / 4];
+#pragma unroll
+            for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = wp[j];
+            wp[0] = w[0] & 0x7F7F7FFFu;  // byte 0 is the node count
+#pragma unroll
+            for (int j = 1; j < SEG_STRIDE / 4; ++j) wp[j] = w[j] & 0x7F7F7F7Fu;
         }
+        s.gx = 255;
+        s.gy = 0;
         s.stamina = P.stamina_level;
     } else {
         s.cross_on = 0;
@@ -681,7 +738,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     if (s.stamina == 0) done = true;
     s.t++;
     if (s.t == P.max_steps) done = true;
-    emp_direction(io, i, s, gt);
+    emp_direction(io, i, s, gt, R);
     if (nx > s.max_x && on_path) s.max_x = nx;
     s.ep_sum += reward;
     s.ep_len++;
@@ -695,7 +752,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     reward_out[i] = (float)reward;
     done_out[i] = done ? 1 : 0;
     if (done && autoreset) return true;
-    emp_fill_desc(P, io, i, s, d, nx);
+    emp_fill_desc(P, io, i, s, d, nx, R);
     return false;
 }
 
