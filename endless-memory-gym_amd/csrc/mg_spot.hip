@@ -855,7 +855,12 @@ class SpotFamily : public Family {
         else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
         else if (key == "agent_visible") must_be(v[0] == 0.0);
         else if (key == "sample_agent_position") B(P_.sample_agent_position);
-        else if (key == "show_last_action") B(P_.show_last_action);
+        else if (key == "show_last_action") {
+            B(P_.show_last_action);
+            // False crashes the ENDLESS reference at its first step (endless_searing_spotlights.py:422 reads action_colors,
+            // which :343 only creates when the flag is set); the finite env guards the use (searing_spotlights.py:465)
+            if (e) must_be(P_.show_last_action != 0);
+        }
         else if (key == "show_last_positive_reward") B(P_.show_last_positive_reward);
         else if (key == "reward_inside_spotlight") P_.r_inside = v[0];
         else if (key == "reward_outside_spotlight") P_.r_outside = v[0];

@@ -166,7 +166,7 @@ def snap_ss(env, info):
              disp_sprite=si, disp_x=dx, disp_y=dy,
              health=env.current_agent_health, alpha=env.spotlight_surface.get_alpha(),
              spawn_timer=env.spawn_timer, n_spots=len(env.spotlights), t=env.t,
-             la0=int(env.last_action[0]), la1=int(env.last_action[1]), last_reward=env.last_reward,
+             la0=int(env.last_action[0]), la1=int(env.last_action[1]), last_reward=getattr(env, "last_reward", np.nan),
              bg_red=int(env.bg is env.red_background_surface), coins_collected=env.coins_collected)
     if endless:
         d.update(coin_t=env.coin_t, coin_x=env.coin.location[0], coin_y=env.coin.location[1])
@@ -459,7 +459,33 @@ def pack(sessions_rows, sessions_meta):
     return out
 
 
+def main_fuzz():
+    """`--fuzz`: sessions with seeded random option dictionaries (tests/option_fuzz.py) -> tests/golden/fuzz_<env>.npz."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from option_fuzz import CASES
+    for env_id, gen in CASES:
+        rng = np.random.Generator(np.random.PCG64(1000 + sum(map(ord, env_id))))
+        rows_all, meta = [], []
+        for trial in range(6):
+            options = gen(rng, env_id)
+            try:
+                rows = run_session(env_id, 100 + trial, options, 0.9, 160)
+            except Exception as e:  # an option set the reference itself cannot run is not a fixture
+                print(env_id, "trial", trial, "skipped:", type(e).__name__, e)
+                continue
+            rows_all.append(rows)
+            n_eps = sum(r["done"] for r in rows)
+            meta.append(dict(seed=100 + trial, options=options, skill=0.9, n_steps=160, episodes=n_eps))
+            print(env_id, "fuzz trial", trial, "rows", len(rows), "episodes", n_eps)
+        out = pack(rows_all, meta)
+        fn = os.path.join(HERE, "fuzz_" + env_id.replace("-", "_") + ".npz")
+        np.savez_compressed(fn, **out)
+        print("  ->", fn, os.path.getsize(fn) // 1024, "KiB")
+
+
 def main():
+    if "--fuzz" in sys.argv:
+        return main_fuzz()
     only = sys.argv[1:] or list(SESSIONS)
     for env_id in only:
         rows_all, meta = [], []

@@ -1,0 +1,65 @@
+"""Seeded generators of reset-option dictionaries inside the ranges the HIP path and the oracle support; shared by
+tests/test_gpu_option_fuzz.py (HIP vs oracle) and tests/golden/make_golden.py (oracle vs the reference: "fuzz" sessions)."""
+import numpy as np  # noqa: F401
+
+
+def _lst(rng, lo, hi, kmax=3):
+    k = int(rng.integers(1, kmax + 1))
+    return sorted({int(v) for v in rng.integers(lo, hi + 1, k)})
+
+
+def _rew(rng):
+    return float(rng.choice([0.0, 0.1, -0.1, 0.25, 1.0, -0.01, 2.0]))
+
+
+def mortar_opts(rng, env_id):
+    b = env_id.startswith("MortarMayhemB")
+    endless = env_id.startswith("Endless")
+    grid = "Grid" in env_id
+    o = dict(allowed_commands=int(rng.integers(4, 10)), explosion_duration=_lst(rng, 1, 6), explosion_delay=_lst(rng, 2, 18),
+             visual_feedback=bool(rng.integers(0, 2)), reward_command_failure=_rew(rng), reward_command_success=_rew(rng))
+    if not b:
+        o.update(command_show_duration=_lst(rng, 1, 4), command_show_delay=_lst(rng, 0, 3))
+    if endless:
+        o.update(max_steps=int(rng.choice([-1, 60, 150])), initial_command_count=int(rng.integers(1, 5)), reward_new_command_success=_rew(rng))
+    else:
+        o.update(arena_size=int(rng.integers(2, 7)), command_count=_lst(rng, 1, 12), reward_episode_success=_rew(rng))
+    if not grid:
+        o.update(agent_speed=float(rng.choice([2.0, 3.0, 4.0])))
+    return o
+
+
+def mystery_opts(rng, env_id):
+    if env_id == "Endless-MysteryPath-v0":
+        return dict(max_steps=int(rng.choice([-1, 80, 200])), stamina_level=int(rng.integers(6, 30)), show_stamina=bool(rng.integers(0, 2)),
+                    show_past_path=bool(rng.integers(0, 2)), visual_feedback=bool(rng.integers(0, 2)), reward_fall_off=_rew(rng),
+                    reward_path_progress=_rew(rng), reward_path_progress_dense=_rew(rng), reward_step=_rew(rng),
+                    camera_offset_scale=float(rng.choice([3.0, 5.0, 7.0])))
+    o = dict(max_steps=int(rng.integers(20, 200)), cardinal_origin_choice=_lst(rng, 0, 3, 4), show_origin=bool(rng.integers(0, 2)),
+             show_goal=bool(rng.integers(0, 2)), visual_feedback=bool(rng.integers(0, 2)), reward_goal=_rew(rng), reward_fall_off=_rew(rng),
+             reward_path_progress=_rew(rng), reward_step=_rew(rng))
+    return o
+
+
+def spot_opts(rng, env_id):
+    o = dict(initial_spawns=int(rng.integers(1, 6)), spot_min_radius=float(rng.choice([7.5, 8.0, 9.0])), spot_max_radius=float(rng.choice([11.0, 13.75])),
+             spot_min_speed=float(rng.choice([0.0025, 0.01])), spot_max_speed=float(rng.choice([0.02, 0.0075 * 4])), spot_damage=float(rng.choice([0.5, 1.0, 2.0])),
+             visual_feedback=bool(rng.integers(0, 2)), light_dim_off_duration=int(rng.integers(1, 10)), light_threshold=int(rng.choice([255, 200, 128])),
+             coins_visible=bool(rng.integers(0, 2)), agent_health=int(rng.integers(3, 40)), sample_agent_position=bool(rng.integers(0, 2)),
+             show_last_positive_reward=bool(rng.integers(0, 2)), reward_inside_spotlight=_rew(rng),
+             reward_outside_spotlight=_rew(rng), reward_death=_rew(rng), reward_coin=_rew(rng))
+    if env_id.startswith("Endless"):
+        o.update(max_steps=int(rng.choice([-1, 100, 300])), steps_per_coin=int(rng.integers(30, 200)), spawn_interval=int(rng.integers(5, 60)),
+                 coin_show_duration=int(rng.integers(1, 12)))
+    else:
+        # show_last_action = False crashes the ENDLESS reference (endless_searing_spotlights.py:422 uses action_colors,
+        # which only exists when the flag is set, :343); the finite env guards the use (:465)
+        o.update(max_steps=int(rng.integers(60, 300)), num_spawns=int(rng.integers(0, 12)), num_coins=_lst(rng, 1, 4), reward_exit=_rew(rng),
+                 show_last_action=bool(rng.integers(0, 2)))
+    return o
+
+
+CASES = [("MortarMayhem-Grid-v0", mortar_opts), ("MortarMayhem-v0", mortar_opts), ("Endless-MortarMayhem-v0", mortar_opts),
+         ("MortarMayhemB-Grid-v0", mortar_opts), ("MortarMayhemB-v0", mortar_opts), ("MysteryPath-v0", mystery_opts),
+         ("MysteryPath-Grid-v0", mystery_opts), ("Endless-MysteryPath-v0", mystery_opts), ("SearingSpotlights-v0", spot_opts),
+         ("Endless-SearingSpotlights-v0", spot_opts)]

@@ -15,22 +15,23 @@ ENV_IDS = ["MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0",
            "MortarMayhemB-Grid-v0", "MortarMayhemB-v0"]
 
 
-def load(env_id):
-    return np.load(os.path.join(GOLDEN, "logic_" + env_id.replace("-", "_") + ".npz"))
+def load(env_id, kind="logic"):
+    return np.load(os.path.join(GOLDEN, kind + "_" + env_id.replace("-", "_") + ".npz"))
 
 
-def sessions(env_id):
-    z = load(env_id)
+def sessions(env_id, kind="logic"):
+    z = load(env_id, kind)
     meta = json.loads(str(z["meta"]))
-    return [(env_id, i) for i in range(len(meta))]
+    return [(env_id, i, kind) for i in range(len(meta))]
 
 
-ALL = [s for e in ENV_IDS for s in sessions(e)]
+# "logic": hand-picked sessions; "fuzz": seeded random option dictionaries (tests/option_fuzz.py, make_golden.py --fuzz)
+ALL = [s for e in ENV_IDS for s in sessions(e)] + [s for e in ENV_IDS for s in sessions(e, "fuzz")]
 
 
-@pytest.mark.parametrize("env_id,si", ALL, ids=["%s-s%d" % a for a in ALL])
-def test_replay_matches_reference(env_id, si):
-    z = load(env_id)
+@pytest.mark.parametrize("env_id,si,kind", ALL, ids=["%s-%s%d" % (a[0], a[2][0], a[1]) for a in ALL])
+def test_replay_matches_reference(env_id, si, kind):
+    z = load(env_id, kind)
     meta = json.loads(str(z["meta"]))[si]
     fields = [str(f) for f in z["fields"]]
     p = "s%d_" % si
