@@ -61,6 +61,7 @@ def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1
         if t % check_every == 0:
             got = obs.cpu().numpy()
             if not np.array_equal(got, o2):
+                env.check_errors()  # a capacity error flagged by the kernels explains a mismatch better than pixels do
                 bad = np.nonzero((got != o2).reshape(n, -1).any(1))[0]
                 px = np.argwhere((got[bad[0]] != o2[bad[0]]).any(-1))
                 raise AssertionError("%s: frame differs at step %d for envs %s; env %d: %d px, first (x,y)=%s hip=%s oracle=%s" % (

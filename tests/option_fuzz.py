@@ -49,8 +49,12 @@ def spot_opts(rng, env_id):
              show_last_positive_reward=bool(rng.integers(0, 2)), reward_inside_spotlight=_rew(rng),
              reward_outside_spotlight=_rew(rng), reward_death=_rew(rng), reward_coin=_rew(rng))
     if env_id.startswith("Endless"):
-        o.update(max_steps=int(rng.choice([-1, 100, 300])), steps_per_coin=int(rng.integers(30, 200)), spawn_interval=int(rng.integers(5, 60)),
-                 coin_show_duration=int(rng.integers(1, 12)))
+        # the HIP path holds at most 16 live spotlights per instance (error bit 1 otherwise, include/memgym.h): keep
+        # initial_spawns + lifetime / spawn_interval below that (lifetime <= 1 / spot_min_speed steps)
+        life = int(np.ceil(1.0 / o["spot_min_speed"]))
+        floor_interval = int(np.ceil(life / (14 - o["initial_spawns"])))
+        o.update(max_steps=int(rng.choice([-1, 100, 300])), steps_per_coin=int(rng.integers(30, 200)),
+                 spawn_interval=max(int(rng.integers(5, 60)), floor_interval), coin_show_duration=int(rng.integers(1, 12)))
     else:
         # show_last_action = False crashes the ENDLESS reference (endless_searing_spotlights.py:422 uses action_colors,
         # which only exists when the flag is set, :343); the finite env guards the use (:465)
