@@ -463,10 +463,14 @@ def main_fuzz():
     """`--fuzz`: sessions with seeded random option dictionaries (tests/option_fuzz.py) -> tests/golden/fuzz_<env>.npz."""
     sys.path.insert(0, os.path.dirname(HERE))
     from option_fuzz import CASES
+    # optional: --seed S --trials T --out DIR (a wider one-off hunt into a scratch directory; the committed fixtures use the defaults)
+    arg = {sys.argv[k]: sys.argv[k + 1] for k in range(len(sys.argv) - 1) if sys.argv[k].startswith("--")}
+    seed0, trials, out_dir = int(arg.get("--seed", 1000)), int(arg.get("--trials", 6)), arg.get("--out", HERE)
+    os.makedirs(out_dir, exist_ok=True)
     for env_id, gen in CASES:
-        rng = np.random.Generator(np.random.PCG64(1000 + sum(map(ord, env_id))))
+        rng = np.random.Generator(np.random.PCG64(seed0 + sum(map(ord, env_id))))
         rows_all, meta = [], []
-        for trial in range(6):
+        for trial in range(trials):
             options = gen(rng, env_id)
             try:
                 rows = run_session(env_id, 100 + trial, options, 0.9, 160)
@@ -478,7 +482,7 @@ def main_fuzz():
             meta.append(dict(seed=100 + trial, options=options, skill=0.9, n_steps=160, episodes=n_eps))
             print(env_id, "fuzz trial", trial, "rows", len(rows), "episodes", n_eps)
         out = pack(rows_all, meta)
-        fn = os.path.join(HERE, "fuzz_" + env_id.replace("-", "_") + ".npz")
+        fn = os.path.join(out_dir, "fuzz_" + env_id.replace("-", "_") + ".npz")
         np.savez_compressed(fn, **out)
         print("  ->", fn, os.path.getsize(fn) // 1024, "KiB")
 

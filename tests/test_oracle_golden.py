@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = os.environ.get("MEMGYM_GOLDEN_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 ENV_IDS = ["MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0", "MysteryPath-v0",
            "Endless-MysteryPath-v0", "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-Grid-v0",
            "MortarMayhemB-Grid-v0", "MortarMayhemB-v0"]
