@@ -196,6 +196,13 @@ int mg_poll_errors(mg_env* env, int* flags) {
     });
 }
 
+int mg_peek_errors(mg_env* env, int* flags) {
+    return guarded(env, [&] {
+        if (!flags) throw std::runtime_error("mg_peek_errors: NULL");
+        *flags = env->fam->peek_errors();
+    });
+}
+
 int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
     return guarded(env, [&] {
         if (i < 0 || i >= env->num_envs) throw std::runtime_error("mg_debug_rng: index out of range");

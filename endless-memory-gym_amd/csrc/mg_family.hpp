@@ -23,6 +23,32 @@ void set_error(const std::string& msg);
     } while (0)
 
 // RAII device array
+// One error word in pinned, coherent host memory mapped into the device's address space: kernels raise bits with a
+// system-scope atomic OR (rare path), the host reads them without touching the stream (mg_peek_errors).
+struct ErrorWord {
+    int* host = nullptr;
+    int* dev = nullptr;
+    ErrorWord() {}
+    ErrorWord(const ErrorWord&) = delete;
+    ErrorWord& operator=(const ErrorWord&) = delete;
+    ~ErrorWord() {
+        if (host) (void)hipHostFree(host);
+    }
+    void alloc() {
+        MG_HIP(hipHostMalloc((void**)&host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *host = 0;
+        MG_HIP(hipHostGetDevicePointer((void**)&dev, host, 0));
+    }
+    int peek() const { return __atomic_load_n(host, __ATOMIC_ACQUIRE); }
+    int take() { return __atomic_exchange_n(host, 0, __ATOMIC_ACQ_REL); }
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void raise_error(int* err, int bit) {
+    __hip_atomic_fetch_or(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 template <typename T>
 struct DevArray {
     T* p = nullptr;
@@ -111,6 +137,8 @@ class Family {
     virtual void debug_rng(int i, uint64_t out[6]) = 0;
     // device-side error bits accumulated since the last call (0 = none); synchronises
     virtual int poll_errors() { return 0; }
+    // the same bits as seen right now, without synchronising or clearing
+    virtual int peek_errors() { return 0; }
 };
 
 Family* make_mortar(int variant, int num_envs);

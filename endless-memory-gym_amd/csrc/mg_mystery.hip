@@ -344,7 +344,7 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
         uint64_t pm = 0;
         int len = coop_path(bg, W, bcast(req.sx, L), bcast(req.sy, L), bcast(req.ex, L), bcast(req.ey, L), node, pm);
         if (len < 0) {
-            if (lane == 0) atomicOr(err, 2);
+            if (lane == 0) raise_error(err, 2);
             len = 0;
             pm = 0;
         }
@@ -486,7 +486,7 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
         uint64_t pm = 0;
         int len = coop_path(bg, W, 0, sy, G - 1, ey, node, pm);
         if (len < 0) {
-            if (lane == 0) atomicOr(io.err, 2);
+            if (lane == 0) raise_error(io.err, 2);
             len = 0;
         }
         uint8_t* stage = W.stage();
@@ -499,7 +499,7 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
             s.have_start = 1;
             s.end_y = (int8_t)ey;
             if (s.num_seg >= MAX_SEG) {
-                atomicOr(io.err, 4);
+                raise_error(io.err, 4);
             } else {
                 uint8_t* sp = seg_ptr(io, i, s.num_seg);
                 for (int k = 0; k < len; ++k) sp[1 + k] = stage[k];
@@ -576,7 +576,7 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
                     int cell = col * G + y;
                     d.tile_mask[cell >> 6] |= 1ull << (cell & 63);
                 } else if (col >= 16) {
-                    atomicOr(io.err, 16);
+                    raise_error(io.err, 16);
                 }
                 if (x == past_x) break;
                 idx--;
@@ -710,7 +710,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
             if (found) done = true;
             if (!found) {
                 if (s.n_falloff < MAX_FALL) fl[s.n_falloff++] = key;
-                else atomicOr(io.err, 8);
+                else raise_error(io.err, 8);
             }
         }
         // reset all stamina flags -- only segments visited since the last reset can hold any; whole records at a time
@@ -892,7 +892,7 @@ class MysteryFamily : public Family {
         core_.alloc(n);
         desc_.alloc(n);
         rng_.alloc(n);
-        err_.alloc(1);
+        err_.alloc();
         if (endless) {
             segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
             falloff_.alloc((size_t)n * MAX_FALL);
@@ -971,11 +971,10 @@ class MysteryFamily : public Family {
     }
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
     int poll_errors() override {
-        int v = 0;
-        MG_HIP(hipMemcpy(&v, err_.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (v) MG_HIP(hipMemset(err_.p, 0, sizeof(int)));
-        return v;
+        MG_HIP(hipDeviceSynchronize());
+        return err_.take();
     }
+    int peek_errors() override { return err_.peek(); }
 
    private:
     // instance-carrying lanes per wave (see instance_of_lane); MEMGYM_MYSTERY_LPW overrides for tuning
@@ -995,7 +994,7 @@ class MysteryFamily : public Family {
         o.falloff = falloff_.p;
         o.rng = rng_.view();
         o.desc = desc_.p;
-        o.err = err_.p;
+        o.err = err_.dev;
         return o;
     }
 
@@ -1042,7 +1041,7 @@ class MysteryFamily : public Family {
     DevArray<uint8_t> segs_;
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
-    DevArray<int> err_;
+    ErrorWord err_;
     RngStore rng_;
 };
 

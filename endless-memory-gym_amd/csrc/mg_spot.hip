@@ -289,7 +289,7 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, S
     int target = start + 180 + g.integers(-45, 45);
     int offset = target + g.integers(-135, 135);
     if (s.n_spots >= SLOTS || s.free_mask == 0) {
-        atomicOr(io.err, 1);
+        raise_error(io.err, 1);
         return;
     }
     int slot = __ffs(s.free_mask) - 1;
@@ -803,7 +803,7 @@ class SpotFamily : public Family {
         coins_.alloc((size_t)MAX_COINS * n);
         desc_.alloc(n);
         rng_.alloc(n);
-        err_.alloc(1);
+        err_.alloc();
         std::vector<double> ct(360), st(360);
         for (int a = 0; a < 360; ++a) {
             if (a % 90 == 0) {
@@ -893,6 +893,18 @@ class SpotFamily : public Family {
     void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) override {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
+        {   // 16 spotlight slots per instance.  Refuse option sets that overflow them in ANY episode that lasts as long
+            // as the fastest spotlight lives (t reaches 1 after ceil(1 / speed) steps, the slot is freed one step later);
+            // rarer overflows raise error bit 1, which mg_peek_errors shows without a synchronisation.
+            const int life_min = (int)std::ceil(1.0 / P_.speed_hi) + 1;
+            const int interval = P_.endless ? P_.spawn_interval : P_.interval0;
+            int later = interval > 0 ? (life_min - 1) / interval : 1 << 20;
+            if (!P_.endless && later > P_.num_spawns) later = P_.num_spawns;
+            if (P_.initial_spawns + later > SLOTS)
+                throw std::runtime_error("these options keep " + std::to_string(P_.initial_spawns + later) +
+                                         " spotlights alive at once; this build holds " + std::to_string(SLOTS) +
+                                         " per instance (raise spawn_interval / spot_max_speed or lower initial_spawns)");
+        }
         if (seeds) seeded_ = true;
         if (P_.endless) hipLaunchKernelGGL(spot_reset_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
         else hipLaunchKernelGGL(spot_reset_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
@@ -923,11 +935,10 @@ class SpotFamily : public Family {
     }
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
     int poll_errors() override {
-        int v = 0;
-        MG_HIP(hipMemcpy(&v, err_.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (v) MG_HIP(hipMemset(err_.p, 0, sizeof(int)));
-        return v;
+        MG_HIP(hipDeviceSynchronize());
+        return err_.take();
     }
+    int peek_errors() override { return err_.peek(); }
 
    private:
     SpotIO io() {
@@ -939,7 +950,7 @@ class SpotFamily : public Family {
         o.coins = coins_.p;
         o.rng = rng_.view();
         o.desc = desc_.p;
-        o.err = err_.p;
+        o.err = err_.dev;
         return o;
     }
 
@@ -1007,7 +1018,7 @@ class SpotFamily : public Family {
     DevArray<uint8_t> sp_r_, sp_done_;
     DevArray<uint32_t> coins_;
     DevArray<SpotDesc> desc_;
-    DevArray<int> err_;
+    ErrorWord err_;
     RngStore rng_;
 };
 

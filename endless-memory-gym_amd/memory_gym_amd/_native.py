@@ -53,6 +53,7 @@ def _load():
     L.mg_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.mg_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.mg_poll_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mg_peek_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     return L
 

@@ -108,6 +108,7 @@ class VecMemoryGym:
             self.info_names.append(nm.decode())
         self.aux = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in self.info_names]
         self._info = _native.InfoBuffers()
+        self._err = C.c_int(0)
         self._info.ep_reward_dev = self.ep_reward.data_ptr()
         self._info.ep_length_dev = self.ep_length.data_ptr()
         for k, t in enumerate(self.aux):
@@ -183,6 +184,9 @@ class VecMemoryGym:
             _native.check(_native.LIB.mg_step(self._h, a.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
                                               self.done_u8.data_ptr(), self.gt.data_ptr() if self.gt_dim else None,
                                               C.byref(self._info), int(self.autoreset), self._stream()), "mg_step")
+        _native.LIB.mg_peek_errors(self._h, C.byref(self._err))  # host-mapped word: no synchronisation
+        if self._err.value:
+            self.check_errors()
         done = self.done_u8.view(torch.bool)
         info = {"done_mask": done, "reward": self.ep_reward, "length": self.ep_length}
         for nm, t in zip(self.info_names, self.aux):
@@ -225,12 +229,20 @@ class VecMemoryGym:
         _native.check(_native.LIB.mg_get_profile(self._h, kind, C.byref(ms), C.byref(n)), "mg_get_profile")
         return ms.value, n.value
 
+    ERROR_BITS = {1: "more than 16 live spotlights in one instance (raise spawn_interval / spot speeds or lower initial_spawns)",
+                  2: "path generation found no valid path (pygame_assets.py:723-724 raises here too)",
+                  4: "endless path longer than 128 segments", 8: "more than 128 distinct fall-off cells",
+                  16: "past-path window wider than 16 columns"}
+
     def check_errors(self):
-        """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device)."""
+        """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device).
+        step() looks at the same bits after every call without synchronising and ends up here when one is set."""
         f = C.c_int()
         _native.check(_native.LIB.mg_poll_errors(self._h, C.byref(f)), "mg_poll_errors")
         if f.value:
-            raise RuntimeError("memory_gym_amd: device error flags 0x%x (see include/memgym.h: mg_poll_errors)" % f.value)
+            what = "; ".join(m for b, m in self.ERROR_BITS.items() if f.value & b)
+            raise RuntimeError("memory_gym_amd: device error flags 0x%x: %s -- the frames of the affected instances are "
+                               "no longer the reference's (include/memgym.h: mg_poll_errors)" % (f.value, what))
 
     def rng_words(self, i):
         w = np.zeros(6, np.uint64)

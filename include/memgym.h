@@ -130,6 +130,12 @@ int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
  *  16  past-path window wider than 16 columns */
 int mg_poll_errors(mg_env* env, int* flags);
 
+/* The same bits as they stand right now: no synchronisation, nothing cleared.  The error word lives in pinned host
+ * memory that the kernels update with system-scope atomics, so a trainer can look after every mg_step for free and
+ * sees a bit at the latest one step after the kernel that raised it finished.  (SearingSpotlights option sets that
+ * overflow the 16 slots in every long enough episode are refused by mg_reset up front; the bit covers the rest.) */
+int mg_peek_errors(mg_env* env, int* flags);
+
 /* Test hook: copy the numpy-compatible PCG64 words of instance i to host:
  * out[6] = {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}.  Synchronous. */
 int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out);

@@ -83,3 +83,26 @@ def test_full_size_sample():
                 o = refs[i].reset(None)
             assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t)
     env.close()
+
+
+def test_slot_capacity_is_checked_at_reset():
+    """Option sets that must overflow the 16 slots per instance are refused up front; rarer overflows surface as a
+    RuntimeError from step() (host-mapped error word, no synchronisation needed to see it)."""
+    import memory_gym_amd
+    import torch
+
+    env = memory_gym_amd.make("Endless-SearingSpotlights-v0", num_envs=64, device=0)
+    with pytest.raises(RuntimeError, match="spotlights alive at once"):
+        env.reset(seed=0, options=dict(initial_spawns=5, spawn_interval=5))
+    # passes the static check (fastest spotlight: 5 + 134 // 10 = 18 > 16 is refused, 12 -> 5 + 11 = 16 fits) ...
+    with pytest.raises(RuntimeError, match="spotlights alive at once"):
+        env.reset(seed=0, options=dict(initial_spawns=5, spawn_interval=10))
+    env.reset(seed=0, options=dict(initial_spawns=5, spawn_interval=12, agent_health=100000, steps_per_coin=100000))
+    # ... but slow spotlights live up to 400 steps, so an agent that survives overflows: step() must say so
+    a = torch.zeros((64, 2), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="more than 16 live spotlights"):
+        for _ in range(400):
+            env.step(a)
+            torch.cuda.synchronize()
+    env.check_errors()  # cleared by the raise
+    env.close()
