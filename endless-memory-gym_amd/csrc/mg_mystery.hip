@@ -114,7 +114,10 @@ struct MysteryIO {
     RngSoA rng;
     MysteryDesc* desc;
     int* err;
+    int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
+    int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
 };
+constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_WORDS = 96;  // one 128-byte line each
 
 // ---- MysteryPath.__init__: walls + noisy A* on a 7x7 grid.  Returns the path length; out[] = flat indices
 // (x*7+y), END FIRST like the reference's list.  -1 = "No valid path found".
@@ -787,7 +790,6 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
     const bool in_range = worker && i < P.n;
     const bool active = in_range && !(mask && !mask[i]);
     if (in_range && !active) io.desc[i].valid = 0;
-    const int ii = in_range ? i : 0;
     Pcg g;
     MysteryCore s;
     MysteryDesc d;
@@ -799,11 +801,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
         g.state = g.inc = 0; g.buf = 0; g.has = false;
         memset(&s, 0, sizeof(s));
     }
-    if (P.endless) {
-        if (active) emp_pre_reset(s);
-        serve_emp(io, W, ii, active ? 3 : 0, s, g);
-        if (active) emp_post_reset(P, io, i, s, d, gt ? gt + 3 * i : nullptr);
-    } else {
+    {
         PathReq req;
         req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
         if (active) req = mp_pre_reset(P, s, g);
@@ -828,7 +826,6 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool active = worker && i < P.n;
-    const int ii = active ? i : 0;
     MysteryCore s;
     Pcg g;
     MysteryDesc d;
@@ -840,15 +837,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         g.state = g.inc = 0; g.buf = 0; g.has = false;
     }
     bool reset_me = false;
-    if (P.endless) {
-        int nx = 0, ny = 0, want = 0;
-        if (active) want = emp_step_a(P, i, s, actions, nx, ny);
-        serve_emp(io, W, ii, want, s, g);
-        if (active) reset_me = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
-        if (reset_me) emp_pre_reset(s);
-        serve_emp(io, W, ii, reset_me ? 3 : 0, s, g);
-        if (reset_me) emp_post_reset(P, io, i, s, d, gt ? gt + 3 * i : nullptr);
-    } else {
+    {
         if (active) reset_me = mp_step(P, i, s, actions, reward_out, done_out, info, autoreset, d);
         PathReq req;
         req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
@@ -862,6 +851,97 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         g.store(io.rng, i);  // unchanged streams are rewritten with the same words
         io.core[i] = s;
         io.desc[i] = d;
+    }
+}
+
+// Endless Mystery Path: nothing that generates a path is served by the wave that carries the instance.  A reset needs
+// three path generations in a row (~70 us of dependent work for one wave), a new segment one, and a wave that happened
+// to hold two or three such instances set the duration of the whole launch (profiles/r01e_logic_tails.md).
+// emp_step_kernel (one lane per instance, no LDS) only queues those instances; emp_serve_kernel spreads the queue over
+// the chip, one wave per entry at a time, lane 0 playing the instance's lane for the unchanged serve_emp /
+// emp_step_b / emp_post_reset.  The last workgroup out clears the counters, so the launches can be replayed from a HIP
+// graph.  Entries: instance | EMP_Q_SEGMENT = "append one segment, then finish the step (which may end in a reset)";
+// plain instance = "reset".
+constexpr int EMP_Q_SEGMENT = 1 << 30;
+
+__global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions, float* reward_out,
+                                                       uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    MysteryCore s = io.core[i];
+    int nx = 0, ny = 0;
+    if (emp_step_a(P, i, s, actions, nx, ny)) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
+        io.core[i] = s;
+        io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i | EMP_Q_SEGMENT;
+        return;
+    }
+    MysteryDesc d;
+    if (emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d))
+        io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+    io.core[i] = s;
+    io.desc[i] = d;
+}
+
+__global__ __launch_bounds__(256) void emp_enqueue_kernel(int n, MysteryIO io, const uint8_t* mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mask[i]) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+    else io.desc[i].valid = 0;
+}
+
+// all != 0: mg_reset of every instance (entry k = instance k, seeds may be given); otherwise the queue is drained
+__global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds, int all, float* reward_out,
+                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    path_ws_init(smem);
+    const PathWS W{smem};
+    const bool me = (threadIdx.x & 63) == 0;
+    const int count = all ? P.n : io.qctr[QC_COUNT];
+    // the first entry of wave w is entry w (no atomic: with thousands of idle waves the same-address atomics of their
+    // failing pops were the launch time); later ones are popped from a shared counter that starts after the last wave
+    const int waves = gridDim.x * (blockDim.x >> 6);
+    int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
+    while (idx < count) {
+        const int entry = all ? idx : bcast(io.queue[idx], 0);
+        const int i = entry & (EMP_Q_SEGMENT - 1);
+        float* gti = gt ? gt + 3 * i : nullptr;
+        Pcg g;
+        MysteryCore s;
+        MysteryDesc d;
+        if (me) {
+            if (seeds) g.seed((uint64_t)seeds[i]);
+            else g.load(io.rng, i);
+            s = io.core[i];
+        } else {
+            g.state = g.inc = 0; g.buf = 0; g.has = false;
+            memset(&s, 0, sizeof(s));
+        }
+        int reset_me = 1;
+        if (entry & EMP_Q_SEGMENT) {
+            serve_emp(io, W, i, me ? 1 : 0, s, g);
+            if (me)
+                reset_me = emp_step_b(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
+                                      gti, info, autoreset, d) ? 1 : 0;
+            reset_me = bcast(reset_me, 0);
+        }
+        if (reset_me) {
+            if (me) emp_pre_reset(s);
+            serve_emp(io, W, i, me ? 3 : 0, s, g);
+            if (me) emp_post_reset(P, io, i, s, d, gti);
+        }
+        if (me) {
+            io.core[i] = s;
+            g.store(io.rng, i);
+            io.desc[i] = d;
+            idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
+        }
+        idx = bcast(idx, 0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == (int)gridDim.x - 1) {  // last workgroup out
+        io.qctr[QC_COUNT] = 0;
+        io.qctr[QC_HEAD] = 0;
+        io.qctr[QC_LEFT] = 0;
     }
 }
 
@@ -893,6 +973,7 @@ class MysteryFamily : public Family {
         desc_.alloc(n);
         rng_.alloc(n);
         err_.alloc();
+        queue_.alloc((size_t)n + 32 + QC_WORDS);
         if (endless) {
             segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
             falloff_.alloc((size_t)n * MAX_FALL);
@@ -945,7 +1026,15 @@ class MysteryFamily : public Family {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;
-        hipLaunchKernelGGL(mystery_reset_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, gt_dim() ? gt : nullptr, lpw());
+        if (P_.endless) {
+            mg_info_buffers none;
+            memset(&none, 0, sizeof(none));
+            if (mask) hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
+            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask ? 0 : 1,
+                               (float*)nullptr, (uint8_t*)nullptr, gt, none, 0);
+        } else {
+            hipLaunchKernelGGL(mystery_reset_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
+        }
         raster(obs, s);
     }
 
@@ -956,8 +1045,14 @@ class MysteryFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
-                           gt_dim() ? gt : nullptr, ib, autoreset, lpw());
+        if (P_.endless) {
+            hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers()), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
+                               reward, done, gt, ib, autoreset);
+        } else {
+            hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
+                               (float*)nullptr, ib, autoreset, lpw());
+        }
         prof.end(0, s);
         prof.begin(1, s);
         raster(obs, s);
@@ -984,7 +1079,17 @@ class MysteryFamily : public Family {
             return e ? atoi(e) : 0;
         }();
         if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
-        return P_.endless ? 8 : 16;  // measured: profiles/r01e_logic_tails.md
+        return 16;  // measured: profiles/r01e_logic_tails.md (the endless variant has its own kernels)
+    }
+    // workgroups (4 waves each) of emp_serve_kernel; MEMGYM_EMP_SERVERS overrides for tuning
+    int servers() const {
+        static const int forced = [] {
+            const char* e = getenv("MEMGYM_EMP_SERVERS");
+            return e ? atoi(e) : 0;
+        }();
+        const int want = forced > 0 ? forced : 512;
+        const int cap = (n_ + 3) / 4;
+        return want < cap ? want : cap;
     }
     int blocks() const { const int per_block = 4 * lpw(); return (n_ + per_block - 1) / per_block; }
     MysteryIO io() {
@@ -995,6 +1100,8 @@ class MysteryFamily : public Family {
         o.rng = rng_.view();
         o.desc = desc_.p;
         o.err = err_.dev;
+        o.queue = queue_.p;
+        o.qctr = queue_.p + ((n_ + 31) & ~31);
         return o;
     }
 
@@ -1041,6 +1148,7 @@ class MysteryFamily : public Family {
     DevArray<uint8_t> segs_;
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
+    DevArray<int> queue_;  // n entries + the counters
     ErrorWord err_;
     RngStore rng_;
 };
