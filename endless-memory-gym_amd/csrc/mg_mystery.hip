@@ -1030,7 +1030,7 @@ class MysteryFamily : public Family {
             mg_info_buffers none;
             memset(&none, 0, sizeof(none));
             if (mask) hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
-            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask ? 0 : 1,
+            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(!mask)), dim3(256), WS_BYTES, s, P_, io(), seeds, mask ? 0 : 1,
                                (float*)nullptr, (uint8_t*)nullptr, gt, none, 0);
         } else {
             hipLaunchKernelGGL(mystery_reset_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
@@ -1047,7 +1047,7 @@ class MysteryFamily : public Family {
         prof.begin(0, s);
         if (P_.endless) {
             hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
-            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers()), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
+            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
                                reward, done, gt, ib, autoreset);
         } else {
             hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
@@ -1082,12 +1082,12 @@ class MysteryFamily : public Family {
         return 16;  // measured: profiles/r01e_logic_tails.md (the endless variant has its own kernels)
     }
     // workgroups (4 waves each) of emp_serve_kernel; MEMGYM_EMP_SERVERS overrides for tuning
-    int servers() const {
+    int servers(bool all) const {
         static const int forced = [] {
             const char* e = getenv("MEMGYM_EMP_SERVERS");
             return e ? atoi(e) : 0;
         }();
-        const int want = forced > 0 ? forced : 512;
+        const int want = forced > 0 ? forced : (all ? 1024 : 512);  // measured: profiles/r01e_logic_tails.md section 4
         const int cap = (n_ + 3) / 4;
         return want < cap ? want : cap;
     }
