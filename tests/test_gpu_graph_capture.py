@@ -6,7 +6,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("env_id,adim,n_act", [("MortarMayhem-Grid-v0", 1, 4), ("Endless-SearingSpotlights-v0", 2, 3),
-                                                ("MysteryPath-Grid-v0", 1, 4)])
+                                                ("MysteryPath-Grid-v0", 1, 4), ("Endless-MysteryPath-v0", 1, 4)])
 def test_step_is_graph_capturable(env_id, adim, n_act):
     import memory_gym_amd
     import torch
