@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_round.sh <tag> -- run on the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes of
+# tools/profile_round.sh <tag> [env ids ...] -- run on the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes of
 # bench.py for the BASELINE configs that fit one GPU; summaries go to gpurun_out/<tag>_*.md via tools/rocpd_summary.py.
 set -u
 TAG=${1:-r01}
@@ -7,7 +7,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out
-for E in MortarMayhem-Grid-v0 MysteryPath-v0 Endless-SearingSpotlights-v0 Endless-MortarMayhem-v0; do
+shift
+ENVS=${@:-MortarMayhem-Grid-v0 MysteryPath-v0 Endless-SearingSpotlights-v0 Endless-MortarMayhem-v0}
+for E in $ENVS; do
   S=$(echo $E | tr -d '-' | tr 'A-Z' 'a-z')
   rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_${S}_kt -o kt -- python bench.py --env $E --steps 200 --warmup 30 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_${S}_kt.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/${TAG}_${S}_w -o w -- python bench.py --env $E --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-events > gpurun_out/${TAG}_${S}_w.log 2>&1
