@@ -29,5 +29,5 @@ for t in range(steps):
     dones += int(d.sum().item())
 lm, ln = env.get_profile(0)
 rm, rn = env.get_profile(1)
-print(json.dumps(dict(env_id=env_id, n=n, options=options, logic_us=lm / ln * 1e3, raster_us=rm / rn * 1e3,
+print(json.dumps(dict(env_id=env_id, n=n, options=options, logic_us=lm / ln * 1e3 if ln else None, raster_us=rm / rn * 1e3,
                       done_rate_per_step=dones / steps / n)))
