@@ -40,31 +40,6 @@ class Atlas {
             for (int y = 0; y < (1 << sh); ++y) data_.push_back(y < s.h ? rgba(s.get(x, y)) : 0u);
         return id;
     }
-    // single-colour stamp of at most 32 x 32 pixels (command glyphs) as one column bit-mask word per column (bit y set
-    // = opaque): a lane of the raster kernel keeps its column in ONE register instead of four RGBA pixels
-    int add_mono_stamp(const Stamp& s) {
-        if (s.w > 32 || s.h > 32) throw std::runtime_error("mono stamp larger than 32x32");
-        int id = n_stamps_++;
-        if (id >= MAX_STAMPS) throw std::runtime_error("too many stamps");
-        uint8_t colour = 0;
-        tables_.stamps[id].off = (uint32_t)data_.size();
-        tables_.stamps[id].w = (uint16_t)s.w;
-        tables_.stamps[id].h = (uint16_t)s.h;
-        tables_.stamps[id].sh = 5;
-        for (int x = 0; x < s.w; ++x) {
-            uint32_t bits = 0;
-            for (int y = 0; y < s.h; ++y) {
-                uint8_t c = s.get(x, y);
-                if (!c) continue;
-                if (colour && c != colour) throw std::runtime_error("mono stamp with more than one colour");
-                colour = c;
-                bits |= 1u << y;
-            }
-            data_.push_back(bits);
-        }
-        tables_.stamps[id].pad = colour;  // palette id of the opaque pixels
-        return id;
-    }
     // palette id -> r | g<<8 | b<<16 | 0xFF<<24 (opaque); id 0 is the colour key -> 0 (transparent)
     uint32_t rgba(uint8_t id) const { return id ? (tables_.palette[id] | 0xFF000000u) : 0u; }
     int n_stamps() const { return n_stamps_; }

@@ -46,35 +46,10 @@ class Atlas {
         if (templates_.empty()) templates_.resize(16, 0);
         stamp_dev_.upload(data_);
         templ_dev_.upload(templates_);
-        // disc column spans for r = 0..DISC_RMAX
-        std::vector<int8_t> span((size_t)(DISC_RMAX + 1) * 2 * DISC_RMAX * 2, 0);
-        for (int r = 0; r <= DISC_RMAX; ++r) {
-            Stamp s(2 * r + 2, 2 * r + 2);
-            if (r >= 1) disc(s, r, r, r, 1);
-            for (int i = 0; i < 2 * DISC_RMAX; ++i) {
-                int lo = 1, hi = 0;
-                if (i < 2 * r) {
-                    int ymin = 1 << 20, ymax = -1;
-                    for (int y = 0; y < s.h; ++y)
-                        if (s.get(i, y)) {
-                            ymin = std::min(ymin, y);
-                            ymax = std::max(ymax, y);
-                        }
-                    if (ymax >= 0) {
-                        lo = ymin - r;
-                        hi = ymax - r;
-                    }
-                }
-                span[((size_t)r * 2 * DISC_RMAX + i) * 2] = (int8_t)lo;
-                span[((size_t)r * 2 * DISC_RMAX + i) * 2 + 1] = (int8_t)hi;
-            }
-        }
-        span_dev_.upload(span);
         std::vector<AtlasTables> t(1, tables_);
         tables_dev_.upload(t);
         dev_.templates = templ_dev_.p;
         dev_.stamp_data = stamp_dev_.p;
-        dev_.disc_span = span_dev_.p;
         dev_.tables = tables_dev_.p;
     }
     const RasterAtlas& dev() const { return dev_; }
@@ -86,7 +61,6 @@ class Atlas {
     std::vector<uint8_t> templates_;
     DevArray<uint32_t> stamp_dev_;
     DevArray<uint8_t> templ_dev_;
-    DevArray<int8_t> span_dev_;
     DevArray<AtlasTables> tables_dev_;
     RasterAtlas dev_;
 };

@@ -16,10 +16,8 @@
 // Helpers (all lanes of the workgroup call them together; callers place __syncthreads() between overlapping layers):
 //   templ_fetch / templ_apply_dark   background template, darkened outside the holes on the way into LDS
 //   stamp_fetch / stamp_apply_lit    colour-keyed RGBA stamp (agent sprites, coin, exit), clipped, darkened per pixel
-//   mono_fetch / mono_apply          single-colour stamps as column bit masks
 //   zero_mask / hole_fetch8 / hole_apply8 / hole_mask   the lit discs as an 84x84 bit mask
 //   darken2 / darken4                SDL's surface-alpha rule d - floor(d*alpha/255), two bytes per multiply
-//   rect, stamp, fill_clear, templ_fetch16 / templ_store16   plain layers
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -94,33 +92,7 @@ __device__ __forceinline__ void put_rgb(uint8_t* frame, int x, int y, uint32_t r
     p[2] = (uint8_t)(rgb >> 16);
 }
 
-// template copy split in two: the six 16-byte loads are issued in the composer's prefetch() (one L2 round trip, in
-// flight while the previous frame streams out), the LDS writes happen in compose()
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct
-struct TemplVec {                                             // (HIP's uint4 class members end up in scratch)
-    u32x4 a, b, c, d, e, f;
-};
-__device__ __forceinline__ void templ_fetch16(const RasterCtx& R, int t, TemplVec& V) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(R.A.templates + (size_t)t * FRAME_BYTES);
-    const int tid = R.tid;
-    V.a = src[tid]; V.b = src[tid + 256]; V.c = src[tid + 512]; V.d = src[tid + 768]; V.e = src[tid + 1024];
-    V.f = (u32x4)(0u);
-    if (tid < TAIL) V.f = src[tid + 1280];
-}
-__device__ __forceinline__ void templ_store16(const RasterCtx& R, const TemplVec& V) {
-    u32x4* lds16 = reinterpret_cast<u32x4*>(R.frame);
-    const int tid = R.tid;
-    lds16[tid] = V.a; lds16[tid + 256] = V.b; lds16[tid + 512] = V.c; lds16[tid + 768] = V.d; lds16[tid + 1024] = V.e;
-    if (tid < TAIL) lds16[tid + 1280] = V.f;
-}
-
-__device__ __forceinline__ void fill_clear(const RasterCtx& R) {
-    uint4* lds16 = reinterpret_cast<uint4*>(R.frame);
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    const int tid = R.tid;
-    lds16[tid] = z; lds16[tid + 256] = z; lds16[tid + 512] = z; lds16[tid + 768] = z; lds16[tid + 1024] = z;
-    if (tid < TAIL) lds16[tid + 1280] = z;
-}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct (HIP's uint4 class members end up in scratch)
 
 // d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black), two bytes at a time in
 // 16-bit lanes: t = d*a <= 65025 and t + 1 + (t >> 8) <= 65280 never carry into the neighbouring lane, and
@@ -132,17 +104,6 @@ __device__ __forceinline__ uint32_t darken2(uint32_t x, uint32_t a) {  // x = 0x
 }
 __device__ __forceinline__ uint32_t darken4(uint32_t v, uint32_t a) {
     return darken2(v & 0x00FF00FFu, a) | (darken2((v >> 8) & 0x00FF00FFu, a) << 8);
-}
-
-__device__ __forceinline__ void stamp(const RasterCtx& R, int id, int x, int y) {
-    const uint32_t* sp = R.A.stamp_data + R.T->stamps[id].off;
-    const int sh = R.T->stamps[id].sh, npx = (int)R.T->stamps[id].w << sh, ym = (1 << sh) - 1;
-    for (int p = R.tid; p < npx; p += 256) {
-        int px = p >> sh, py = p & ym;
-        uint32_t c = sp[p];
-        int X = x + px, Y = y + py;
-        if ((c >> 24) && (unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, c);
-    }
 }
 
 // The same blit split in two so that the stamp's pixels are requested from global memory EARLY (together with the
@@ -192,42 +153,6 @@ __device__ __forceinline__ void stamp_apply_lit(const RasterCtx& R, const StampR
 #pragma unroll
     for (int k = 0; k < K; ++k) one(R.tid + k * 256, s.px[k]);
     for (int p = R.tid + K * 256; p < s.npx; p += 256) one(p, s.src[p]);
-}
-template <int K>
-__device__ __forceinline__ void stamp_apply(const RasterCtx& R, const StampRegs<K>& s, int x, int y) {
-    stamp_apply_lit<K>(R, s, x, y, 0u, never_skip);
-}
-
-// Single-colour stamps (Atlas::add_mono_stamp): lane t owns 4 rows (t & 7) * 4 .. + 3 of column t >> 3.
-struct MonoRegs {
-    uint32_t bits;  // the lane's column mask (0 beyond the stamp's width / for "no stamp")
-    uint32_t rgb;
-};
-__device__ __forceinline__ void mono_fetch(const RasterCtx& R, int id, MonoRegs& M) {
-    const int col = R.tid >> 3;
-    const uint32_t* sp = R.A.stamp_data + R.T->stamps[id].off;
-    M.bits = col < (int)R.T->stamps[id].w ? sp[col] : 0u;
-    M.rgb = R.T->palette[R.T->stamps[id].pad];
-}
-__device__ __forceinline__ void mono_apply(const RasterCtx& R, const MonoRegs& M, int x, int y) {
-    const int X = x + (R.tid >> 3), r0 = (R.tid & 7) * 4;
-    const uint32_t four = (M.bits >> r0) & 0xFu;
-    if (!four || (unsigned)X >= (unsigned)SCREEN) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int Y = y + r0 + k;
-        if (((four >> k) & 1u) && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, M.rgb);
-    }
-}
-
-__device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, int h, int fill, bool bordered) {
-    const uint32_t cf = R.T->palette[fill], ce = R.T->palette[R.T->border_of[fill]];
-    for (int p = R.tid; p < w * h; p += 256) {
-        int px = p / h, py = p - px * h;
-        int X = x + px, Y = y + py;
-        bool on_edge = bordered && (px == 0 || py == 0 || px == w - 1 || py == h - 1);
-        if ((unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) put_rgb(R.frame, X, Y, on_edge ? ce : cf);
-    }
 }
 
 __device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {

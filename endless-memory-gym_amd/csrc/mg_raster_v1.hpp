@@ -22,8 +22,8 @@
 //   fill_clear     black frame
 //   stamp          colour-keyed blit of a palette-indexed stamp (agent sprites, glyphs, cross, coin, exit), clipped
 //   rect           filled rectangle with optional 1-px inset border (tiles, bars), clipped
-//   darken         the spotlight layer: pixels outside every hole disc blended towards black with SDL's
-//                  surface-alpha rule d - floor(d*alpha/255)
+// (The spotlight family's layers live in generation 2, mg_raster.hpp; the hole-mask words stay part of this
+// skeleton's LDS request because its occupancy and pacing were tuned with them: profiles/r01c_raster_generations.md.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,7 +35,6 @@
 namespace mg {
 namespace v1 {
 
-constexpr int DISC_RMAX = 64;
 constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
@@ -58,7 +57,6 @@ struct AtlasTables {
 struct RasterAtlas {
     const uint8_t* templates;   // [n_templates][84][84][3]
     const uint32_t* stamp_data; // r | g<<8 | b<<16 | 0xFF<<24 per opaque pixel, 0 = transparent (colour key)
-    const int8_t* disc_span;    // [DISC_RMAX+1][2*DISC_RMAX][2]: per column i of a radius-r disc, (lo, hi) y offsets; lo > hi = empty
     const AtlasTables* tables;
 };
 
@@ -160,141 +158,6 @@ __device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, in
     }
 }
 
-// d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black), two bytes at a time in
-// 16-bit lanes: t = d*a <= 65025 and t + 1 + (t >> 8) <= 65280 never carry into the neighbouring lane, and
-// (t + 1 + (t >> 8)) >> 8 == t / 255 for every t <= 65535.
-__device__ __forceinline__ uint32_t darken2(uint32_t x, uint32_t a) {  // x = 0x00dd00dd
-    uint32_t t = x * a;
-    uint32_t q = ((t + 0x00010001u + ((t >> 8) & 0x00FF00FFu)) >> 8) & 0x00FF00FFu;
-    return x - q;
-}
-__device__ __forceinline__ uint32_t darken4(uint32_t v, uint32_t a) {
-    return darken2(v & 0x00FF00FFu, a) | (darken2((v >> 8) & 0x00FF00FFu, a) << 8);
-}
-
-__device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
-    return (uint32_t)(x + 128) | ((uint32_t)(y + 128) << 9) | ((uint32_t)r << 18);
-}
-
-// holes[i] = pack_hole(x, y, r): filled discs (pygame's even-diameter midpoint disc) that stay lit.
-// hole_mask: union of the discs as an 84x84 bit mask in LDS; tasks = (hole, column), 4 holes x 64 columns per round,
-// so the span-table loads of all holes are in flight together.  The mask must have been zeroed (and synchronised).
-__device__ __forceinline__ void zero_mask(const RasterCtx& R) {
-    if (R.tid < SCREEN * MASK_WORDS) R.mask[R.tid] = 0u;
-}
-__device__ __forceinline__ void hole_mask(const RasterCtx& R, const uint32_t* holes, int nholes) {
-    const int sub = R.tid >> 6, col0 = R.tid & 63;
-    for (int base = 0; base < nholes; base += 4) {
-        int hI = base + sub;
-        if (hI >= nholes) continue;
-        const uint32_t hv = holes[hI];
-        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
-        for (int col = col0; col < 2 * r; col += 64) {
-            int X = hx - r + col;
-            int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
-            int y0 = hy + lo, y1 = hy + hi;
-            y0 = y0 < 0 ? 0 : y0;
-            y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
-            if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) {
-                for (int wI = 0; wI < MASK_WORDS; ++wI) {
-                    int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
-                    a0 = a0 < 0 ? 0 : a0;
-                    a1 = a1 > 31 ? 31 : a1;
-                    if (a0 <= a1) {
-                        uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
-                        atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
-                    }
-                }
-            }
-        }
-    }
-}
-// hole_mask split in two for radii <= 32 and <= 16 holes: the span-table bytes are requested up front (with the other
-// global reads of the frame), the LDS atomics happen after the mask has been zeroed.
-struct HoleRegs {
-    uint32_t v[4];  // per round: x | y0 << 8 | y1 << 16 | valid << 24 (column and clipped y range handled by this lane)
-};
-__device__ __forceinline__ bool holes_prefetchable(const uint32_t* holes, int nholes) {
-    bool ok = nholes <= 16;
-    for (int h = 0; h < nholes; ++h) ok = ok && (int)(holes[h] >> 18) <= 32;
-    return ok;
-}
-__device__ __forceinline__ HoleRegs hole_fetch(const RasterCtx& R, const uint32_t* holes, int nholes) {
-    HoleRegs H;
-    const int sub = R.tid >> 6, col = R.tid & 63;
-#pragma unroll
-    for (int rnd = 0; rnd < 4; ++rnd) {
-        H.v[rnd] = 0u;
-        int hI = rnd * 4 + sub;
-        if (hI < nholes) {
-            const uint32_t hv = holes[hI];
-            const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
-            if (col < 2 * r) {
-                int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
-                int X = hx - r + col, y0 = hy + lo, y1 = hy + hi;
-                y0 = y0 < 0 ? 0 : y0;
-                y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
-                if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) H.v[rnd] = (uint32_t)X | ((uint32_t)y0 << 8) | ((uint32_t)y1 << 16) | (1u << 24);
-            }
-        }
-    }
-    return H;
-}
-__device__ __forceinline__ void hole_apply(const RasterCtx& R, const HoleRegs& H) {
-#pragma unroll
-    for (int rnd = 0; rnd < 4; ++rnd) {
-        const uint32_t hv = H.v[rnd];
-        if (!(hv >> 24)) continue;
-        int X = (int)(hv & 255u), y0 = (int)((hv >> 8) & 255u), y1 = (int)((hv >> 16) & 255u);
-        for (int wI = 0; wI < MASK_WORDS; ++wI) {
-            int a0 = y0 - 32 * wI, a1 = y1 - 32 * wI;
-            a0 = a0 < 0 ? 0 : a0;
-            a1 = a1 > 31 ? 31 : a1;
-            if (a0 <= a1) {
-                uint32_t bits = (a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0);
-                atomicOr(&R.mask[X * MASK_WORDS + wI], bits);
-            }
-        }
-    }
-}
-
-// in-place darkening of every pixel whose mask bit is clear; 4 pixels (12 bytes = 3 dwords) per task:
-// 84 columns x 21 segments.  The caller synchronises before (frame + mask complete) and after.
-__device__ __forceinline__ void darken_apply(const RasterCtx& R, uint32_t alpha) {
-    uint32_t* f32 = reinterpret_cast<uint32_t*>(R.frame);
-    for (int k = R.tid; k < SCREEN * 21; k += 256) {
-        int X = k / 21, seg = k - X * 21, y0 = seg * 4;
-        uint32_t lit = (R.mask[X * MASK_WORDS + (y0 >> 5)] >> (y0 & 31)) & 0xFu;
-        if (lit == 0xFu) continue;
-        uint32_t* p = f32 + X * (COL_BYTES / 4) + seg * 3;
-        uint32_t v0 = p[0], v1 = p[1], v2 = p[2];
-        uint32_t m0 = ((lit & 1u) ? 0x00FFFFFFu : 0u) | ((lit & 2u) ? 0xFF000000u : 0u);
-        uint32_t m1 = ((lit & 2u) ? 0x0000FFFFu : 0u) | ((lit & 4u) ? 0xFFFF0000u : 0u);
-        uint32_t m2 = ((lit & 4u) ? 0x000000FFu : 0u) | ((lit & 8u) ? 0xFFFFFF00u : 0u);
-        uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
-        if (alpha < 255u) {
-            d0 = darken4(v0, alpha);
-            d1 = darken4(v1, alpha);
-            d2 = darken4(v2, alpha);
-        }
-        p[0] = (v0 & m0) | (d0 & ~m0);
-        p[1] = (v1 & m1) | (d1 & ~m1);
-        p[2] = (v2 & m2) | (d2 & ~m2);
-    }
-}
-
-// Composer concept:
-//   struct Desc;                                   trivially copyable, sizeof % 16 == 0
-//   static __device__ bool skip(const Desc*);      true: leave the frame untouched (masked reset)
-//   static __device__ void compose(const Desc*, const RasterCtx&);   leaves the frame complete (no trailing barrier needed)
-// The descriptor is read through its (workgroup-uniform) global pointer, so every field access -- also array
-// elements with a run-time index -- is a scalar load; a by-value copy would push indexed arrays to scratch.
-// ---- frame stream-out ---------------------------------------------------------------------------------------
-// MG_OBS_U8_XYC: the reference's observation, pygame.surfarray.array3d order [x][y][c] uint8 (21,168 B = 1,323 x 16 B).
-// MG_OBS_F32_CYX / MG_OBS_F16_CYX: what a trainer builds from it before its CNN: value / 255 as
-// float32 / float16 in image order [c][y][x].  The transpose is done LDS-side (byte gathers, stride 252 B), the
-// global stores stay contiguous 16-B vectors.
-// 16-bit element of the half formats: IEEE half, or bfloat16 = the float32 quotient rounded to nearest even
 template <int FMT>
 __device__ __forceinline__ uint16_t to_half16(float q) {
     if constexpr (FMT == MG_OBS_BF16_CYX) {
