@@ -257,22 +257,39 @@ __device__ int coop_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey
         in_open &= ~(1ull << cur);
         closed |= 1ull << cur;
         const int gcur = bcast(gval, cur);
+        // Node.add_neighbors order x+1, x-1, y+1, y-1 (-1 = outside).  Everything about WHICH neighbours are evaluated,
+        // the draws and the list order is wave-uniform (scalar); the per-node updates are done by the node's own lane,
+        // all four at once.  integers(1, 9) has a span of 8: Lemire never rejects, the draw is 1 + (word >> 29).
+        const int cx = cur / G, cy = cur - cx * G;
+        const int nb[4] = {cx < G - 1 ? cur + G : -1, cx > 0 ? cur - G : -1, cy < G - 1 ? cur + 1 : -1, cy > 0 ? cur - 1 : -1};
+        const uint64_t blocked = closed | wall;
+        int gg = 0;
+        bool mine = false;
+        int pos = n_open;
+        const uint64_t was_open = in_open;
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int nb = nb_of(cur, k);
-            if (nb < 0) continue;
-            if (((closed >> nb) & 1ull) || ((wall >> nb) & 1ull)) continue;
-            const int gg = gcur + g.integers(1, 9);
-            bool new_path = false;
-            if ((in_open >> nb) & 1ull) {
-                if (gg < bcast(gval, nb)) new_path = true;  // `neighbor.g = g` typo: g_cost is NOT updated
-            } else {
-                if (lane == nb) gval = gg;
-                new_path = true;
-                if (lane == n_open) lst = nb;
-                ++n_open;
-                in_open |= 1ull << nb;
+            const bool valid = nb[k] >= 0 && !((blocked >> (nb[k] & 63)) & 1ull);
+            if (!valid) continue;  // uniform
+            const int cost = gcur + 1 + (int)(g.next32() >> 29);
+            if (lane == nb[k]) {
+                mine = true;
+                gg = cost;
             }
-            if (new_path && lane == nb) prev = cur;
+            if (!((was_open >> nb[k]) & 1ull)) {  // open_set.append(neighbor)
+                if (lane == pos) lst = nb[k];
+                ++pos;
+                in_open |= 1ull << nb[k];
+            }
+        }
+        n_open = pos;
+        if (mine) {
+            if ((was_open >> lane) & 1ull) {
+                if (gg < gval) prev = cur;  // `neighbor.g = g` typo: g_cost is NOT updated
+            } else {
+                gval = gg;
+                prev = cur;
+            }
         }
     }
 }
@@ -473,7 +490,7 @@ struct SegRec {
 
 // EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604), served by the whole wave: every lane passes the number
 // of segments its instance still needs (3 at reset, 1 when the agent enters the last-but-one segment, else 0).  All 64
-// lanes, converged.  The finished path is staged in LDS and written to the instance's segment store by the requester.
+// lanes, converged.  The finished record is assembled in LDS and written to the instance's segment store as 13 dwords.
 __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want, MysteryCore& s, Pcg& g) {
     const int lane = threadIdx.x & 63;
     int todo_n = want;
@@ -492,24 +509,30 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
             if (lane == 0) raise_error(io.err, 2);
             len = 0;
         }
+        // the segment record as stored: byte 0 = node count, bytes 1..len = the path START first (our list is END first:
+        // position p sits in lane len-1-p), byte len+1 = the transition node at x = 8*seg + 7, zeros after it.
+        // Assembled in LDS by 52 lanes, written by 13 lanes as dwords (the requester alone copied it byte by byte before).
         uint8_t* stage = W.stage();
-        if (lane < len) {  // reference order: start first; our list is END first
-            const int x = node / G, y = node - x * G;
-            stage[len - 1 - lane] = (uint8_t)(x | (y << 3));
+        {
+            const int from = len - lane;  // lane b in 1..len holds path position b-1
+            const int nd = __shfl(node, from >= 0 && from < 64 ? from : 0);
+            const int x = nd / G, y = nd - x * G;
+            int b = 0;
+            if (lane == 0) b = len + 1;
+            else if (lane <= len) b = x | (y << 3);
+            else if (lane == len + 1) b = 7 | (ey << 3);
+            stage[lane] = (uint8_t)b;
         }
+        const int nseg = bcast((int)s.num_seg, L);
+        if (nseg < MAX_SEG && lane < SEG_STRIDE / 4)
+            reinterpret_cast<uint32_t*>(seg_ptr(io, bcast(i, L), nseg))[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the requester's lane reads the record back (emp_post_reset, SegRec)
         if (lane == L) {
             g = bg;
             s.have_start = 1;
             s.end_y = (int8_t)ey;
-            if (s.num_seg >= MAX_SEG) {
-                raise_error(io.err, 4);
-            } else {
-                uint8_t* sp = seg_ptr(io, i, s.num_seg);
-                for (int k = 0; k < len; ++k) sp[1 + k] = stage[k];
-                sp[1 + len] = (uint8_t)(7 | (ey << 3));  // transition node at x = 8*seg + 7
-                sp[0] = (uint8_t)(len + 1);
-                s.num_seg++;
-            }
+            if (s.num_seg >= MAX_SEG) raise_error(io.err, 4);
+            else s.num_seg++;
             todo_n--;
         }
     }
