@@ -30,11 +30,13 @@ namespace mg {
 constexpr int SLOTS = 16;
 constexpr int MAX_COINS = 8;
 constexpr int MAX_HOLES = 24;
+constexpr int LAYER_COIN_ABOVE = 1, LAYER_EXIT_ABOVE = 2, LAYER_AGENT_TOP = 4;  // SpotDesc::coin_above: what is drawn over the dark layer
 
 struct SpotParams {
     int endless, n;
     int max_steps, steps_per_coin, initial_spawns, spawn_interval, interval0, num_spawns;
     int visual_feedback, dim_duration, dim_step, light_threshold;
+    int layer_flags;                // LAYER_EXIT_ABOVE (exit_visible) | LAYER_AGENT_TOP (agent_visible), OR-ed into SpotDesc::coin_above
     int coin_enabled, coin_show_duration, coins_visible, sample_agent_position, show_last_action, show_last_positive_reward;
     int r_lo, r_hi;                 // radius = integers(r_lo, r_hi)
     int agent_radius, sprite_half, coin_radius;
@@ -130,20 +132,25 @@ struct SpotComposer {
         templ_apply_dark(R, P.bg, alpha);
         __syncthreads();
         auto under_bar = [&](int X, int Y) { return Y < BAR_H && bar_covers(d, X); };
-        if (!d.coin_above) {
-            // coins keep their distance from each other and from the exit (sampler block radius): no overlap
+        // coins keep their distance from each other and from the exit (sampler block radius): no overlap among them.
+        // coins_visible / exit_visible / agent_visible move a layer from below the dark layer to above it (the agent:
+        // to the very top, over the bar -- the reference's list.insert index is past the end of its surface list).
+        const uint32_t lf = d.coin_above;
+        const bool exit_here = d.exit_stamp != 0xFF;
+        if (!(lf & LAYER_COIN_ABOVE))
             for (int k = 0; k < d.n_coins; ++k)
                 stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, alpha, never_skip);
-            if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
-            __syncthreads();
-            stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, under_bar);
+        if (exit_here && !(lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
+        __syncthreads();
+        if (!(lf & (LAYER_COIN_ABOVE | LAYER_EXIT_ABOVE))) {  // the bar follows without a barrier: leave its pixels alone
+            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, under_bar);
         } else {
-            if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
+            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, never_skip);
             __syncthreads();
-            stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, never_skip);
-            __syncthreads();
-            for (int k = 0; k < d.n_coins; ++k)
-                stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
+            if (lf & LAYER_COIN_ABOVE)
+                for (int k = 0; k < d.n_coins; ++k)
+                    stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
+            if (exit_here && (lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, 0u, under_bar);
         }
         static_assert(BAR_H == 4, "one bar column = 4 pixels = 3 dwords");
         if (R.tid < SCREEN) {
@@ -155,6 +162,10 @@ struct SpotComposer {
                 p[1] = g | (b << 8) | (r << 16) | (g << 24);
                 p[2] = b | (r << 8) | (g << 16) | (b << 24);
             }
+        }
+        if (lf & LAYER_AGENT_TOP) {
+            __syncthreads();
+            stamp_apply_lit<1>(R, agent, d.sx, d.sy, 0u, never_skip);
         }
     }
 };
@@ -329,8 +340,12 @@ __device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore&
 
 // ENDLESS is a compile-time flag: the endless instantiation has no run-time indexed local arrays (coin lists), so the
 // descriptor and the state stay in registers -- with both variants in one kernel they lived in 176 B of scratch per lane.
+// stale_holes: the spotlight surface is NOT repainted by reset() (searing_spotlights.py:394-397 only set its alpha), so
+// the first frame of an episode shows the holes of the last frame drawn before it; they only show when the alpha is not
+// 0 at reset, i.e. with light_dim_off_duration == 0.  The hole words themselves are still in the descriptor.
 template <bool EN>
-__device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt) {
+__device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
+                                           int stale_holes) {
     s.t = 0;
     s.coin_t = 0;
     s.ep_sum = 0.0;
@@ -356,7 +371,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.health = P.agent_health;
     s.red_w = 0;
     s.last_pos = 0;
-    s.alpha = (uint8_t)(P.dim_duration > 0 ? 0 : P.light_threshold);
+    s.alpha = (uint8_t)(P.dim_duration > 0 ? 0 : (P.light_threshold > 255 ? 255 : (P.light_threshold < 0 ? 0 : P.light_threshold)));
     s.n_spots = 0;
     s.order = 0;
     s.free_mask = 0xFFFFu;
@@ -408,9 +423,8 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     }
     s.bg_red = 0;
 
-    // reset frame: blue board, sprite index 0 (not the sampled rotation), dark layer at the reset alpha
-    // (its hole pattern is whatever the previous episode left -- only visible if light_dim_off_duration == 0,
-    // which this build rejects), coin(s) shown above the dark layer while coin_t < coin_show_duration
+    // reset frame: blue board, sprite index 0 (not the sampled rotation), dark layer at the reset alpha with the hole
+    // pattern the previous frame left, coin(s) shown above the dark layer while coin_t < coin_show_duration
     memset(&d, 0, sizeof(d));
     d.valid = 1;
     d.bg = 0;
@@ -418,15 +432,15 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     d.sx = (int16_t)(ax - P.sprite_half);
     d.sy = (int16_t)(ay - P.sprite_half);
     d.alpha = s.alpha;
-    d.n_holes = 0;
+    d.n_holes = (uint8_t)stale_holes;
     d.exit_stamp = 0xFF;
     if constexpr (EN) {
         d.n_coins = s.n_coins;
-        d.coin_above = (P.coins_visible || s.coin_t < P.coin_show_duration) ? 1 : 0;
+        d.coin_above = (uint8_t)(((P.coins_visible || s.coin_t < P.coin_show_duration) ? LAYER_COIN_ABOVE : 0) | P.layer_flags);
         d.coins[0] = (uint32_t)(s.coin_x - P.coin_radius + 128) | ((uint32_t)(s.coin_y - P.coin_radius + 128) << 16);
     } else {
         d.n_coins = s.n_coins;
-        d.coin_above = P.coins_visible ? 1 : 0;
+        d.coin_above = (uint8_t)((P.coins_visible ? LAYER_COIN_ABOVE : 0) | P.layer_flags);
 #pragma unroll
         for (int k = 0; k < MAX_COINS; ++k) {
             if (k < s.n_coins) {
@@ -487,7 +501,8 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     else g.load(io.rng, i);
     SpotCore s = io.core[i];
     SpotDesc d;
-    spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr);
+    const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);  // n_holes of the frame drawn last
+    spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes);
     if (ls == 0) {
         io.core[i] = s;
         g.store(io.rng, i);
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     // dim the light until off
     if ((int)s.alpha <= P.light_threshold) {
         int a = P.dim_duration > 0 ? (int)s.alpha + P.dim_step : P.light_threshold;
-        s.alpha = (uint8_t)(a > 255 ? 255 : a);
+        s.alpha = (uint8_t)(a > 255 ? 255 : (a < 0 ? 0 : a));  // Surface.set_alpha clamps
     }
 
     SpotDesc d;
@@ -721,7 +736,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     }
 
     if (__builtin_expect(done && autoreset, 0)) {  // cold: keep the reset code out of the hot instruction stream
-        spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr);
+        spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh);
     } else {
         d.bg = s.bg_red;
         d.sprite = s.rot8;
@@ -732,11 +747,11 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         d.exit_stamp = 0xFF;
         if constexpr (EN) {
             d.n_coins = P.coin_enabled ? 1 : 0;
-            d.coin_above = (P.coins_visible || s.coin_t < P.coin_show_duration) ? 1 : 0;
+            d.coin_above = (uint8_t)(((P.coins_visible || s.coin_t < P.coin_show_duration) ? LAYER_COIN_ABOVE : 0) | P.layer_flags);
             d.coins[0] = (uint32_t)(s.coin_x - P.coin_radius + 128) | ((uint32_t)(s.coin_y - P.coin_radius + 128) << 16);
         } else {
             d.n_coins = s.n_coins;
-            d.coin_above = P.coins_visible ? 1 : 0;
+            d.coin_above = (uint8_t)((P.coins_visible ? LAYER_COIN_ABOVE : 0) | P.layer_flags);
 #pragma unroll
             for (int q = 0; q < MAX_COINS; ++q) {
                 if (q < s.n_coins) {
@@ -846,14 +861,14 @@ class SpotFamily : public Family {
         else if (key == "spot_damage") P_.damage = v[0];
         else if (key == "visual_feedback") B(P_.visual_feedback);
         else if (key == "black_background" || key == "hide_chessboard") must_be(v[0] == 0.0);
-        else if (key == "light_dim_off_duration") { I(dim_duration_); must_be(dim_duration_ > 0); dirty_ = true; }
-        else if (key == "light_threshold") { I(P_.light_threshold); must_be(P_.light_threshold == 255); }
+        else if (key == "light_dim_off_duration") { I(dim_duration_); dirty_ = true; }
+        else if (key == "light_threshold") I(P_.light_threshold);
         else if (key == "coin_scale") { coin_scale_ = v[0]; dirty_ = true; }
         else if (key == "coins_visible") B(P_.coins_visible);
         else if (key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
         else if (key == "agent_health") P_.agent_health = v[0];
         else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
-        else if (key == "agent_visible") must_be(v[0] == 0.0);
+        else if (key == "agent_visible") P_.layer_flags = (P_.layer_flags & ~LAYER_AGENT_TOP) | (v[0] != 0.0 ? LAYER_AGENT_TOP : 0);
         else if (key == "sample_agent_position") B(P_.sample_agent_position);
         else if (key == "show_last_action") {
             B(P_.show_last_action);
@@ -884,7 +899,7 @@ class SpotFamily : public Family {
         }
         else if (!e && key == "use_exit") must_be(v[0] != 0.0);  // use_exit=False crashes the reference itself
         else if (!e && key == "exit_scale") { exit_scale_ = v[0]; dirty_ = true; }
-        else if (!e && key == "exit_visible") must_be(v[0] == 0.0);
+        else if (!e && key == "exit_visible") P_.layer_flags = (P_.layer_flags & ~LAYER_EXIT_ABOVE) | (v[0] != 0.0 ? LAYER_EXIT_ABOVE : 0);
         else if (!e && key == "reward_exit") P_.r_exit = v[0];
         else if (!e && key == "reward_max_steps") {}
         else throw OptionError{-2, "unknown reset parameter " + key};
@@ -969,7 +984,7 @@ class SpotFamily : public Family {
         P_.r_hi = (int)(spot_max_radius_ + 1);
         if (P_.r_hi - 1 > DISC_RMAX || P_.r_lo < 1 || P_.r_hi <= P_.r_lo) throw OptionError{-3, "spot radius range not supported"};
         P_.dim_duration = dim_duration_;
-        P_.dim_step = (int)(255.0 / dim_duration_);
+        P_.dim_step = dim_duration_ > 0 ? (int)(255.0 / dim_duration_) : 0;
         P_.coin_radius = (int)(10 * coin_scale_);
         P_.spawn_clamp = (int)(30 * SCALE);
         P_.quarter = (int)(SCREEN / 4);

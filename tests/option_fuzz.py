@@ -44,9 +44,9 @@ def mystery_opts(rng, env_id):
 def spot_opts(rng, env_id):
     o = dict(initial_spawns=int(rng.integers(1, 6)), spot_min_radius=float(rng.choice([7.5, 8.0, 9.0])), spot_max_radius=float(rng.choice([11.0, 13.75])),
              spot_min_speed=float(rng.choice([0.0025, 0.01])), spot_max_speed=float(rng.choice([0.02, 0.0075 * 4])), spot_damage=float(rng.choice([0.5, 1.0, 2.0])),
-             visual_feedback=bool(rng.integers(0, 2)), light_dim_off_duration=int(rng.integers(1, 10)), light_threshold=int(rng.choice([255, 200, 128])),
+             visual_feedback=bool(rng.integers(0, 2)), light_dim_off_duration=int(rng.integers(0, 10)), light_threshold=int(rng.choice([255, 200, 128, 30])),
              coins_visible=bool(rng.integers(0, 2)), agent_health=int(rng.integers(3, 40)), sample_agent_position=bool(rng.integers(0, 2)),
-             show_last_positive_reward=bool(rng.integers(0, 2)), reward_inside_spotlight=_rew(rng),
+             show_last_positive_reward=bool(rng.integers(0, 2)), agent_visible=bool(rng.integers(0, 2)), reward_inside_spotlight=_rew(rng),
              reward_outside_spotlight=_rew(rng), reward_death=_rew(rng), reward_coin=_rew(rng))
     if env_id.startswith("Endless"):
         # the HIP path holds at most 16 live spotlights per instance (error bit 1 otherwise, include/memgym.h): keep
@@ -59,7 +59,7 @@ def spot_opts(rng, env_id):
         # show_last_action = False crashes the ENDLESS reference (endless_searing_spotlights.py:422 uses action_colors,
         # which only exists when the flag is set, :343); the finite env guards the use (:465)
         o.update(max_steps=int(rng.integers(60, 300)), num_spawns=int(rng.integers(0, 12)), num_coins=_lst(rng, 1, 4), reward_exit=_rew(rng),
-                 show_last_action=bool(rng.integers(0, 2)))
+                 show_last_action=bool(rng.integers(0, 2)), exit_visible=bool(rng.integers(0, 2)))
     return o
 
 

@@ -106,3 +106,24 @@ def test_slot_capacity_is_checked_at_reset():
             torch.cuda.synchronize()
     env.check_errors()  # cleared by the raise
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["SearingSpotlights-v0", "Endless-SearingSpotlights-v0"])
+@pytest.mark.parametrize("threshold,duration", [(128, 6), (200, 3), (40, 0), (0, 4), (255, 0), (300, 5), (-5, 0)])
+def test_light_threshold(env_id, threshold, duration):
+    """The dark layer's alpha ramps by int(255 / duration) while it is <= light_threshold (then stays: a partly lit
+    board), or is set to the threshold at once when the duration is 0 (searing_spotlights.py:397,471-475); set_alpha clamps."""
+    run_parity(env_id, dict(light_threshold=threshold, light_dim_off_duration=duration), n=32, steps=40)
+
+
+@pytest.mark.parametrize("opts", [dict(agent_visible=True), dict(exit_visible=True), dict(agent_visible=True, exit_visible=True, coins_visible=True),
+                                  dict(exit_visible=True, coins_visible=True), dict(agent_visible=True, coins_visible=True, light_threshold=120)])
+def test_layers_above_the_dark_layer_finite(opts):
+    """coins_visible / exit_visible / agent_visible move a layer from below the spotlight layer to above it
+    (searing_spotlights.py:524-545); the agent lands on top of the top bar."""
+    run_parity("SearingSpotlights-v0", dict(opts, sample_agent_position=False), n=48, steps=120, policy=coin_seeker, n_policy=24)
+
+
+@pytest.mark.parametrize("opts", [dict(agent_visible=True), dict(agent_visible=True, coins_visible=True), dict(agent_visible=True, light_dim_off_duration=0, light_threshold=90)])
+def test_layers_above_the_dark_layer_endless(opts):
+    run_parity("Endless-SearingSpotlights-v0", opts, n=48, steps=200, policy=coin_seeker, n_policy=24)
