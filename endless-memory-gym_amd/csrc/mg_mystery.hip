@@ -35,7 +35,7 @@ constexpr int STAMINA_W = 4;      // int(16 * SCALE)
 
 struct MysteryParams {
     int endless, grid, n;
-    int max_steps, show_origin, show_goal, visual_feedback, show_past_path, show_stamina, stamina_level, depth;
+    int max_steps, show_origin, show_goal, visual_feedback, show_past_path, show_background, show_stamina, stamina_level, depth;
     int agent_radius, sprite_dim, v_axis_i, v_diag_i, tile, cross_dim;
     int camera_offset;  // integral at the supported camera_offset_scale values
     OptList cardinal;
@@ -54,7 +54,8 @@ struct __attribute__((aligned(16))) MysteryCore {
     double ep_sum;
     uint8_t td[3], have_start;
     int8_t end_y;
-    uint8_t gx, gy, pad;  // grid controller position (MysteryPath-Grid-v0)
+    uint8_t gx, gy;       // grid controller position (MysteryPath-Grid-v0); endless: range of segments holding stamina flags
+    uint8_t bg;           // endless: -bg_scroll, the scrolling background's phase in pixels (< tile)
 };
 static_assert(sizeof(MysteryCore) == 96, "MysteryCore must be 96 bytes");
 
@@ -65,7 +66,8 @@ struct __attribute__((aligned(16))) MysteryDesc {
     // past-path tiles (endless): bit (col*7 + row) of the 16-column x 7-row window whose column 0 is drawn at tile_x0
     uint64_t tile_mask[2];
     int32_t tile_x0;
-    uint32_t pad[3];
+    uint8_t bg_on, bg_phase, pad8[2];        // show_background: template = icy columns shifted left by bg_phase pixels
+    uint32_t pad[2];
 };
 static_assert(sizeof(MysteryDesc) == 64, "MysteryDesc must be 64 bytes");
 
@@ -77,7 +79,8 @@ struct MysteryComposer {
         StampRegs<4> sprite = stamp_fetch<4>(R, d.sprite);
         StampRegs<1> cross;
         if (d.cross_on) cross = stamp_fetch<1>(R, ST_CROSS);
-        fill_clear(R);
+        if (d.bg_on) fill_template(R, d.bg_phase);
+        else fill_clear(R);
         __syncthreads();
         if (d.goal_on) rect(R, d.goal_x * TILE, d.goal_y * TILE, TILE, TILE, C_GREEN, false);
         if (d.origin_on) rect(R, d.origin_x * TILE, d.origin_y * TILE, TILE, TILE, C_BLUE, false);
@@ -575,6 +578,8 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
     d.cross_on = (P.visual_feedback && s.cross_on) ? 1 : 0;
     d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
     d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
+    d.bg_on = P.show_background ? 1 : 0;
+    d.bg_phase = s.bg;
     if (P.show_stamina) {
         d.stamina_on = 1;
         int st = s.stamina < P.stamina_level ? s.stamina : P.stamina_level;
@@ -625,6 +630,7 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
     s.sx = (uint8_t)node_x(0, s0[1]);
     s.sy = (uint8_t)node_y(s0[1]);
     s.camera_x = P.camera_offset;
+    s.bg = 0;
     s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
     s.ay = (int16_t)(s.sy * P.tile + P.agent_radius);
     s.rot8 = 6;  // 270 degrees
@@ -657,8 +663,14 @@ __device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, const i
     if (!s.off) {
         int before = s.ax;
         move_agent(P, s, a0, a1, false);
-        s.camera_x += s.ax - before;  // camera follows the agent's x velocity
+        const int vx = s.ax - before;
+        s.camera_x += vx;  // camera follows the agent's x velocity
+        // bg_scroll -= velocity.x; once |bg_scroll| >= tile it becomes (|bg_scroll| % |velocity.x|) * sign, which is 0:
+        // it has only ever moved in steps of the same velocity.x (endless_mystery_path.py:311-316)
+        int bg = s.bg + vx;
+        s.bg = (uint8_t)(bg >= P.tile ? bg % vx : bg);
     } else {
+        s.bg = 0;
         s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
         s.ay = (int16_t)(s.sy * P.tile + P.agent_radius);
         move_agent(P, s, 0, 0, false);
@@ -1030,7 +1042,7 @@ class MysteryFamily : public Family {
         else if (key == "reward_path_progress") P_.r_progress = v[0];
         else if (key == "reward_step") P_.r_step = v[0];
         else if (e && key == "show_past_path") B(P_.show_past_path);
-        else if (e && key == "show_background") must_be(v[0] == 0.0);
+        else if (e && key == "show_background") B(P_.show_background);
         else if (e && key == "show_stamina") B(P_.show_stamina);
         else if (e && key == "camera_offset_scale") { camera_offset_scale_ = v[0]; dirty_ = true; }
         else if (e && key == "stamina_level") { I(P_.stamina_level); must_be(P_.stamina_level > 0); }
@@ -1148,6 +1160,20 @@ class MysteryFamily : public Family {
         atlas_.reset(new Atlas());
         for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
         atlas_->add_stamp(cross);                         // 8
+        if (P_.endless) {
+            // show_background: draw_column_tile_surface / draw_icy_surface (pygame_assets.py:780-817) blitted every `tile`
+            // pixels from x = bg_scroll - tile on (endless_mystery_path.py:141-143) = one template per scroll phase
+            const uint8_t ice[3] = {125, 177, 250}, edge[3] = {210, 210, 210};
+            std::vector<uint8_t> t((size_t)P_.tile * FRAME_BYTES);
+            for (int ph = 0; ph < P_.tile; ++ph)
+                for (int x = 0; x < SCREEN; ++x)
+                    for (int y = 0; y < SCREEN; ++y) {
+                        const int u = (x + ph) % P_.tile, w = y % P_.tile;
+                        const bool on_edge = u == 0 || w == 0 || u == P_.tile - 1 || w == P_.tile - 1;
+                        for (int c = 0; c < 3; ++c) t[(size_t)ph * FRAME_BYTES + ((size_t)x * SCREEN + y) * 3 + c] = on_edge ? edge[c] : ice[c];
+                    }
+            atlas_->set_templates(t);
+        }
         atlas_->upload();
         dirty_ = false;
     }

@@ -34,7 +34,8 @@ def mystery_opts(rng, env_id):
         return dict(max_steps=int(rng.choice([-1, 80, 200])), stamina_level=int(rng.integers(6, 30)), show_stamina=bool(rng.integers(0, 2)),
                     show_past_path=bool(rng.integers(0, 2)), visual_feedback=bool(rng.integers(0, 2)), reward_fall_off=_rew(rng),
                     reward_path_progress=_rew(rng), reward_path_progress_dense=_rew(rng), reward_step=_rew(rng),
-                    camera_offset_scale=float(rng.choice([3.0, 5.0, 7.0])))
+                    camera_offset_scale=float(rng.choice([3.0, 5.0, 7.0])), show_background=bool(rng.integers(0, 2)),
+                    agent_speed=float(rng.choice([2.0, 3.0, 4.0])))
     o = dict(max_steps=int(rng.integers(20, 200)), cardinal_origin_choice=_lst(rng, 0, 3, 4), show_origin=bool(rng.integers(0, 2)),
              show_goal=bool(rng.integers(0, 2)), visual_feedback=bool(rng.integers(0, 2)), reward_goal=_rew(rng), reward_fall_off=_rew(rng),
              reward_path_progress=_rew(rng), reward_step=_rew(rng))

@@ -80,6 +80,9 @@ EMP_OPTS = [
     dict(max_steps=300, stamina_level=12, reward_fall_off=-0.1, reward_path_progress_dense=0.05, reward_step=-0.001,
          camera_offset_scale=3.0),
     dict(show_stamina=True, show_past_path=False, visual_feedback=False),
+    dict(show_background=True),                                      # icy columns scrolling with the agent
+    dict(show_background=True, agent_speed=5.0, show_stamina=True),  # 5 px per step: phases 0, 5, 10, then 15 -> 0
+    dict(show_background=True, agent_speed=2.0, camera_offset_scale=3.0, max_steps=200),
 ]
 
 
