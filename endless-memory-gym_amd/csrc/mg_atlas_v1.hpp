@@ -26,9 +26,14 @@ class Atlas {
     }
 
     // stamp pixels are palette ids (0 = transparent); stored column-major [x][y]
-    int add_stamp(const Stamp& s) {
+    // max_px: what the composer that draws this stamp can hold in registers (256 pixels per StampRegs slot); a scale
+    // option that needs more is refused instead of being drawn truncated
+    int add_stamp(const Stamp& s, int max_px = 1 << 30) {
         int id = n_stamps_++;
         if (id >= MAX_STAMPS) throw std::runtime_error("too many stamps");
+        if (s.w * s.h > max_px)
+            throw OptionError{-3, "a *_scale reset parameter makes a sprite larger than the " + std::to_string(max_px) +
+                                      " pixels this build's raster holds per layer"};
         tables_.stamps[id].off = (uint32_t)data_.size();
         tables_.stamps[id].w = (uint16_t)s.w;
         tables_.stamps[id].h = (uint16_t)s.h;

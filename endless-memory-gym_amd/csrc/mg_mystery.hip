@@ -1158,8 +1158,8 @@ class MysteryFamily : public Family {
         Stamp cross = build_cross(SCALE);
         P_.cross_dim = cross.w;
         atlas_.reset(new Atlas());
-        for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
-        atlas_->add_stamp(cross);                         // 8
+        for (auto& sp : sprites) atlas_->add_stamp(sp, 1024);  // 0..7   (MysteryComposer: StampRegs<4>)
+        atlas_->add_stamp(cross, 256);                          // 8      (StampRegs<1>)
         if (P_.endless) {
             // show_background: draw_column_tile_surface / draw_icy_surface (pygame_assets.py:780-817) blitted every `tile`
             // pixels from x = bg_scroll - tile on (endless_mystery_path.py:141-143) = one template per scroll phase

@@ -999,12 +999,11 @@ class SpotFamily : public Family {
         P_.sin_tab = sin_.p;
 
         atlas_.reset(new Atlas());
-        for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
-        atlas_->add_stamp(build_coin(coin_scale_));       // 8
+        for (auto& sp : sprites) atlas_->add_stamp(sp, 256);  // 0..7   (SpotComposer::Pre holds StampRegs<1> per layer)
+        atlas_->add_stamp(build_coin(coin_scale_), 256);       // 8
         if (!P_.endless) {
-            if (exit_scale_ != 2.0 * SCALE) throw OptionError{-3, "exit_scale other than the default is not supported"};
-            atlas_->add_stamp(build_exit(exit_scale_, false));  // 9
-            atlas_->add_stamp(build_exit(exit_scale_, true));   // 10
+            atlas_->add_stamp(build_exit(exit_scale_, false), 256);  // 9
+            atlas_->add_stamp(build_exit(exit_scale_, true), 256);   // 10
         }
         atlas_->set_templates(build_chessboards(SCALE, SCREEN));
         atlas_->upload();

@@ -66,5 +66,7 @@ def last_error():
 
 
 def check(rc, what):
+    if rc == -3:  # an option value this build does not support (include/memgym.h), e.g. found when the geometry is rebuilt
+        raise NotImplementedError("%s: %s" % (what, last_error()))
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))

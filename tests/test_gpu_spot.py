@@ -127,3 +127,27 @@ def test_layers_above_the_dark_layer_finite(opts):
 @pytest.mark.parametrize("opts", [dict(agent_visible=True), dict(agent_visible=True, coins_visible=True), dict(agent_visible=True, light_dim_off_duration=0, light_threshold=90)])
 def test_layers_above_the_dark_layer_endless(opts):
     run_parity("Endless-SearingSpotlights-v0", opts, n=48, steps=200, policy=coin_seeker, n_policy=24)
+
+
+@pytest.mark.parametrize("env_id,opts", [("SearingSpotlights-v0", dict(exit_scale=0.75, coin_scale=0.5)), ("SearingSpotlights-v0", dict(exit_scale=0.3, agent_scale=0.2)),
+                                         ("Endless-SearingSpotlights-v0", dict(coin_scale=0.6, agent_scale=0.2))])
+def test_scale_options(env_id, opts):
+    run_parity(env_id, opts, n=48, steps=150, policy=coin_seeker, n_policy=24)
+
+
+def test_oversized_sprites_are_refused():
+    """A sprite that does not fit the raster's per-layer registers must be an error, not a truncated drawing."""
+    import memory_gym_amd
+
+    env = memory_gym_amd.make("SearingSpotlights-v0", num_envs=4, device=0)
+    with pytest.raises(NotImplementedError, match="sprite larger"):
+        env.reset(seed=0, options=dict(agent_scale=0.6))
+    with pytest.raises(NotImplementedError, match="sprite larger"):
+        env.reset(seed=0, options=dict(exit_scale=1.0))
+    env.reset(seed=0)  # the handle is still usable with supported values
+    env.close()
+    env = memory_gym_amd.make("MysteryPath-v0", num_envs=4, device=0)
+    with pytest.raises(NotImplementedError, match="sprite larger"):
+        env.reset(seed=0, options=dict(agent_scale=0.5))
+    env.reset(seed=0, options=dict(agent_scale=0.28))
+    env.close()
