@@ -1,6 +1,8 @@
 """GPU (-m gpu): randomised sweep over the reset-options space.  For every env id a seeded generator draws option
 dictionaries inside the ranges both the HIP path and the oracle support (lists for the "sample one per episode" keys,
 rewards, durations, sizes, speeds), and the HIP path must stay bit-exact with the oracle under random actions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -16,9 +18,11 @@ from option_fuzz import CASES  # noqa: E402
 def test_random_option_sets(env_id, gen):
     import memory_gym_amd
 
-    rng = np.random.Generator(np.random.PCG64(sum(map(ord, env_id))))
+    # MEMGYM_FUZZ_TRIALS / MEMGYM_FUZZ_SEED: one-off hunts with more and other draws
+    trials = int(os.environ.get("MEMGYM_FUZZ_TRIALS", "6"))
+    rng = np.random.Generator(np.random.PCG64(sum(map(ord, env_id)) + int(os.environ.get("MEMGYM_FUZZ_SEED", "0"))))
     tried = 0
-    for trial in range(6):
+    for trial in range(trials):
         options = gen(rng, env_id)
         try:  # ranges the build rejects raise from both sides alike; skip those draws (they are errors, not mismatches)
             memory_gym_amd.reset_params.process_reset_params(env_id, options)
