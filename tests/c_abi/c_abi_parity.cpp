@@ -1,0 +1,121 @@
+// tests/c_abi/c_abi_parity.cpp -- TEST INFRASTRUCTURE.  A C++ trainer's view of the drop-in boundary: no Python, no torch.
+// It drives libmemgym_hip.so through include/memgym.h with hipMalloc'd buffers on its own stream and checks every frame,
+// reward and done flag bit-exactly against the CPU oracle (oracle/_build/libmemgym_oracle.so, the checker only).
+// Usage: c_abi_parity ENV_ID NUM_ENVS STEPS   -> prints "OK ..." and exits 0, or the first mismatch and exits 1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "memgym.h"
+
+extern "C" {  // oracle/mgo_api.c
+struct mgo_batch;
+mgo_batch* mgo_batch_create(const char* env_id, int n, double scale);
+void mgo_batch_destroy(mgo_batch* b);
+void mgo_batch_reset(mgo_batch* b, const int64_t* seeds, uint8_t* obs);
+void mgo_batch_step(mgo_batch* b, const int32_t* actions, int autoreset, uint8_t* obs, double* reward, uint8_t* done);
+}
+
+#define HIP_OK(e)                                                                  \
+    do {                                                                           \
+        hipError_t e_ = (e);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_));                \
+            return 2;                                                              \
+        }                                                                          \
+    } while (0)
+#define MG_OK(e)                                                                   \
+    do {                                                                           \
+        if ((e) != 0) {                                                            \
+            fprintf(stderr, "%s: %s\n", #e, mg_last_error());                      \
+            return 2;                                                              \
+        }                                                                          \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s ENV_ID NUM_ENVS STEPS\n", argv[0]);
+        return 2;
+    }
+    const char* env_id = argv[1];
+    const int n = atoi(argv[2]), steps = atoi(argv[3]);
+    const size_t frame = 84 * 84 * 3;
+
+    HIP_OK(hipSetDevice(0));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    mg_env* env = nullptr;
+    MG_OK(mg_create(env_id, n, 0, &env));
+    const int adim = mg_action_dim(env), n_act = adim == 1 ? 4 : 3;
+
+    uint8_t *obs_d, *done_d;
+    float* rew_d;
+    int32_t* act_d;
+    int64_t* seeds_d;
+    HIP_OK(hipMalloc((void**)&obs_d, frame * n));
+    HIP_OK(hipMalloc((void**)&done_d, n));
+    HIP_OK(hipMalloc((void**)&rew_d, sizeof(float) * n));
+    HIP_OK(hipMalloc((void**)&act_d, sizeof(int32_t) * n * adim));
+    HIP_OK(hipMalloc((void**)&seeds_d, sizeof(int64_t) * n));
+
+    std::vector<int64_t> seeds(n);
+    for (int i = 0; i < n; ++i) seeds[i] = 100 + i;
+    HIP_OK(hipMemcpy(seeds_d, seeds.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
+
+    mgo_batch* ref = mgo_batch_create(env_id, n, 0.25);
+    if (!ref) {
+        fprintf(stderr, "oracle: unknown env id %s\n", env_id);
+        return 2;
+    }
+    std::vector<uint8_t> obs(frame * n), want(frame * n), done(n), want_done(n);
+    std::vector<float> rew(n);
+    std::vector<double> want_rew(n);
+    std::vector<int32_t> act((size_t)n * adim);
+
+    MG_OK(mg_reset(env, seeds_d, nullptr, obs_d, nullptr, stream));
+    HIP_OK(hipMemcpyAsync(obs.data(), obs_d, frame * n, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    mgo_batch_reset(ref, seeds.data(), want.data());
+    if (memcmp(obs.data(), want.data(), frame * n) != 0) {
+        printf("MISMATCH in the reset frames\n");
+        return 1;
+    }
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    long episodes = 0;
+    for (int t = 0; t < steps; ++t) {
+        for (size_t k = 0; k < act.size(); ++k) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            act[k] = (int32_t)((lcg >> 33) % (uint64_t)n_act);
+        }
+        HIP_OK(hipMemcpyAsync(act_d, act.data(), sizeof(int32_t) * act.size(), hipMemcpyHostToDevice, stream));
+        MG_OK(mg_step(env, act_d, obs_d, rew_d, done_d, nullptr, nullptr, 1, stream));
+        HIP_OK(hipMemcpyAsync(obs.data(), obs_d, frame * n, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(rew.data(), rew_d, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(done.data(), done_d, n, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        mgo_batch_step(ref, act.data(), 1, want.data(), want_rew.data(), want_done.data());
+        for (int i = 0; i < n; ++i) {
+            if (done[i] != want_done[i] || rew[i] != (float)want_rew[i] || memcmp(&obs[frame * i], &want[frame * i], frame) != 0) {
+                printf("MISMATCH at step %d, instance %d: done %d/%d reward %g/%g\n", t, i, done[i], want_done[i], rew[i], want_rew[i]);
+                return 1;
+            }
+            episodes += done[i];
+        }
+    }
+    int flags = 0;
+    MG_OK(mg_poll_errors(env, &flags));
+    if (flags) {
+        printf("device error flags 0x%x\n", flags);
+        return 1;
+    }
+    printf("OK %s: %d instances x %d steps, %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, episodes);
+    mg_destroy(env);
+    mgo_batch_destroy(ref);
+    (void)hipFree(obs_d); (void)hipFree(done_d); (void)hipFree(rew_d); (void)hipFree(act_d); (void)hipFree(seeds_d);
+    (void)hipStreamDestroy(stream);
+    return 0;
+}
