@@ -132,7 +132,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--obs-format", default="u8_xyc", choices=["u8_xyc", "f32_chw", "f16_chw", "bf16_chw"],
                     help="raster stream-out format; the BASELINE.json metric is quoted on the default (the reference's uint8 obs)")
-    ap.add_argument("--gather", action="store_true", help="RCCL gather of obs/reward/done to rank 0 every step")
+    ap.add_argument("--gather", nargs="?", const="rccl", default=None, choices=["rccl", "peer"],
+                    help="BASELINE config 5's observation gather to rank 0 every step: 'rccl' = torch.distributed.gather, "
+                         "'peer' = the raster kernels store straight into rank 0's HBM (memory_gym_amd.dist.PeerObsBuffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5-shard measurements (N = 1 only)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -161,7 +163,13 @@ def main():
     env_id = args.env
     n_local = args.envs_per_gpu or DEFAULT_ENVS[env_id]
     n_total = n_local * world
-    env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank, obs_format=args.obs_format)
+    peer = None
+    if args.gather == "peer" and world > 1:
+        from memory_gym_amd.dist import PeerObsBuffer
+        code, dt, shape = memory_gym_amd.VecMemoryGym.OBS_FORMATS[args.obs_format]
+        peer = PeerObsBuffer(n_total, frame_shape=shape, dtype=dt, device=dev)
+    env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank, obs_format=args.obs_format,
+                              obs_buffer=peer.local if peer else None)
     obs_elem = {"u8_xyc": 1, "f32_chw": 4, "f16_chw": 2, "bf16_chw": 2}[args.obs_format]
     # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
     from memory_gym_amd.dist import gather_to_rank0, shard_seeds
@@ -176,11 +184,13 @@ def main():
     else:
         acts = [torch.randint(0, 3, (n_local, 2), device=dev, generator=g, dtype=torch.int32) for _ in range(n_act_bufs)]
 
-    gather_bufs = [torch.empty_like(env.obs) for _ in range(world)] if (args.gather and world > 1 and rank == 0) else None
+    gather_bufs = [torch.empty_like(env.obs) for _ in range(world)] if (args.gather == "rccl" and world > 1 and rank == 0) else None
 
     def one_step(k):
         obs, rew, done, _, _ = env.step(acts[k % n_act_bufs])
-        if args.gather and world > 1:  # equal shards: plain gather into preallocated buffers (no per-step allocation)
+        if peer is not None:  # the frames are already in rank 0's memory; one 4-byte all-reduce orders the streams
+            peer.fence()
+        elif args.gather and world > 1:  # equal shards: plain gather into preallocated buffers (no per-step allocation)
             dist.gather(obs, gather_bufs, dst=0)
 
     for k in range(W):
@@ -219,10 +229,10 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format,
             "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 obs (%s), same-step auto-reset, uniform random "
                                    "actions generated on device%s" % (env_id, n_local, world, args.obs_format,
-                                                                     ", RCCL obs gather to rank 0" if args.gather and world > 1 else ""),
+                                                                     (", peer-mapped obs stores into rank 0's HBM" if peer is not None else ", RCCL obs gather to rank 0") if args.gather and world > 1 else ""),
                        "env_id": env_id, "envs_per_gpu": n_local, "envs_total": n_total,
                        "parallelism": "env-sharded x%d, no data-path collective" % world if not args.gather else
-                       "env-sharded x%d + gather(obs)->rank0" % world},
+                       "env-sharded x%d + %s(obs)->rank0" % (world, "peer-mapped stores" if peer is not None else "gather")},
         }
         if raster_n:
             avg_ms = raster_ms / raster_n

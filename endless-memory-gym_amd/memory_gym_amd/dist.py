@@ -5,7 +5,12 @@ the CPU tests).  Environment instances are independent, so the path shards with 
     base_seed + i whatever W is, so results do not depend on the world size.
 
 The only (optional) exchange is BASELINE config 5's gather of observations/rewards/dones to rank 0 for a
-single-learner rollout.
+single-learner rollout.  Two forms with the same result on rank 0:
+
+    gather_to_rank0   a torch.distributed gather (RCCL send/recv): every rank writes its frames locally, then ships them;
+    PeerObsBuffer     rank 0's [N_total, ...] observation tensor is mapped into every rank (HIP IPC, peer access over
+                      xGMI) and handed to VecMemoryGym as `obs_buffer`: the raster kernels store their frames straight
+                      into rank 0's HBM -- no second copy, no collective on the data path (only a barrier per step).
 """
 import torch
 import torch.distributed as dist
@@ -41,3 +46,39 @@ def gather_to_rank0(tensor, dst=0, group=None):
     if rank != dst:
         return None
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+class PeerObsBuffer:
+    """Rank `dst`'s observation tensor [N_total, *frame_shape], shared with every rank of `group`.
+
+    `full` is the whole tensor (memory on dst's GPU, mapped into this process), `local` this rank's rows
+    `shard_range(N_total, rank, world)` -- pass it as `obs_buffer=` to `memory_gym_amd.make`.  `fence()` is the per-step
+    synchronisation: after it returns on dst, every rank's frames of the step are in `full`.
+
+    The mapping uses torch's CUDA-IPC tensor sharing (`hipIpcGetMemHandle` / `hipIpcOpenMemHandle`, dmabuf mode:
+    keep HSA_ENABLE_IPC_MODE_LEGACY=0); dst must keep the object alive while the others use it."""
+
+    def __init__(self, n_total, frame_shape=(84, 84, 3), dtype=torch.uint8, device=None, dst=0, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.rank, self.world, self.dst, self.group = dist.get_rank(group), dist.get_world_size(group), dst, group
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        payload = [None]
+        if self.rank == dst:
+            self.full = torch.empty((int(n_total),) + tuple(frame_shape), dtype=dtype, device=self.device)
+            payload[0] = reduce_tensor(self.full)  # (rebuild function, picklable arguments incl. the IPC handle)
+        dist.broadcast_object_list(payload, src=dst, group=group)
+        if self.rank != dst:
+            rebuild, args = payload[0]
+            self.full = rebuild(*args)
+        lo, hi = shard_range(n_total, self.rank, self.world)
+        self.local = self.full[lo:hi]
+        self._token = torch.zeros(1, device=self.device)
+
+    def fence(self):
+        """Stream-ordered on the nccl backend (a 4-byte all-reduce enqueued behind this rank's kernels); on gloo the
+        device is synchronised first."""
+        if dist.get_backend(self.group) != "nccl":
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+        else:
+            dist.all_reduce(self._token, group=self.group)

@@ -60,7 +60,8 @@ class VecMemoryGym:
     OBS_FORMATS = {"u8_xyc": (0, torch.uint8, (84, 84, 3)), "f32_chw": (1, torch.float32, (3, 84, 84)),
                    "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
-    def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False):
+    def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False,
+                 obs_buffer=None):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -87,7 +88,14 @@ class VecMemoryGym:
         code, dt, shape = self.OBS_FORMATS[obs_format]
         _native.check(_native.LIB.mg_set_obs_format(h, code), "mg_set_obs_format")
         assert _native.LIB.mg_obs_bytes(h) == 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
-        self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
+        if obs_buffer is None:
+            self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
+        else:
+            # caller-owned observation memory: the raster kernel writes the frames there (any device-accessible address,
+            # e.g. this rank's rows of a peer-mapped buffer on another GPU: memory_gym_amd.dist.PeerObsBuffer)
+            if tuple(obs_buffer.shape) != (N,) + shape or obs_buffer.dtype != dt or not obs_buffer.is_cuda or not obs_buffer.is_contiguous():
+                raise ValueError("obs_buffer must be a contiguous CUDA tensor of shape %s and dtype %s" % ((N,) + shape, dt))
+            self.obs = obs_buffer
         # gymnasium-0.29 vector convention: keep the terminal frame of instances that finish (and auto-reset) in a step
         self.final_obs = torch.zeros((N,) + shape, dtype=dt, device=dev) if final_observation else None
         # MortarMayhemB*: obs is the reference's Dict; `vector_obs` is written by the library whenever an instance resets
