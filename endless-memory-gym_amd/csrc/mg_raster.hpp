@@ -46,8 +46,9 @@ constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
 constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
-constexpr int RASTER_GRID = 256 * 7 * 8;      // 7 workgroups fit one CU's 160 KiB of LDS; 8 rounds of persistent workgroups (bench sweep: best of 2..37)
+constexpr int RASTER_GRID = 256 * 7 * 8;      // persistent workgroups; flat between 10,752 and 14,336 at five resident workgroups per CU
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
+constexpr int RASTER_LDS_REQUEST = 28 * 1024;  // uint8 format: see launch_raster
 
 struct StampInfo {
     uint32_t off;  // pixel offset into the stamp data, pixels stored [x][y] (column-major like the frame)
@@ -399,10 +400,16 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         const char* e = getenv("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : RASTER_GRID;
     }();
-    static const int lds = [] {  // MEMGYM_RASTER_LDS inflates the LDS request (fewer resident workgroups per CU; tuning only)
+    // The kernel needs RASTER_LDS (22,176 B: 7 workgroups per CU); for the uint8 format, whose stores are non-temporal,
+    // it asks for 28 KiB = FIVE per CU: that stream is faster with fewer concurrent writers (Endless-SearingSpotlights
+    // raster, same call: 7 per CU 78-82 us, 6: 72-77, 5: 72-73, 4: 81, 3: 138; with plain stores -- the float formats, or
+    // this format without the hint -- it is the other way round, 7: 85, 5: 98: profiles/r01j_ess_raster_ablation.md).
+    // MEMGYM_RASTER_LDS overrides the request (tuning only).
+    static const int forced_lds = [] {
         const char* e = getenv("MEMGYM_RASTER_LDS");
-        return e && atoi(e) > RASTER_LDS ? atoi(e) : RASTER_LDS;
+        return e && atoi(e) >= RASTER_LDS ? atoi(e) : 0;
     }();
+    const int lds = forced_lds ? forced_lds : (fmt == MG_OBS_U8_XYC ? RASTER_LDS_REQUEST : RASTER_LDS);
     const int grid = n < tuned ? n : tuned;
     if (fmt == MG_OBS_F32_CYX)
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
