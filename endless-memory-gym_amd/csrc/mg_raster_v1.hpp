@@ -39,7 +39,7 @@ constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
 constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
-constexpr int RASTER_GRID = 256 * 7 * 8;      // 7 workgroups fit one CU's 160 KiB of LDS; 8 rounds of persistent workgroups (bench sweep: best of 2..37)
+constexpr int RASTER_GRID = 256 * 7 * 8;      // persistent workgroups (bench sweep at seven per CU: best of 2..37 rounds)
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
 
 struct StampInfo {
@@ -242,14 +242,22 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         return e ? atoi(e) : RASTER_GRID;
     }();
     const int grid = n < tuned ? n : tuned;
+    // The kernel uses RASTER_LDS (22,176 B: seven workgroups per CU) and asks for 24 KiB = SIX per CU: 1-3 % faster on every
+    // generation-1 workload, three repetitions each in one call (MortarMayhem-Grid 257.7-258.8 -> 252.6-253.6 us,
+    // Endless-MortarMayhem 134.9-137.7 -> 133.5-134.0, Endless-MysteryPath 141.1-141.8 -> 137.6-138.8, MysteryPath
+    // 135.1-139.1 -> 135.8-138.0); five per CU is slower again (261 us).  MEMGYM_RASTER_LDS overrides (tuning only).
+    static const int lds = [] {
+        const char* e = getenv("MEMGYM_RASTER_LDS");
+        return e && atoi(e) >= RASTER_LDS ? atoi(e) : 24 * 1024;
+    }();
     if (fmt == MG_OBS_F32_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else if (fmt == MG_OBS_BF16_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_BF16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else if (fmt == MG_OBS_F16_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
 }
 
 }  // namespace v1
