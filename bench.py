@@ -252,6 +252,8 @@ def main():
                                "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": raster_n, "event_stride": max(1, args.event_stride),
                                "logic_kernel_avg_ms": (logic_ms / logic_n) if logic_n else None,
                                "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * n_total / (dt_max / K) / 1e9}
+        if getattr(env, "placement_probe_ms", None):  # raster time into each candidate allocation of the observation buffer
+            out["obs_placement_probe_ms"] = [round(t, 4) for t in env.placement_probe_ms]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(env_id)

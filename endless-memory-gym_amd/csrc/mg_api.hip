@@ -125,6 +125,13 @@ int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, voi
     });
 }
 
+int mg_render(mg_env* env, void* obs_dev, void* stream) {
+    return guarded(env, [&] {
+        if (!obs_dev) throw std::runtime_error("mg_render: obs_dev is NULL");
+        env->fam->raster_only(obs_dev, nullptr, (hipStream_t)stream);
+    });
+}
+
 int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* reward_dev, uint8_t* done_dev, float* gt_dev,
             const mg_info_buffers* info, int autoreset, void* stream) {
     return guarded(env, [&] {

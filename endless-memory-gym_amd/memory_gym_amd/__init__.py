@@ -15,11 +15,12 @@ from .vector import GymnasiumVectorEnv  # noqa: F401
 
 
 
-def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False, obs_buffer=None):
+def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False, obs_buffer=None,
+         tune_placement=None):
     if num_envs is None:
         return MemoryGymEnv(env_id, device=device, render_mode=render_mode)
     return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode, obs_format=obs_format,
-                        final_observation=final_observation, obs_buffer=obs_buffer)
+                        final_observation=final_observation, obs_buffer=obs_buffer, tune_placement=tune_placement)
 
 
 def _register_with_gymnasium():

@@ -99,6 +99,12 @@ size_t mg_obs_bytes(const mg_env* env);
 int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, void* obs_dev, float* gt_dev,
              void* stream);
 
+/* Rasterise the CURRENT frame of every instance again into obs_dev (the frame the last mg_reset / mg_step produced; the
+ * reference's _draw_surfaces + surfarray.array3d without stepping, e.g. mortar_mayhem_grid.py:92-102,373).  No state
+ * changes; instances that the last call left untouched (a masked mg_reset) are skipped here as well.  Uses: observations into a second buffer, a changed observation format, and the placement probe of the
+ * Python mirror (the store stream is 8-13 % faster into some allocations than into others: profiles/r01l_placement.md). */
+int mg_render(mg_env* env, void* obs_dev, void* stream);
+
 /* Env.step(action) (e.g. mortar_mayhem_grid.py:280-375) for all instances.
  * actions_dev: int32 [num_envs] (Discrete) or [num_envs][2] (MultiDiscrete).
  * reward_dev: float32 [num_envs] (the reference's Python float, rounded once to float32);
