@@ -205,30 +205,40 @@ class VecMemoryGym:
         k = int(min(candidates, budget_bytes // nbytes, (free // 2) // nbytes))
         if k < 2:
             return
-        scratch = VecMemoryGym(self.env_id, self.num_envs, device=self.device, obs_format=self.obs_format, tune_placement=False,
-                               obs_buffer=self.obs)
         keep = self.obs.clone()  # the scratch handle draws over the frames of this reset
-        bufs = [self.obs] + [torch.empty_like(self.obs) for _ in range(k - 1)]
-        scratch.reset(seed=0)
-        a = torch.zeros((self.num_envs,) if self.action_dim == 1 else (self.num_envs, 2), dtype=torch.int32, device=self.device)
-        times = []
-        for b in bufs:
-            scratch.obs = b
-            for _ in range(4):
-                scratch.step(a)
-            scratch.set_profiling(1)
-            for _ in range(probe_steps):
-                scratch.step(a)
-            ms, cnt = scratch.get_profile(1)
-            scratch.set_profiling(0)
-            times.append(ms / max(cnt, 1))
-        scratch.obs = keep  # (any tensor: the handle is closed next)
-        scratch.close()
-        best = min(range(k), key=lambda i: times[i])
-        self.placement_probe_ms = times  # kept for inspection (bench.py reports it)
-        self.obs = bufs[best]
+        first = self.obs
+        scratch = None
+        try:
+            scratch = VecMemoryGym(self.env_id, self.num_envs, device=self.device, obs_format=self.obs_format, tune_placement=False,
+                                   obs_buffer=self.obs)
+            bufs = [self.obs] + [torch.empty_like(self.obs) for _ in range(k - 1)]
+            scratch.reset(seed=0)
+            a = torch.zeros((self.num_envs,) if self.action_dim == 1 else (self.num_envs, 2), dtype=torch.int32, device=self.device)
+            times = []
+            for b in bufs:
+                scratch.obs = b
+                for _ in range(4):
+                    scratch.step(a)
+                scratch.set_profiling(1)
+                for _ in range(probe_steps):
+                    scratch.step(a)
+                ms, cnt = scratch.get_profile(1)
+                scratch.set_profiling(0)
+                times.append(ms / max(cnt, 1))
+            best = min(range(k), key=lambda i: times[i])
+            self.placement_probe_ms = times  # kept for inspection (bench.py reports it)
+            self.obs = bufs[best]
+            del bufs
+        except (RuntimeError, MemoryError) as e:  # e.g. not enough memory for the scratch handle: keep the first allocation
+            import warnings
+            warnings.warn("memory_gym_amd: observation placement probe skipped (%s)" % (e,))
+            self.obs = first
+        finally:
+            if scratch is not None:
+                scratch.obs = keep  # (any live tensor: the handle is closed next)
+                scratch.close()
         self.obs.copy_(keep)
-        del bufs, keep
+        del keep
 
     def step(self, actions):
         with torch.cuda.device(self.device):
