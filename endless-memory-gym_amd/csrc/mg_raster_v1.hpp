@@ -242,13 +242,12 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         return e ? atoi(e) : RASTER_GRID;
     }();
     const int grid = n < tuned ? n : tuned;
-    // The kernel uses RASTER_LDS (22,176 B: seven workgroups per CU) and asks for 24 KiB = SIX per CU: 1-3 % faster on every
-    // generation-1 workload, three repetitions each in one call (MortarMayhem-Grid 257.7-258.8 -> 252.6-253.6 us,
-    // Endless-MortarMayhem 134.9-137.7 -> 133.5-134.0, Endless-MysteryPath 141.1-141.8 -> 137.6-138.8, MysteryPath
-    // 135.1-139.1 -> 135.8-138.0); five per CU is slower again (261 us).  MEMGYM_RASTER_LDS overrides (tuning only).
+    // MEMGYM_RASTER_LDS inflates the LDS request = fewer resident workgroups per CU (tuning only).  Seven per CU (what
+    // fits) is the optimum once the observation buffer sits in a fast allocation (profiles/r01l_placement.md):
+    // MortarMayhem-Grid 223.4-224.5 us at 7, 229.4 at 6, 243-244 at 5; in a slow allocation 6 was 1-3 % ahead of 7.
     static const int lds = [] {
         const char* e = getenv("MEMGYM_RASTER_LDS");
-        return e && atoi(e) >= RASTER_LDS ? atoi(e) : 24 * 1024;
+        return e && atoi(e) >= RASTER_LDS ? atoi(e) : RASTER_LDS;
     }();
     if (fmt == MG_OBS_F32_CYX)
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
