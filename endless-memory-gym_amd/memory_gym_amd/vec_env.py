@@ -249,6 +249,7 @@ class VecMemoryGym:
                 scratch.close()
         self.obs.copy_(keep)
         del keep
+        torch.cuda.empty_cache()  # the rejected candidates go back to the driver, not into torch's cache
 
     def step(self, actions):
         with torch.cuda.device(self.device):
