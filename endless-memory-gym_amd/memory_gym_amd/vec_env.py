@@ -191,14 +191,15 @@ class VecMemoryGym:
         info = {"ground_truth": self.gt} if self.gt_dim else {}
         return self._obs(), info
 
-    def _tune_placement(self, candidates=16, budget_bytes=32 << 30, probe_steps=24):
+    def _tune_placement(self, candidates=32, budget_bytes=64 << 30, probe_steps=24):
         """The raster kernel's store stream is 6-13 % faster into some allocations of the observation buffer than into
         others (same size, same 2-MiB alignment, same process: MortarMayhem-Grid 232-234 vs 249-253 us, MysteryPath 119
         vs 138 us -- profiles/r01l_placement.md), a property that stays with the allocation and only shows with the
         logic kernel running between the raster launches.  Once, after the first full reset: allocate candidate
         tensors one after the other, let a scratch handle of the same env id take real steps into each (raster
         launches bracketed with events by the library) until one is clearly in the fast mode (>= 5 % faster than the
-        slowest seen, at least three tried) or 16 candidates / 32 GB / half of the free memory are used up, and keep the
+        slowest seen, at least three tried) or 32 candidates / 64 GB / half of the free memory are used up (slow runs of up
+        to eight consecutive 1.4-GB allocations were seen), and keep the
         fastest for this handle.  `env.obs` may be a different tensor
         afterwards; reset() returns it.  MEMGYM_TUNE_PLACEMENT=0 or tune_placement=False switches this off."""
         self._placement_pending = False
