@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- aggregate env-steps/s of the batched Memory Gym hot path on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--env ID] [--envs-per-gpu M] [--gather]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--env ID] [--envs-per-gpu M] [--gather [rccl|peer]]
 
 A "step" is one mg_step() over every instance of the workload: logic kernel + raster kernel, with
 same-step auto-reset, 84x84x3 uint8 observations written to HBM.  Inputs (actions) are generated on the device
-before the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), instances sharded
-with no data-path collective (weak scaling: per-GPU work fixed); --gather adds the optional RCCL gather of
-observations to rank 0 that BASELINE.json's config 5 names.
+before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (raster kernel, HIP events on the
-launch stream inside the timed region) and `cpu_baseline` (the CPU oracle = a port of the reference's algorithm,
-bounded sample, OpenMP over instances; rank 0, N=1 only).
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), instances sharded with no data-path collective
+(weak scaling: per-GPU work fixed).  `python bench.py --gpus N` alone spawns the N ranks itself (one per GPU, rendezvous on
+127.0.0.1); launched under torch.distributed.run it uses the ranks it is given.  After the headline workload an N > 1
+run also measures BASELINE.json's config 5 (Endless-MortarMayhem-v0, 32,768 instances per GPU) without gather, with the
+RCCL gather of observations to rank 0 and with the peer-mapped variant, reported under "config5".
+
+Setup (not timed, not counted as warm-up): reset of every instance and `--settle` steps with random actions, so that the
+episodes de-synchronise -- right after a reset all instances are in the same phase of their episode and the first ~40
+raster launches are 10-20 % slower than the stationary mix.  Then W warm-up steps, then EXACTLY K timed steps between
+barrier + synchronize on both sides (max over ranks).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (raster kernel, HIP events recorded by
+the library on the launch stream: every 8th step of the timed region when K >= 64; for shorter runs the timed region stays
+undisturbed and the 32 steps after it are all bracketed) and `cpu_baseline` (the CPU oracle = a port of the reference's
+algorithm, bounded sample, OpenMP over instances, timed in a subprocess; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,41 +39,87 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 FRAME = 84 * 84 * 3
 # algorithmic bytes of the RASTER kernel per env-step: the observation it writes + the 16-byte draw descriptor it reads.
 # (Whole step incl. logic kernel state/action/reward traffic, SURVEY.md 8(d): MM-Grid 21,305 B.)
-RASTER_BYTES = {"default": FRAME + 16}
 STEP_BYTES = {"MortarMayhem-Grid-v0": 21305, "MortarMayhem-v0": 21309, "Endless-MortarMayhem-v0": 21821,
               "MysteryPath-v0": 21437, "Endless-SearingSpotlights-v0": 22205}
 DEFAULT_ENVS = {"MortarMayhem-Grid-v0": 65536, "MortarMayhem-v0": 65536, "MortarMayhemB-Grid-v0": 65536, "MortarMayhemB-v0": 65536, "Endless-MortarMayhem-v0": 32768,
                 "MysteryPath-v0": 32768, "MysteryPath-Grid-v0": 32768, "Endless-MysteryPath-v0": 32768, "SearingSpotlights-v0": 16384,
                 "Endless-SearingSpotlights-v0": 16384}
+OBS_ELEM = {"u8_xyc": 1, "f32_chw": 4, "f16_chw": 2, "bf16_chw": 2}
 
 
-def cpu_baseline(env_id, budget_s=15.0):
-    """Time the CPU oracle (oracle/: a restatement of the reference's per-instance algorithm, incl. its software
-    raster) on this host.  Bounded sample: `n` instances stepped with auto-reset for ~budget_s seconds."""
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_worker(env_id, threads, budget_s):
+    """(subprocess) Time the CPU oracle -- oracle/: a restatement of the reference's per-instance algorithm incl. its
+    software raster -- with `threads` OpenMP threads (the environment variables were set before this process started).
+    Observation, reward and done buffers are allocated once; a step touches no fresh memory."""
     import numpy as np
 
     import oracle_lib
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    n = 64 * cores
+    n = 64 * threads if threads > 1 else 256
     b = oracle_lib.OracleBatch(env_id, n)
     disc = b.discrete
-    b.reset(np.arange(n, dtype=np.int64))
+    obs = np.zeros((n, 84, 84, 3), np.uint8)
+    rew, done = np.zeros(n, np.float64), np.zeros(n, np.uint8)
+    b.reset(np.arange(n, dtype=np.int64), out=obs)
     g = np.random.Generator(np.random.PCG64(0))
     acts = [(g.integers(0, 4, n) if disc else g.integers(0, 3, (n, 2))).astype(np.int32) for _ in range(16)]
-    for a in acts[:2]:
-        b.step(a, autoreset=True)
+    for a in acts[:3]:
+        b.step(a, autoreset=True, out=(obs, rew, done))
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < budget_s:
-        b.step(acts[steps % 16], autoreset=True)
+        b.step(acts[steps % 16], autoreset=True, out=(obs, rew, done))
         steps += 1
     dt = time.perf_counter() - t0
     b.close()
-    return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d instances x %d steps of %s, CPU oracle (C, OpenMP over instances, incl. software raster), %.1f s"
-                      % (n, steps, env_id, dt)}
+    print(json.dumps({"value": n * steps / dt, "instances": n, "steps": steps, "seconds": dt, "threads": threads}))
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that shows 256
+    CPUs but may burn 16 CPU-seconds per second runs 256 busy threads at a sixteenth of their speed)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota)))
+    return n
+
+
+def cpu_baseline(env_id):
+    """Single-thread and all-core rate of the CPU oracle on this host, each in its own subprocess so that the OpenMP
+    runtime is configured before it loads (OMP_NUM_THREADS / OMP_PROC_BIND)."""
+    cores = usable_cpus()
+    res = {}
+    for threads, budget in ((1, 4.0), (cores, 12.0)):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", env_id, str(threads), str(budget)],
+                             env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if not line:
+            raise RuntimeError("cpu worker failed: " + out.stderr[-300:])
+        res[threads] = json.loads(line[-1])
+        if cores == 1:
+            break
+    one, allc = res[1], res[cores]
+    return {"value": allc["value"], "unit": "env steps/s", "cores": cores, "kind": "port",
+            "cores_note": "usable CPUs = affinity mask (%d) capped by the cgroup CPU quota" % (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores),
+            "single_thread": one["value"], "scaling_efficiency": allc["value"] / (cores * one["value"]),
+            "sample": "%s, CPU oracle (C, incl. software raster, preallocated buffers): %d instances x %d steps on %d OpenMP "
+                      "threads in %.1f s; 1 thread: %d instances x %d steps in %.1f s"
+                      % (env_id, allc["instances"], allc["steps"], cores, allc["seconds"], one["instances"], one["steps"], one["seconds"])}
 
 
 def pygame_baseline(env_id, episodes=30):
@@ -88,39 +146,129 @@ def pygame_baseline(env_id, episodes=30):
             "sample": "%d episodes of %s, PyGame reference, 1 process" % (episodes, env_id)}
 
 
-def secondary_workloads(primary, device_index, steps=200, warmup=30):
-    """The other single-GPU BASELINE configs (C3, C4, the per-GPU shard of C5), measured the same way after the headline
-    run so that one bench line carries them; informational (the contract's `value` is the headline workload's)."""
+# ---------------------------------------------------------------------------------------------------------------- one workload
+def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8_xyc", gather=None, events=True, event_stride=8):
+    """Create the environments, settle, warm up, time K steps; returns a dict (identical on every rank)."""
     import torch
+    import torch.distributed as dist
 
     import memory_gym_amd
+    from memory_gym_amd.dist import PeerObsBuffer, shard_seeds
 
+    n_total = n_local * world
+    peer = None
+    note = None
+    if gather == "peer" and world > 1:
+        code, dt_, shape = memory_gym_amd.VecMemoryGym.OBS_FORMATS[obs_format]
+        peer = PeerObsBuffer(n_total, frame_shape=shape, dtype=dt_, device=dev)
+        if not peer.ok:  # no peer access between this GPU and rank 0's: fall back to the collective
+            note = "peer mapping unavailable (%s): fell back to the RCCL gather" % peer.why
+            peer, gather = None, "rccl"
+    env = memory_gym_amd.make(env_id, num_envs=n_local, device=dev.index, obs_format=obs_format,
+                              obs_buffer=peer.local if peer else None)
+    # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
+    env.reset(seed=shard_seeds(n_total, rank, world, base_seed=0, device=dev))
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_act_bufs = 64
+    shape, hi = ((n_local,), 4) if env.action_dim == 1 else ((n_local, 2), 3)
+    acts = [torch.randint(0, hi, shape, device=dev, generator=g, dtype=torch.int32) for _ in range(n_act_bufs)]
+    gather_bufs = [torch.empty_like(env.obs) for _ in range(world)] if (gather == "rccl" and world > 1 and rank == 0) else None
+
+    def one_step(k):
+        obs, rew, done, _, _ = env.step(acts[k % n_act_bufs])
+        if peer is not None:  # the frames are already in rank 0's memory; one 4-byte all-reduce orders the streams
+            peer.fence()
+        elif gather and world > 1:  # equal shards: plain gather into preallocated buffers (no per-step allocation)
+            dist.gather(obs, gather_bufs, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(settle):  # setup: de-synchronise the episodes
+        one_step(k)
+    for k in range(W):
+        one_step(settle + k)
+    in_region = events and K >= 64
+    if in_region:
+        env.set_profiling(max(1, event_stride))
+    fence()
+    t0 = time.perf_counter()
+    for k in range(K):
+        one_step(settle + W + k)
+    fence()
+    dt = time.perf_counter() - t0
+    raster_ms = raster_n = logic_ms = logic_n = 0
+    region = None
+    if events:
+        if in_region:
+            region = "every %d-th step of the timed region" % max(1, event_stride)
+        else:  # short run: keep the timed region undisturbed, bracket every launch of the 32 steps after it
+            env.set_profiling(1)
+            for k in range(32):
+                one_step(settle + W + K + k)
+            region = "32 steps right after the timed region, every launch bracketed"
+        raster_ms, raster_n = env.get_profile(1)
+        logic_ms, logic_n = env.get_profile(0)
+        env.set_profiling(False)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    out = {"env_id": env_id, "n_local": n_local, "n_total": n_total, "seconds": dt_max, "value": n_total * K / dt_max,
+           "ms_per_step": dt_max / K * 1e3, "raster_avg_ms": raster_ms / raster_n if raster_n else None, "raster_launches": raster_n,
+           "logic_avg_ms": logic_ms / logic_n if logic_n else None, "event_region": region,
+           "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if world > 1 else None, "note": note}
+    env.close()
+    del env, gather_bufs, peer
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_workloads(primary, dev, settle):
+    """The other single-GPU BASELINE configs (C3, C4, the per-GPU shard of C5), measured the same way after the headline
+    run so that one bench line carries them; informational (the contract's `value` is the headline workload's)."""
     out = []
     for env_id, label in (("MysteryPath-v0", "C3"), ("Endless-SearingSpotlights-v0", "C4"), ("Endless-MortarMayhem-v0", "C5 per-GPU shard")):
         if env_id == primary:
             continue
-        n = DEFAULT_ENVS[env_id]
-        env = memory_gym_amd.make(env_id, num_envs=n, device=device_index)
-        env.reset(seed=0)
-        g = torch.Generator(device="cuda").manual_seed(99)
-        shape, hi = ((n,), 4) if env.action_dim == 1 else ((n, 2), 3)
-        acts = [torch.randint(0, hi, shape, device="cuda", generator=g, dtype=torch.int32) for _ in range(32)]
-        for k in range(warmup):
-            env.step(acts[k % 32])
-        env.set_profiling(8)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            env.step(acts[k % 32])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        rm, rn = env.get_profile(1)
-        lm, ln = env.get_profile(0)
-        env.close()
-        out.append({"config": label, "workload": "%s, %d envs" % (env_id, n), "value": n * steps / dt, "unit": "env steps/s",
-                    "ms_per_step": dt / steps * 1e3, "raster_avg_ms": rm / rn if rn else None, "logic_avg_ms": lm / ln if ln else None,
-                    "raster_GBps": (FRAME + 16) * n / (rm / rn * 1e-3) / 1e9 if rn else None})
+        r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev)
+        out.append({"config": label, "workload": "%s, %d envs" % (env_id, r["n_local"]), "value": r["value"], "unit": "env steps/s",
+                    "ms_per_step": r["ms_per_step"], "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"],
+                    "raster_GBps": (FRAME + 16) * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 if r["raster_avg_ms"] else None,
+                    "obs_placement_zones": (r["obs_placement"] or {}).get("zones")})
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- launch
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU); rank 0 prints the JSON line."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print("bench.py: --gpus %d but this host shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -128,23 +276,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--settle", type=int, default=200, help="setup steps after the reset (episodes de-synchronise); not timed, not warm-up")
     ap.add_argument("--env", default="MortarMayhem-Grid-v0")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
-    ap.add_argument("--obs-format", default="u8_xyc", choices=["u8_xyc", "f32_chw", "f16_chw", "bf16_chw"],
+    ap.add_argument("--obs-format", default="u8_xyc", choices=sorted(OBS_ELEM),
                     help="raster stream-out format; the BASELINE.json metric is quoted on the default (the reference's uint8 obs)")
     ap.add_argument("--gather", nargs="?", const="rccl", default=None, choices=["rccl", "peer"],
-                    help="BASELINE config 5's observation gather to rank 0 every step: 'rccl' = torch.distributed.gather, "
+                    help="observation gather to rank 0 every step for the HEADLINE workload: 'rccl' = torch.distributed.gather, "
                          "'peer' = the raster kernels store straight into rank 0's HBM (memory_gym_amd.dist.PeerObsBuffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5-shard measurements (N = 1 only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5 measurements")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every N-th step with HIP events (each bracketed step costs ~15 us)")
+    ap.add_argument("--cpu-worker", nargs=3, metavar=("ENV", "THREADS", "SECONDS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker[0], int(args.cpu_worker[1]), float(args.cpu_worker[2]))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
-
-    import memory_gym_amd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -156,120 +308,84 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d (the launcher decides)" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
 
     env_id = args.env
     n_local = args.envs_per_gpu or DEFAULT_ENVS[env_id]
-    n_total = n_local * world
-    peer = None
-    if args.gather == "peer" and world > 1:
-        from memory_gym_amd.dist import PeerObsBuffer
-        code, dt, shape = memory_gym_amd.VecMemoryGym.OBS_FORMATS[args.obs_format]
-        peer = PeerObsBuffer(n_total, frame_shape=shape, dtype=dt, device=dev)
-    env = memory_gym_amd.make(env_id, num_envs=n_local, device=local_rank, obs_format=args.obs_format,
-                              obs_buffer=peer.local if peer else None)
-    obs_elem = {"u8_xyc": 1, "f32_chw": 4, "f16_chw": 2, "bf16_chw": 2}[args.obs_format]
-    # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
-    from memory_gym_amd.dist import gather_to_rank0, shard_seeds
-    seeds = shard_seeds(n_total, rank, world, base_seed=0, device=dev)
-    env.reset(seed=seeds)
-
     K, W = args.steps, args.warmup
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act_bufs = min(K + W, 64)
-    if env.action_dim == 1:
-        acts = [torch.randint(0, 4, (n_local,), device=dev, generator=g, dtype=torch.int32) for _ in range(n_act_bufs)]
-    else:
-        acts = [torch.randint(0, 3, (n_local, 2), device=dev, generator=g, dtype=torch.int32) for _ in range(n_act_bufs)]
+    r = run_workload(env_id, n_local, K, W, args.settle, world, rank, dev, args.obs_format, args.gather, not args.no_events, args.event_stride)
+    obs_elem = OBS_ELEM[args.obs_format]
 
-    gather_bufs = [torch.empty_like(env.obs) for _ in range(world)] if (args.gather == "rccl" and world > 1 and rank == 0) else None
-
-    def one_step(k):
-        obs, rew, done, _, _ = env.step(acts[k % n_act_bufs])
-        if peer is not None:  # the frames are already in rank 0's memory; one 4-byte all-reduce orders the streams
-            peer.fence()
-        elif args.gather and world > 1:  # equal shards: plain gather into preallocated buffers (no per-step allocation)
-            dist.gather(obs, gather_bufs, dst=0)
-
-    for k in range(W):
-        one_step(k)
-    if not args.no_events:
-        env.set_profiling(max(1, args.event_stride))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        one_step(W + k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
-    raster_ms = raster_n = logic_ms = logic_n = 0
-    if not args.no_events:
-        raster_ms, raster_n = env.get_profile(1)
-        logic_ms, logic_n = env.get_profile(0)
-        env.set_profiling(False)
-
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
-
+    out = None
     if rank == 0:
-        value = n_total * K / dt_max
+        gather_txt = ""
+        if r["gather"]:
+            gather_txt = ", peer-mapped obs stores into rank 0's HBM" if r["gather"] == "peer" else ", RCCL obs gather to rank 0"
         out = {
-            "metric": "env steps/sec (aggregate)", "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format,
+            "metric": "env steps/sec (aggregate)", "value": r["value"], "unit": "env steps/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format, "setup_steps": args.settle,
             "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 obs (%s), same-step auto-reset, uniform random "
-                                   "actions generated on device%s" % (env_id, n_local, world, args.obs_format,
-                                                                     (", peer-mapped obs stores into rank 0's HBM" if peer is not None else ", RCCL obs gather to rank 0") if args.gather and world > 1 else ""),
-                       "env_id": env_id, "envs_per_gpu": n_local, "envs_total": n_total,
-                       "parallelism": "env-sharded x%d, no data-path collective" % world if not args.gather else
-                       "env-sharded x%d + %s(obs)->rank0" % (world, "peer-mapped stores" if peer is not None else "gather")},
+                                   "actions generated on device%s" % (env_id, n_local, world, args.obs_format, gather_txt),
+                       "env_id": env_id, "envs_per_gpu": n_local, "envs_total": r["n_total"],
+                       "parallelism": "env-sharded x%d, no data-path collective" % world if not r["gather"] else
+                       "env-sharded x%d + %s(obs)->rank0" % (world, "peer-mapped stores" if r["gather"] == "peer" else "gather")},
+            "per_gpu_value": r["value"] / world,
         }
-        if raster_n:
-            avg_ms = raster_ms / raster_n
+        if r["note"]:
+            out["note"] = r["note"]
+        if r["raster_launches"]:
+            avg_ms = r["raster_avg_ms"]
             rb = (FRAME * obs_elem + 16) * n_local
             achieved = rb / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
                     if j.get("env_id") == env_id and j.get("envs_per_gpu") == n_local and obs_elem == 1:
                         traffic = j.get("hbm_bytes_per_launch")
+                        traffic_source = ("NOT measured in this run: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload, "
+                                          "%s (profiles/pmc_latest.json, regenerated by tools/profile_round.sh)" % j.get("source", "committed profile"))
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": "raster", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                               "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": raster_n, "event_stride": max(1, args.event_stride),
-                               "logic_kernel_avg_ms": (logic_ms / logic_n) if logic_n else None,
-                               "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * n_total / (dt_max / K) / 1e9}
-        if getattr(env, "placement_probe_ms", None):  # raster time into each candidate allocation of the observation buffer
-            out["obs_placement_probe_ms"] = [round(t, 4) for t in env.placement_probe_ms]
+            out["roofline"] = {"bound": "hbm", "kernel": "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                               "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],
+                               "event_region": r["event_region"], "logic_kernel_avg_ms": r["logic_avg_ms"],
+                               "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * r["n_total"] / (r["seconds"] / K) / 1e9}
+        if r["obs_placement"]:  # mg_obs_alloc: observation buffer assembled from pieces in different HBM zones
+            out["obs_placement"] = r["obs_placement"]
+
+    if world > 1 and not args.no_secondary and args.obs_format == "u8_xyc":
+        # BASELINE.json config 5: Endless-MortarMayhem-v0, 32,768 instances per GPU, with and without the gather to rank 0
+        c5 = {}
+        for label, gm in (("no_gather", None), ("gather_rccl", "rccl"), ("gather_peer", "peer")):
+            try:
+                q = run_workload("Endless-MortarMayhem-v0", 32768, 100, 20, args.settle, world, rank, dev, "u8_xyc", gm, not args.no_events, args.event_stride)
+                c5[label] = {"value": q["value"], "unit": "env steps/s", "per_gpu_value": q["value"] / world, "ms_per_step": q["ms_per_step"],
+                             "raster_avg_ms_rank0": q["raster_avg_ms"], "note": q["note"]}
+            except Exception as e:  # keep the headline line alive
+                c5[label] = "failed: %s" % (str(e)[:200],)
+        if rank == 0:
+            out["config5"] = {"workload": "Endless-MortarMayhem-v0, 32768 envs/GPU x %d GPU (%d envs)" % (world, 32768 * world), **c5}
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(env_id)
             except Exception as e:  # the oracle is optional equipment on a box without gcc
                 out["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "unavailable: %s" % e}
-        if world == 1 and not args.no_cpu_baseline:
             out["pygame_baseline"] = pygame_baseline(env_id)
-    env.close()
-    if rank == 0:
         if world == 1 and not args.no_secondary and args.obs_format == "u8_xyc":
             try:
-                out["secondary_workloads"] = secondary_workloads(env_id, local_rank)
+                out["secondary_workloads"] = secondary_workloads(env_id, dev, args.settle)
             except Exception as e:
                 out["secondary_workloads"] = "failed: %s" % e
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

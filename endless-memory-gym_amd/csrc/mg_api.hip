@@ -210,6 +210,36 @@ int mg_peek_errors(mg_env* env, int* flags) {
     });
 }
 
+int mg_enable_peer_access(int device, int peer_device) {
+    try {
+        int prev = 0;
+        MG_HIP(hipGetDevice(&prev));
+        struct Restore {
+            int d;
+            ~Restore() { (void)hipSetDevice(d); }
+        } restore{prev};
+        if (device == peer_device) return 0;
+        int can = 0;
+        MG_HIP(hipDeviceCanAccessPeer(&can, device, peer_device));
+        if (!can) {
+            mg::set_error("device " + std::to_string(device) + " has no peer access to device " + std::to_string(peer_device));
+            return -1;
+        }
+        MG_HIP(hipSetDevice(device));
+        hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+            (void)hipGetLastError();
+            mg::set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            return -1;
+        }
+        (void)hipGetLastError();
+        return 0;
+    } catch (const std::exception& e) {
+        mg::set_error(e.what());
+        return -1;
+    }
+}
+
 int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
     return guarded(env, [&] {
         if (i < 0 || i >= env->num_envs) throw std::runtime_error("mg_debug_rng: index out of range");

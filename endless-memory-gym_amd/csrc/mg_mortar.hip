@@ -625,3 +625,11 @@ class MortarFamily : public Family {
 Family* make_mortar(int variant, int num_envs) { return new MortarFamily(variant, num_envs); }
 
 }  // namespace mg
+
+#ifdef MG_LAB
+extern "C" int mg_lab_set_window_offsets(const long long* off, int n) {
+    long long v[16] = {0};
+    for (int i = 0; i < n && i < 16; ++i) v[i] = off[i];
+    return hipMemcpyToSymbol(HIP_SYMBOL(mg::v1::g_lab_win_off), v, sizeof v) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -213,6 +213,10 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
     }
 }
 
+#ifdef MG_LAB  // measurement builds only (tools/placement_lab.py): window k of the frame walk is displaced by g_lab_win_off[k] bytes
+static __device__ long long g_lab_win_off[16];
+#endif
+
 template <class Composer, int FMT>
 __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
                                                      void* __restrict__ obs, int n, const uint8_t* __restrict__ only) {
@@ -229,7 +233,11 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
         if (Composer::skip(d) || (only && !only[env])) continue;  // `only`: per-frame filter (final observations)
         Composer::compose(d, R);
         __syncthreads();
+#ifdef MG_LAB
+        store_frame<FMT>(smem, static_cast<uint8_t*>(obs) + g_lab_win_off[(env / (int)gridDim.x) & 15], env, tid);
+#else
         store_frame<FMT>(smem, obs, env, tid);
+#endif
         __syncthreads();  // the LDS frame is reused by the next iteration
     }
 }

@@ -10,17 +10,17 @@ If gymnasium is installed on the host the ids are also registered there (gymnasi
 single-instance adapter), mirroring the reference's registration side effect on import.
 """
 from .reset_params import DEFAULTS, process_reset_params  # noqa: F401
-from .vec_env import ENV_IDS, MemoryGymEnv, VecMemoryGym  # noqa: F401
+from .vec_env import ENV_IDS, MemoryGymEnv, VecMemoryGym, alloc_obs_buffer  # noqa: F401
 from .vector import GymnasiumVectorEnv  # noqa: F401
 
 
 
 def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False, obs_buffer=None,
-         tune_placement=None):
+         obs_placement=None):
     if num_envs is None:
         return MemoryGymEnv(env_id, device=device, render_mode=render_mode)
     return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode, obs_format=obs_format,
-                        final_observation=final_observation, obs_buffer=obs_buffer, tune_placement=tune_placement)
+                        final_observation=final_observation, obs_buffer=obs_buffer, obs_placement=obs_placement)
 
 
 def _register_with_gymnasium():

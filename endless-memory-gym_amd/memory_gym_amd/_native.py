@@ -21,6 +21,14 @@ class InfoBuffers(C.Structure):
                 ("final_obs_dev", C.c_void_p)]
 
 
+class ObsAllocInfo(C.Structure):
+    _fields_ = [("zones", C.c_int), ("pieces", C.c_int), ("piece_bytes", C.c_size_t), ("searched_bytes", C.c_size_t),
+                ("probe_same_tbps", C.c_double), ("probe_cross_tbps", C.c_double), ("search_ms", C.c_double)]
+
+
+MG_OBS_SEARCH_DEFAULT = (1 << 64) - 1
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -55,6 +63,9 @@ def _load():
     L.mg_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.mg_poll_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mg_peek_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mg_obs_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(ObsAllocInfo)]
+    L.mg_obs_free.argtypes = [C.c_void_p]
+    L.mg_enable_peer_access.argtypes = [C.c_int, C.c_int]
     L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     return L
 

@@ -54,14 +54,42 @@ class PeerObsBuffer:
     `full` is the whole tensor (memory on dst's GPU, mapped into this process), `local` this rank's rows
     `shard_range(N_total, rank, world)` -- pass it as `obs_buffer=` to `memory_gym_amd.make`.  `fence()` is the per-step
     synchronisation: after it returns on dst, every rank's frames of the step are in `full`.
+    `ok` is False (on every rank alike, `why` says which rank and why, a warning is issued) when some rank's GPU has no peer
+    access to dst's GPU; `full` / `local` are None then and the caller falls back to `gather_to_rank0`.
 
     The mapping uses torch's CUDA-IPC tensor sharing (`hipIpcGetMemHandle` / `hipIpcOpenMemHandle`, dmabuf mode:
     keep HSA_ENABLE_IPC_MODE_LEGACY=0); dst must keep the object alive while the others use it."""
 
     def __init__(self, n_total, frame_shape=(84, 84, 3), dtype=torch.uint8, device=None, dst=0, group=None):
         from torch.multiprocessing.reductions import reduce_tensor
+
+        from . import _native
         self.rank, self.world, self.dst, self.group = dist.get_rank(group), dist.get_world_size(group), dst, group
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ok, self.why, self.full, self.local = True, "", None, None
+        # 1. can this rank's GPU store into dst's GPU?  (peer access is checked and switched on explicitly: the raster kernels
+        #    run on THIS device with a pointer into dst's memory; nothing else on the path would enable it for them)
+        idx = [None]
+        if self.rank == dst:
+            idx[0] = self.device.index
+        dist.broadcast_object_list(idx, src=dst, group=group)
+        dst_index = idx[0]
+        if self.rank != dst and torch.cuda.device_count() > 1 and dst_index != self.device.index:
+            if dst_index >= torch.cuda.device_count():
+                self.ok, self.why = False, "rank %d does not see device %d" % (self.rank, dst_index)
+            elif _native.LIB.mg_enable_peer_access(self.device.index, dst_index) != 0:
+                self.ok, self.why = False, "rank %d: %s" % (self.rank, _native.last_error())
+        # every rank must take the same path
+        flags = [None] * self.world
+        dist.all_gather_object(flags, (self.ok, self.why), group=group)
+        bad = [w for ok, w in flags if not ok]
+        if bad:
+            self.ok, self.why = False, "; ".join(bad)
+            import warnings
+            warnings.warn("memory_gym_amd.dist.PeerObsBuffer: peer-mapped observation stores are not available (%s); "
+                          "use gather_to_rank0 instead" % self.why)
+            return
+        # 2. share dst's tensor (HIP IPC, dmabuf mode)
         payload = [None]
         if self.rank == dst:
             self.full = torch.empty((int(n_total),) + tuple(frame_shape), dtype=dtype, device=self.device)

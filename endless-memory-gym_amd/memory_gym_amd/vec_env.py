@@ -55,6 +55,43 @@ def _spaces(action_dim, gt_dim, vec_dim=0):
     return act, obs, gt
 
 
+class _ObsMemory:
+    """Owner of a device buffer obtained from mg_obs_alloc; tensors made from it keep it alive (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr, info):
+        self.ptr, self.info = ptr, info
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _native.LIB.mg_obs_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
+    """A tensor of `shape` / `dtype` on `device` whose memory comes from mg_obs_alloc (pieces from two HBM zones, see
+    include/memgym.h); returns (tensor, info dict).  The memory is released when the last tensor viewing it goes away.
+    MEMGYM_OBS_SEARCH_GB bounds the transient spacer allocations of the search (default: a quarter of the free memory,
+    at most 80 GiB; 0 = do not search)."""
+    device = torch.device(device)
+    elem = torch.empty((), dtype=dtype).element_size()
+    nbytes = int(np.prod(shape)) * elem
+    if search_budget_bytes is None:
+        e = os.environ.get("MEMGYM_OBS_SEARCH_GB")
+        search_budget_bytes = _native.MG_OBS_SEARCH_DEFAULT if e is None else int(float(e) * (1 << 30))
+    ptr, info = C.c_void_p(), _native.ObsAllocInfo()
+    with torch.cuda.device(device):
+        torch.cuda.current_stream().synchronize()
+        _native.check(_native.LIB.mg_obs_alloc(device.index or 0, nbytes, C.c_size_t(search_budget_bytes), C.byref(ptr), C.byref(info)), "mg_obs_alloc")
+    # bfloat16 has no array-interface typestr: expose the bytes and view them
+    owner = _ObsMemory(ptr.value, (nbytes,), "|u1", {k: getattr(info, k) for k, _ in info._fields_})
+    t = torch.as_tensor(owner, device=device).view(dtype).view(tuple(shape))
+    return t, owner.info
+
+
 class VecMemoryGym:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
 
@@ -62,7 +99,7 @@ class VecMemoryGym:
                    "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
     def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False,
-                 obs_buffer=None, tune_placement=None):
+                 obs_buffer=None, obs_placement=None):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -89,18 +126,30 @@ class VecMemoryGym:
         code, dt, shape = self.OBS_FORMATS[obs_format]
         _native.check(_native.LIB.mg_set_obs_format(h, code), "mg_set_obs_format")
         assert _native.LIB.mg_obs_bytes(h) == 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
+        self.obs_placement_info = None
+        if obs_placement is None:
+            obs_placement = os.environ.get("MEMGYM_OBS_PLACEMENT", "balanced")
+        if obs_placement not in ("balanced", "plain"):
+            raise ValueError("obs_placement must be 'balanced' or 'plain'")
         if obs_buffer is None:
-            self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
+            # "balanced": physical pages from two HBM zones (include/memgym.h: mg_obs_alloc; 12-15 % on the raster kernel);
+            # buffers below 128 MiB and "plain" are ordinary allocations
+            nbytes = N * 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
+            self.obs = None
+            if obs_placement == "balanced" and nbytes > (304 << 20):
+                try:
+                    self.obs, self.obs_placement_info = alloc_obs_buffer((N,) + shape, dt, dev)
+                except RuntimeError as e:  # e.g. out of memory during the search: an ordinary allocation works as well
+                    import warnings
+                    warnings.warn("memory_gym_amd: balanced observation buffer not available (%s); using a plain allocation" % (e,))
+            if self.obs is None:
+                self.obs = torch.empty((N,) + shape, dtype=dt, device=dev)
         else:
             # caller-owned observation memory: the raster kernel writes the frames there (any device-accessible address,
             # e.g. this rank's rows of a peer-mapped buffer on another GPU: memory_gym_amd.dist.PeerObsBuffer)
             if tuple(obs_buffer.shape) != (N,) + shape or obs_buffer.dtype != dt or not obs_buffer.is_cuda or not obs_buffer.is_contiguous():
                 raise ValueError("obs_buffer must be a contiguous CUDA tensor of shape %s and dtype %s" % ((N,) + shape, dt))
             self.obs = obs_buffer
-        # Placement probe at the first reset (see _tune_placement); off for caller-owned or small observation buffers
-        if tune_placement is None:
-            tune_placement = os.environ.get("MEMGYM_TUNE_PLACEMENT", "1") != "0"
-        self._placement_pending = bool(tune_placement) and obs_buffer is None and self.obs.numel() * self.obs.element_size() >= (64 << 20)
         # gymnasium-0.29 vector convention: keep the terminal frame of instances that finish (and auto-reset) in a step
         self.final_obs = torch.zeros((N,) + shape, dtype=dt, device=dev) if final_observation else None
         # MortarMayhemB*: obs is the reference's Dict; `vector_obs` is written by the library whenever an instance resets
@@ -186,71 +235,8 @@ class VecMemoryGym:
             _native.check(_native.LIB.mg_reset(self._h, None if s is None else s.data_ptr(),
                                                None if m is None else m.data_ptr(), self.obs.data_ptr(),
                                                self.gt.data_ptr() if self.gt_dim else None, self._stream()), "mg_reset")
-            if self._placement_pending and mask is None:
-                self._tune_placement()
         info = {"ground_truth": self.gt} if self.gt_dim else {}
         return self._obs(), info
-
-    def _tune_placement(self, candidates=32, budget_bytes=64 << 30, probe_steps=24):
-        """The raster kernel's store stream is 6-13 % faster into some allocations of the observation buffer than into
-        others (same size, same 2-MiB alignment, same process: MortarMayhem-Grid 232-234 vs 249-253 us, MysteryPath 119
-        vs 138 us -- profiles/r01l_placement.md), a property that stays with the allocation and only shows with the
-        logic kernel running between the raster launches.  Once, after the first full reset: allocate candidate
-        tensors one after the other, let a scratch handle of the same env id take real steps into each (raster
-        launches bracketed with events by the library) until one is clearly in the fast mode (>= 5 % faster than the
-        slowest seen, at least three tried) or 32 candidates / 64 GB / half of the free memory are used up (slow runs of up
-        to eight consecutive 1.4-GB allocations were seen), and keep the
-        fastest for this handle.  `env.obs` may be a different tensor
-        afterwards; reset() returns it.  MEMGYM_TUNE_PLACEMENT=0 or tune_placement=False switches this off."""
-        self._placement_pending = False
-        nbytes = self.obs.numel() * self.obs.element_size()
-        free = torch.cuda.mem_get_info(self.device)[0]
-        k = int(min(candidates, budget_bytes // nbytes, (free // 2) // nbytes))
-        if k < 2:
-            return
-        keep = self.obs.clone()  # the scratch handle draws over the frames of this reset
-        first = self.obs
-        scratch = None
-        try:
-            scratch = VecMemoryGym(self.env_id, self.num_envs, device=self.device, obs_format=self.obs_format, tune_placement=False,
-                                   obs_buffer=self.obs)
-            bufs = [self.obs]
-            scratch.reset(seed=0)
-            shape = (self.num_envs,) if self.action_dim == 1 else (self.num_envs, 2)
-            gen = torch.Generator(device=self.device).manual_seed(0)
-            acts = [torch.randint(0, 4 if self.action_dim == 1 else 3, shape, device=self.device, generator=gen, dtype=torch.int32) for _ in range(8)]
-            for t in range(120):  # random agents: the episodes drift apart, the mix of frames becomes stationary
-                scratch.step(acts[t % 8])
-            times = []
-            while True:
-                scratch.obs = bufs[-1]
-                for t in range(4):
-                    scratch.step(acts[t % 8])
-                scratch.set_profiling(1)
-                for t in range(probe_steps):
-                    scratch.step(acts[t % 8])
-                ms, cnt = scratch.get_profile(1)
-                scratch.set_profiling(0)
-                times.append(ms / max(cnt, 1))
-                if len(times) >= k or (len(times) >= 3 and min(times) < 0.95 * max(times)):
-                    break
-                bufs.append(torch.empty_like(self.obs))
-            k = len(times)
-            best = min(range(k), key=lambda i: times[i])
-            self.placement_probe_ms = times  # kept for inspection (bench.py reports it)
-            self.obs = bufs[best]
-            del bufs
-        except (RuntimeError, MemoryError) as e:  # e.g. not enough memory for the scratch handle: keep the first allocation
-            import warnings
-            warnings.warn("memory_gym_amd: observation placement probe skipped (%s)" % (e,))
-            self.obs = first
-        finally:
-            if scratch is not None:
-                scratch.obs = keep  # (any live tensor: the handle is closed next)
-                scratch.close()
-        self.obs.copy_(keep)
-        del keep
-        torch.cuda.empty_cache()  # the rejected candidates go back to the driver, not into torch's cache
 
     def step(self, actions):
         with torch.cuda.device(self.device):

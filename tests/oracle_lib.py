@@ -147,17 +147,23 @@ class OracleBatch:
             self.L.mgo_batch_destroy(self.h)
             self.h = None
 
-    def reset(self, seeds=None):
-        obs = np.empty((self.n, self.dim, self.dim, 3), np.uint8)
+    def reset(self, seeds=None, out=None):
+        """`out`: a preallocated uint8 [n, dim, dim, 3] array to write the frames into (no allocation per call)."""
+        obs = np.empty((self.n, self.dim, self.dim, 3), np.uint8) if out is None else out
         s = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int64)
         self.L.mgo_batch_reset(self.h, None if s is None else s.ctypes.data, obs.ctypes.data)
         return obs
 
-    def step(self, actions, autoreset=True, want_obs=True):
+    def step(self, actions, autoreset=True, want_obs=True, out=None):
+        """`out` = (obs uint8 [n, dim, dim, 3], reward float64 [n], done uint8 [n]): preallocated outputs, nothing is
+        allocated per call (bench.py's CPU baseline; a fresh 347-MB frame array per step is mostly page faults)."""
         a = np.ascontiguousarray(actions, dtype=np.int32)
-        obs = np.empty((self.n, self.dim, self.dim, 3), np.uint8) if want_obs else None
-        rew = np.empty(self.n, np.float64)
-        done = np.empty(self.n, np.uint8)
+        if out is not None:
+            obs, rew, done = out
+        else:
+            obs = np.empty((self.n, self.dim, self.dim, 3), np.uint8) if want_obs else None
+            rew = np.empty(self.n, np.float64)
+            done = np.empty(self.n, np.uint8)
         self.L.mgo_batch_step(self.h, a.ctypes.data, int(autoreset), obs.ctypes.data if want_obs else None,
                               rew.ctypes.data, done.ctypes.data)
         return obs, rew, done

@@ -74,3 +74,35 @@ def test_gather_world2_even_and_ragged(tmp_path):
         d.mkdir()
         mp.spawn(_worker, args=(2, _free_port(), n_total, str(d)), nprocs=2, join=True)
         assert (d / "ok").exists()
+
+
+def test_bench_self_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without a launcher spawns N ranks with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and
+    lets only rank 0 write to stdout (the driver's SCALE runs call bench.py exactly like that)."""
+    import subprocess
+    import sys
+    import types
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    script = tmp_path / "fake_rank.py"
+    script.write_text("import os\nprint('rank', os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], "
+                      "os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'], os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], flush=True)\n")
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(script))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 3)
+    seen = []
+    real_popen = subprocess.Popen
+
+    def spy(cmd, env=None, stdout=None, **kw):
+        seen.append((env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], stdout))
+        return real_popen(cmd, env=env, stdout=subprocess.DEVNULL, **kw)
+
+    monkeypatch.setattr(bench.subprocess, "Popen", spy)
+    assert bench.self_launch(types.SimpleNamespace(gpus=3)) == 0
+    assert [(r, lr, w) for r, lr, w, _ in seen] == [("0", "0", "3"), ("1", "1", "3"), ("2", "2", "3")]
+    assert seen[0][3] is None and all(s[3] == subprocess.DEVNULL for s in seen[1:])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.self_launch(types.SimpleNamespace(gpus=3)) == 2  # fewer GPUs than ranks: refuse, do not time 1 GPU as 3

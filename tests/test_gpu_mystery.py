@@ -124,7 +124,9 @@ def test_full_size_sample():
     refs = {i: oracle_lib.OracleEnv("MysteryPath-v0") for i in sample}
     first = obs[sample].cpu().numpy()
     for k, i in enumerate(sample):
-        assert np.array_equal(first[k], refs[i].reset(i, options=dict(max_steps=40)))
+        want = refs[i].reset(i, options=dict(max_steps=40))
+        assert np.array_equal(first[k], want), "reset frame of instance %d differs in %d bytes (frame all zero: %s; placement %s)" % (
+            i, int((first[k] != want).sum()), not first[k].any(), env.obs_placement_info)
     g = torch.Generator(device="cuda").manual_seed(0)
     for t in range(130):
         a = torch.randint(0, 3, (n, 2), device="cuda", generator=g, dtype=torch.int32)

@@ -29,21 +29,44 @@ def test_render_reproduces_the_current_frames(env_id, adim, n_act):
     env.close()
 
 
-def test_placement_probe_is_transparent():
+def test_balanced_obs_buffer_is_transparent():
+    """mg_obs_alloc (pieces from two HBM zones mapped into one virtual range) holds the same frames as a plain tensor,
+    for the uint8 and a float format; its memory outlives the handle while a tensor views it."""
     import memory_gym_amd
     import torch
 
-    n = 4096  # 86 MB of observations: above the probe's threshold
-    a = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0, tune_placement=True)
-    b = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0, tune_placement=False)
-    oa, _ = a.reset(seed=3)
-    ob, _ = b.reset(seed=3)
-    assert getattr(a, "placement_probe_ms", None) and len(a.placement_probe_ms) >= 2 and not hasattr(b, "placement_probe_ms")
-    assert torch.equal(oa, ob)
-    g = torch.Generator(device="cuda").manual_seed(1)
-    for t in range(40):
-        act = torch.randint(0, 3, (n, 2), device="cuda", generator=g, dtype=torch.int32)
-        ra, rb = a.step(act), b.step(act)
-        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2]), "step %d" % t
-    a.close()
-    b.close()
+    n = 24576  # 520 MB of uint8 observations: two 304-MiB pieces (smaller buffers are plain allocations)
+    for fmt in ("u8_xyc", "bf16_chw"):
+        a = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0, obs_placement="balanced", obs_format=fmt)
+        b = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0, obs_placement="plain", obs_format=fmt)
+        info = a.obs_placement_info
+        assert info is not None and info["zones"] in (1, 2, 3) and info["pieces"] * info["piece_bytes"] >= a.obs.numel() * a.obs.element_size()
+        assert b.obs_placement_info is None
+        oa, _ = a.reset(seed=3)
+        ob, _ = b.reset(seed=3)
+        assert torch.equal(oa, ob)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for t in range(40):
+            act = torch.randint(0, 3, (n, 2), device="cuda", generator=g, dtype=torch.int32)
+            ra, rb = a.step(act), b.step(act)
+            assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2]), "step %d" % t
+        keep = a.obs
+        want = keep.clone()
+        a.close()
+        b.close()
+        del a
+        torch.cuda.synchronize()
+        assert torch.equal(keep, want)  # the buffer belongs to its tensors, not to the handle
+
+
+def test_obs_alloc_small_and_no_search():
+    import ctypes as C
+
+    from memory_gym_amd import _native
+
+    for nbytes, budget in ((1 << 20, _native.MG_OBS_SEARCH_DEFAULT), (300 << 20, 0)):
+        p, info = C.c_void_p(), _native.ObsAllocInfo()
+        _native.check(_native.LIB.mg_obs_alloc(0, nbytes, C.c_size_t(budget), C.byref(p), C.byref(info)), "mg_obs_alloc")
+        assert p.value and info.zones == 0 and info.searched_bytes == 0
+        assert _native.LIB.mg_obs_free(p) == 0
+    assert _native.LIB.mg_obs_free(C.c_void_p(12345)) != 0

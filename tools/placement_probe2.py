@@ -15,7 +15,7 @@ from memory_gym_amd import _native  # noqa: E402
 env_id = sys.argv[1] if len(sys.argv) > 1 else "MortarMayhem-Grid-v0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-env = memory_gym_amd.make(env_id, num_envs=n, device=0, tune_placement=False)
+env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_placement="plain")
 env.reset(seed=0)
 g = torch.Generator(device="cuda").manual_seed(0)
 hi = 4 if env.action_dim == 1 else 3

@@ -18,7 +18,7 @@ bufs = [torch.empty((n, 84, 84, 3), dtype=torch.uint8, device="cuda") for _ in r
 g = torch.Generator(device="cuda").manual_seed(0)
 keep = []
 for h in range(handles):
-    env = memory_gym_amd.make(env_id, num_envs=n, device=0, tune_placement=False, obs_buffer=bufs[0])
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_placement="plain", obs_buffer=bufs[0])
     keep.append(env)
     env.reset(seed=0)
     hi = 4 if env.action_dim == 1 else 3
