@@ -17,6 +17,18 @@ struct mg_env {
 };
 
 namespace {
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        MG_HIP(hipGetDevice(&prev));
+        if (prev != device) MG_HIP(hipSetDevice(device));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 template <typename F>
 int guarded(mg_env* env, F&& f) {
     try {
@@ -24,7 +36,7 @@ int guarded(mg_env* env, F&& f) {
             mg::set_error("null handle");
             return -1;
         }
-        MG_HIP(hipSetDevice(env->device));
+        DeviceGuard guard(env->device);  // the caller's current device is left as it was
         f();
         return 0;
     } catch (const mg::OptionError& e) {
@@ -47,7 +59,7 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
             mg::set_error("mg_create: bad arguments");
             return -1;
         }
-        MG_HIP(hipSetDevice(device));
+        DeviceGuard guard(device);
         std::string id(env_id);
         mg::Family* fam = nullptr;
         if (id == "MortarMayhem-Grid-v0") fam = mg::make_mortar(0, num_envs);
@@ -79,9 +91,12 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
 
 void mg_destroy(mg_env* env) {
     if (!env) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     (void)hipSetDevice(env->device);
     delete env->fam;
     delete env;
+    if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 int32_t mg_num_envs(const mg_env* env) { return env ? env->num_envs : 0; }
@@ -178,6 +193,7 @@ int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
             MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
             p += b.second;
         }
+        env->fam->on_state_loaded();  // reset(seed=None) / auto-reset are legal on a restored handle
     });
 }
 

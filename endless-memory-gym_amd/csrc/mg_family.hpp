@@ -134,6 +134,8 @@ class Family {
     virtual void raster_only(void* obs, const uint8_t* only, hipStream_t s) = 0;
     // checkpoint: list of (device pointer, bytes) making up the state
     virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;
+    // called by mg_set_state after the blobs were restored: the instances now carry seeded RNG streams
+    virtual void on_state_loaded() {}
     virtual void debug_rng(int i, uint64_t out[6]) = 0;
     // device-side error bits accumulated since the last call (0 = none); synchronises
     virtual int poll_errors() { return 0; }

@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
         }
     }
     reward_out[i] = (float)reward;
+    if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
 
     MortarDesc d;
@@ -615,6 +616,11 @@ class MortarFamily : public Family {
     std::unique_ptr<Atlas> atlas_;
     double agent_scale_, agent_speed_;
     bool dirty_ = true, seeded_ = false;
+
+   public:
+    void on_state_loaded() override { seeded_ = true; }
+
+   private:
     float* vec_ = nullptr;
     DevArray<MortarState> state_;
     DevArray<uint8_t> cmds_;

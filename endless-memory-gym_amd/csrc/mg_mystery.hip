@@ -448,6 +448,7 @@ __device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, const int
         if (info.aux_dev[1]) info.aux_dev[1][i] = (float)s.fails;
     }
     reward_out[i] = (float)reward;
+    if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
     if (done && autoreset) return true;
     memset(&d, 0, sizeof(d));
@@ -788,6 +789,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
         if (info.aux_dev[2]) info.aux_dev[2][i] = (float)s.tiles_visited;
     }
     reward_out[i] = (float)reward;
+    if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
     if (done && autoreset) return true;
     emp_fill_desc(P, io, i, s, d, nx, R);
@@ -1192,6 +1194,11 @@ class MysteryFamily : public Family {
     MysteryParams P_;
     double agent_scale_, agent_speed_, camera_offset_scale_ = 5.0;
     bool dirty_ = true, seeded_ = false;
+
+   public:
+    void on_state_loaded() override { seeded_ = true; }
+
+   private:
     std::unique_ptr<Atlas> atlas_;
     DevArray<MysteryCore> core_;
     DevArray<uint8_t> segs_;

@@ -732,6 +732,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     }
     if (leader) {
         reward_out[i] = (float)reward;
+        if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
         done_out[i] = done ? 1 : 0;
     }
 
@@ -872,6 +873,7 @@ class SpotFamily : public Family {
         else if (key == "sample_agent_position") B(P_.sample_agent_position);
         else if (key == "show_last_action") {
             B(P_.show_last_action);
+            dirty_ = true;  // the last-reward bar's position and width depend on it (searing_spotlights.py:385-390)
             // False crashes the ENDLESS reference at its first step (endless_searing_spotlights.py:422 reads action_colors,
             // which :343 only creates when the flag is set); the finite env guards the use (searing_spotlights.py:465)
             if (e) must_be(P_.show_last_action != 0);
@@ -1026,6 +1028,11 @@ class SpotFamily : public Family {
     double initial_spawn_interval_ = 30, spawn_interval_threshold_ = 10;
     int dim_duration_;
     bool dirty_ = true, seeded_ = false;
+
+   public:
+    void on_state_loaded() override { seeded_ = true; }
+
+   private:
     std::unique_ptr<Atlas> atlas_;
     DevArray<SpotCore> core_;
     DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;

@@ -158,6 +158,7 @@ class VecMemoryGym:
             self.vector_obs = torch.zeros((N, self.vec_dim), dtype=torch.float32, device=dev)
             _native.check(_native.LIB.mg_bind_vector_obs(h, self.vector_obs.data_ptr()), "mg_bind_vector_obs")
         self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.reward64 = torch.zeros(N, dtype=torch.float64, device=dev)  # the reference's Python float, unrounded
         self.done_u8 = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.gt = torch.zeros((N, max(self.gt_dim, 1)), dtype=torch.float32, device=dev)
         self.ep_reward = torch.zeros(N, dtype=torch.float64, device=dev)
@@ -176,10 +177,12 @@ class VecMemoryGym:
         for k, t in enumerate(self.aux):
             self._info.aux_dev[k] = t.data_ptr()
         self._info.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
+        self._info.reward64_dev = self.reward64.data_ptr()
         self.reset_params = process_reset_params(env_id, None)
         self._applied = dict(DEFAULTS[env_id])
         self.max_episode_steps = None
         self.autoreset = True
+        self._seeded = False  # no instance has an RNG stream before the first reset (or load_state_dict)
         self._truncated = torch.zeros(N, dtype=torch.bool, device=dev)  # `truncation` is always False in the reference
 
     # ------------------------------------------------------------------ plumbing
@@ -214,7 +217,11 @@ class VecMemoryGym:
 
     def _seed_tensor(self, seed):
         if seed is None:
-            return None
+            if self._seeded:
+                return None
+            # first reset without a seed: like gymnasium's np_random(None), every instance starts from OS entropy
+            seed = np.random.SeedSequence().generate_state(self.num_envs, np.uint64) >> np.uint64(1)
+            seed = seed.astype(np.int64)
         if isinstance(seed, torch.Tensor):
             s = seed.to(device=self.device, dtype=torch.int64)
         elif np.isscalar(seed):
@@ -230,11 +237,14 @@ class VecMemoryGym:
         """Env.reset(seed, options) for all instances (or those selected by the bool/uint8 tensor `mask`)."""
         with torch.cuda.device(self.device):
             self._apply_options(options)
+            if mask is not None and seed is None and not self._seeded:
+                raise RuntimeError("a masked reset(seed=None) needs an earlier full reset: the other instances have no RNG stream yet")
             s = self._seed_tensor(seed)
             m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
             _native.check(_native.LIB.mg_reset(self._h, None if s is None else s.data_ptr(),
                                                None if m is None else m.data_ptr(), self.obs.data_ptr(),
                                                self.gt.data_ptr() if self.gt_dim else None, self._stream()), "mg_reset")
+            self._seeded = True
         info = {"ground_truth": self.gt} if self.gt_dim else {}
         return self._obs(), info
 
@@ -273,13 +283,23 @@ class VecMemoryGym:
     def state_dict(self):
         n = _native.LIB.mg_state_size(self._h)
         buf = np.empty(n, np.uint8)
-        _native.check(_native.LIB.mg_get_state(self._h, buf.ctypes.data, n), "mg_get_state")
-        return {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf}
+        with torch.cuda.device(self.device):
+            _native.check(_native.LIB.mg_get_state(self._h, buf.ctypes.data, n), "mg_get_state")
+        # the reset options in force belong to the state: geometry, schedules and limits are derived from them
+        return {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf, "options": dict(self._applied), "seeded": self._seeded}
 
     def load_state_dict(self, sd):
+        """Restore a checkpoint, also into a handle that was never reset: the options in force when it was taken are
+        applied first (a rebuild of the geometry happens at the restore, not at some later reset), then the state."""
         assert sd["env_id"] == self.env_id and sd["num_envs"] == self.num_envs
-        buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
-        _native.check(_native.LIB.mg_set_state(self._h, buf.ctypes.data, buf.size), "mg_set_state")
+        with torch.cuda.device(self.device):
+            opts = sd.get("options")
+            if opts is not None and any(self._applied.get(k) != v for k, v in opts.items()):
+                # options only take effect at a reset: do one (its frames and RNG consumption are overwritten right below)
+                self.reset(seed=0, options={k: v for k, v in opts.items() if k in DEFAULTS[self.env_id]})
+            buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
+            _native.check(_native.LIB.mg_set_state(self._h, buf.ctypes.data, buf.size), "mg_set_state")
+            self._seeded = bool(sd.get("seeded", True))  # (env.obs shows the restored episodes from the next step on)
 
     def set_profiling(self, every):
         """Bracket the kernels of every `every`-th step with HIP events (0/False = off, 1/True = every step)."""
@@ -323,10 +343,26 @@ class VecMemoryGym:
             pass
 
 
-class MemoryGymEnv:
-    """Single-instance adapter with the reference's exact signatures (reset -> (obs, info); step -> 5-tuple)."""
+try:  # a real gymnasium.Env when the host has gymnasium (the reference's CustomEnv(gym.Env), environment.py:3-7)
+    import gymnasium as _gym
+    _EnvBase = _gym.Env
+except Exception:  # gymnasium is not a dependency of the hot path
+    _gym = None
+    _EnvBase = object
 
-    def __init__(self, env_id, device=None, render_mode=None):
+
+class MemoryGymEnv(_EnvBase):
+    """Single-instance environment with the reference's exact signatures (reset -> (obs, info); step -> 5-tuple of numpy
+    obs, Python float reward, bool, False, dict) -- what `gymnasium.make(id)` returns.  Subclasses gymnasium.Env when
+    gymnasium is importable; without it the same protocol surface (`unwrapped`, `spec`, `np_random`, `metadata`,
+    `render_mode`, spaces) is provided here, so code written against the reference runs either way."""
+
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
+    spec = None
+    env_id = None  # set by the per-id subclasses in memory_gym_amd.envs
+
+    def __init__(self, env_id=None, device=None, render_mode=None):
+        env_id = env_id or self.env_id
         self.vec = VecMemoryGym(env_id, 1, device, render_mode)
         self.vec.autoreset = False
         self.action_space = self.vec.action_space
@@ -334,14 +370,31 @@ class MemoryGymEnv:
         self.has_ground_truth_info = self.vec.has_ground_truth_info
         if self.has_ground_truth_info:
             self.ground_truth_space = self.vec.ground_truth_space
-        self.metadata = self.vec.metadata
         self.render_mode = render_mode
+        self._np_random = None
         # one device->host round trip per call: pinned staging buffers, asynchronous copies, a single stream sync
         self._h_obs = torch.empty(self.vec.obs.shape[1:], dtype=self.vec.obs.dtype).pin_memory()
-        self._h_rd = torch.empty(2, dtype=torch.float32).pin_memory()
+        self._h_rd = torch.empty(2, dtype=torch.float64).pin_memory()
         self._h_gt = torch.empty(max(self.vec.gt_dim, 1), dtype=torch.float32).pin_memory()
         self._h_vec = torch.empty(self.vec.vec_dim, dtype=torch.float32).pin_memory() if self.vec.vec_dim else None
-        self._d_rd = torch.empty(2, dtype=torch.float32, device=self.vec.device)
+        self._d_rd = torch.empty(2, dtype=torch.float64, device=self.vec.device)
+
+    # ---- gymnasium.Env protocol surface that exists with or without gymnasium
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def np_random(self):
+        """A numpy Generator like gymnasium.Env.np_random (the environment's own draws happen on the device, from the
+        PCG64 stream that reset(seed) seeds exactly like gymnasium does; this host-side generator is seeded alike)."""
+        if self._np_random is None:
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence()))
+        return self._np_random
+
+    @np_random.setter
+    def np_random(self, value):
+        self._np_random = value
 
     def _fetch(self, obs, reward=None, done=None):
         """Copies obs (+ reward, done, ground truth) of the single instance to the host with one synchronisation."""
@@ -350,7 +403,7 @@ class MemoryGymEnv:
         if self._h_vec is not None:
             self._h_vec.copy_(obs["vector_observation"][0], non_blocking=True)
         if reward is not None:
-            self._d_rd[0] = reward[0]
+            self._d_rd[0] = self.vec.reward64[0]
             self._d_rd[1] = done[0]
             self._h_rd.copy_(self._d_rd, non_blocking=True)
         if self.vec.gt_dim:
@@ -365,13 +418,9 @@ class MemoryGymEnv:
     def max_episode_steps(self):
         return self.vec.max_episode_steps
 
-    @staticmethod
-    def _first(obs):
-        if isinstance(obs, dict):  # MortarMayhemB*: the reference's Dict observation
-            return {k: v[0].cpu().numpy() for k, v in obs.items()}
-        return obs[0].cpu().numpy()
-
     def reset(self, seed=None, return_info=True, options=None):
+        if seed is not None:  # gymnasium.Env.reset(seed): the host-side generator follows the same seed
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(seed))))
         obs, info = self.vec.reset(seed=seed, options=options)
         o = self._fetch(obs)
         out = {}
@@ -383,7 +432,7 @@ class MemoryGymEnv:
         a = np.atleast_1d(np.asarray(action)).reshape(1, -1)
         obs, reward, done, _, info = self.vec.step(a)
         o = self._fetch(obs, reward, done)
-        r, d = float(self._h_rd[0]), bool(self._h_rd[1] != 0)
+        r, d = float(self._h_rd[0]), bool(self._h_rd[1] != 0)  # r: the reference's Python float, bit for bit
         out = {}
         if d:  # end of episode (rare): the reference's terminal info dict
             out["reward"] = float(info["reward"][0].item())

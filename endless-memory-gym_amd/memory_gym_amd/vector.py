@@ -29,15 +29,23 @@ except Exception:  # gymnasium is not a dependency of the hot path
 class GymnasiumVectorEnv(_Base):
     def __init__(self, env_id, num_envs, device=None, obs_format="u8_xyc", as_numpy=False):
         self.env = VecMemoryGym(env_id, num_envs=num_envs, device=device, obs_format=obs_format, final_observation=True)
-        self.num_envs = int(num_envs)
         self.as_numpy = bool(as_numpy)
-        self.is_vector_env = True
-        self.single_observation_space = self.env.observation_space
-        self.single_action_space = self.env.action_space
-        self.observation_space, self.action_space = self._batched_spaces()
+        done = False
+        if _Base is not object:  # gymnasium 0.29: VectorEnv.__init__(num_envs, observation_space, action_space) batches the spaces
+            try:
+                _Base.__init__(self, int(num_envs), self.env.observation_space, self.env.action_space)
+                done = True
+            except TypeError:  # gymnasium 1.x: no constructor arguments, attributes are set by the subclass
+                _Base.__init__(self)
+        if not done:
+            self.num_envs = int(num_envs)
+            self.is_vector_env = True
+            self.single_observation_space = self.env.observation_space
+            self.single_action_space = self.env.action_space
+            self.observation_space, self.action_space = self._batched_spaces()
+            self.closed = False
         self.metadata = self.env.metadata
         self.spec = None
-        self.closed = False
 
     def _batched_spaces(self):
         try:
@@ -102,4 +110,8 @@ class GymnasiumVectorEnv(_Base):
             self.closed = True
 
     def close_extras(self, **kwargs):
-        pass
+        self.env.close()
+
+    @property
+    def unwrapped(self):
+        return self

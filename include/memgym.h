@@ -40,6 +40,9 @@ typedef struct mg_info_buffers {
      * buffer (same format and shape as obs_dev; rows of other instances are left untouched) while obs_dev row i holds
      * the first observation of the new episode.  Costs one masked reset launch and two masked raster launches. */
     void* final_obs_dev;
+    /* Optional: the step reward of every instance as the reference computes it -- a Python float, i.e. a double
+     * (e.g. mortar_mayhem_grid.py:288-352) -- next to reward_dev's float32 rounding of it; [num_envs]. */
+    double* reward64_dev;
 } mg_info_buffers;
 
 /* gymnasium.make(id) + Env.__init__  (memory_gym/__init__.py:13-61; e.g. mortar_mayhem_grid.py:55-90).

@@ -1,0 +1,84 @@
+"""TEST INFRASTRUCTURE (see gymnasium/__init__.py of this stand-in): Env and Wrapper."""
+import numpy as np
+
+
+class Env:
+    metadata = {"render_modes": []}
+    render_mode = None
+    spec = None
+    action_space = None
+    observation_space = None
+    _np_random = None
+
+    def step(self, action):
+        raise NotImplementedError
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+    def render(self):
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def np_random(self):
+        if self._np_random is None:
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence()))
+        return self._np_random
+
+    @np_random.setter
+    def np_random(self, value):
+        self._np_random = value
+
+
+class Wrapper(Env):
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    @property
+    def spec(self):
+        return self.env.spec
+
+    @property
+    def action_space(self):
+        return self.env.action_space
+
+    @property
+    def observation_space(self):
+        return self.env.observation_space
+
+    @property
+    def metadata(self):
+        return self.env.metadata
+
+    @property
+    def render_mode(self):
+        return self.env.render_mode
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self, *, seed=None, options=None):
+        return self.env.reset(seed=seed, options=options)
+
+    def render(self):
+        return self.env.render()
+
+    def close(self):
+        return self.env.close()

@@ -42,3 +42,54 @@ def test_restore_into_fresh_handle(env_id, adim, n_act, options):
         assert np.array_equal(a_env.rng_words(i), b_env.rng_words(i))
     a_env.close()
     b_env.close()
+
+
+@pytest.mark.parametrize("env_id,adim,n_act,options", [CASES[0], CASES[2], ("SearingSpotlights-v0", 2, 3, dict(show_last_action=False, max_steps=80))])
+def test_restore_into_never_reset_handle(env_id, adim, n_act, options):
+    """the usual way to resume -- a fresh process creates the handle and loads the checkpoint, no reset.  The
+    options in force travel with the checkpoint; auto-reset, reset(seed=None) and the final-observation path (step
+    without auto-reset + masked reset(seed=None)) must work on the restored handle."""
+    import memory_gym_amd
+    import torch
+
+    n = 96
+    a_env = memory_gym_amd.make(env_id, num_envs=n, device=0, final_observation=True)
+    a_env.reset(seed=5, options=options)
+    prng = np.random.Generator(np.random.PCG64(9))
+    draw = (lambda: prng.integers(0, n_act, (n, adim)).astype(np.int32).squeeze(-1) if adim == 1 else prng.integers(0, n_act, (n, adim)).astype(np.int32))
+    for _ in range(50):
+        a_env.step(draw())
+    sd = a_env.state_dict()
+    b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, final_observation=True)
+    b_env.load_state_dict(sd)  # no reset on this handle
+    n_done = 0
+    for t in range(120):
+        a = draw()
+        o1, r1, d1, _, i1 = a_env.step(a)
+        o2, r2, d2, _, i2 = b_env.step(a)
+        assert torch.equal(o1, o2), "%s: frames differ %d steps after the restore" % (env_id, t)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2)
+        if bool(d1.any()):
+            assert torch.equal(i1["final_observation"][d1], i2["final_observation"][d2])
+        n_done += int(d1.sum())
+    assert n_done > 0
+    o1, _ = a_env.reset()  # seed=None on both: the streams continue
+    o2, _ = b_env.reset()
+    assert torch.equal(o1, o2)
+    a_env.close()
+    b_env.close()
+
+
+def test_first_reset_without_seed():
+    """gymnasium's common call pattern make(id).reset(): instances are seeded from OS entropy instead of raising."""
+    import memory_gym_amd
+
+    env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=8, device=0)
+    obs, _ = env.reset()
+    assert obs.shape == (8, 84, 84, 3) and bool(obs.any())
+    env.step(np.zeros(8, np.int32))
+    env.close()
+    single = memory_gym_amd.make("Endless-SearingSpotlights-v0")
+    o, info = single.reset()
+    assert o.shape == (84, 84, 3)
+    single.close()

@@ -37,6 +37,7 @@ SS_OPTS = [
          reward_inside_spotlight=-0.01, reward_outside_spotlight=0.001),
     dict(num_coins=[2], agent_health=50, light_dim_off_duration=3),
     dict(sample_agent_position=False, agent_health=100),
+    dict(show_last_action=False),  # on its own: moves and widens the last-reward bar (searing_spotlights.py:385-390)
 ]
 
 
