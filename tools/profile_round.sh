@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out
 shift
-ENVS=${@:-MortarMayhem-Grid-v0 MysteryPath-v0 Endless-SearingSpotlights-v0 Endless-MortarMayhem-v0}
+ENVS=${@:-MortarMayhem-Grid-v0 MysteryPath-v0 Endless-SearingSpotlights-v0 Endless-MortarMayhem-v0 Endless-MysteryPath-v0 SearingSpotlights-v0 MysteryPath-Grid-v0}
 for E in $ENVS; do
   S=$(echo $E | tr -d '-' | tr 'A-Z' 'a-z')
   rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_${S}_kt -o kt -- python bench.py --env $E --steps 200 --warmup 30 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_${S}_kt.log 2>&1
@@ -19,6 +19,9 @@ for E in $ENVS; do
     echo "bench.py line of the kernel-trace run:"; echo '```'; grep '^{' gpurun_out/${TAG}_${S}_kt.log; echo '```'; echo
     python tools/rocpd_summary.py gpurun_out/${TAG}_${S}_kt/kt_results.db gpurun_out/${TAG}_${S}_w/w_results.db gpurun_out/${TAG}_${S}_r/r_results.db | grep -v "at::native\|__amd_rocclr\|elementwise_kernel"
   } > gpurun_out/${TAG}_${S}.md
+  if [ "$E" = "MortarMayhem-Grid-v0" ]; then
+    python tools/pmc_json.py gpurun_out/${TAG}_${S}_w/w_results.db gpurun_out/${TAG}_${S}_r/r_results.db $E 65536 ${TAG}_${S}.md > gpurun_out/pmc_latest.json
+  fi
   rm -rf gpurun_out/${TAG}_${S}_kt gpurun_out/${TAG}_${S}_w gpurun_out/${TAG}_${S}_r
 done
 ls -la gpurun_out/${TAG}_*.md
