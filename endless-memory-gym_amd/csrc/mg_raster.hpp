@@ -330,10 +330,15 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
         // non-temporal stores: the observation stream does not displace the logic kernel's state and descriptors
         // from L2 (spotlight workloads: raster -4 %, logic kernel -9 %; for the mortar frames of generation 1 the
         // same hint costs 40 %, profiles/r01c_raster_generations.md)
+#ifdef MG_LAB_PLAIN_STORES  // measurement builds only
+        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
+        if (tid < TAIL) dst[tid + 1280] = v5;
+#else
         __builtin_nontemporal_store(v0, &dst[tid]); __builtin_nontemporal_store(v1, &dst[tid + 256]);
         __builtin_nontemporal_store(v2, &dst[tid + 512]); __builtin_nontemporal_store(v3, &dst[tid + 768]);
         __builtin_nontemporal_store(v4, &dst[tid + 1024]);
         if (tid < TAIL) __builtin_nontemporal_store(v5, &dst[tid + 1280]);
+#endif
     } else if constexpr (FMT == MG_OBS_F32_CYX) {
         float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
         constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame

@@ -68,6 +68,39 @@ int mgo_step(mgo_env* e, const int* action, uint8_t* obs, double* reward, int* d
     return 0;
 }
 
+/* Env.render() with render_mode "debug_rgb_array" (e.g. mortar_mayhem_grid.py:403-405): the debug surface, stretched to
+ * 336 x 336 like pygame.transform.scale (transform.c stretch(): an error accumulator per axis -- an integer factor
+ * replicates every pixel), then fliplr(rot90(array3d, 3)) = image order [y][x][c]. */
+int mgo_render_debug(mgo_env* e, uint8_t* out) {
+    if (!e->vt->debug) return -1;
+    const int sd = e->screen_dim, dd = 336;
+    mgo_surf* s = mgo_surf_new(sd, sd);
+    e->vt->debug(e, s);
+    int h_err = 2 * sd - 2 * dd, sy = 0;
+    for (int y = 0; y < dd; y++) {
+        int w_err = 2 * sd - 2 * dd, sx = 0;
+        for (int x = 0; x < dd; x++) {
+            uint32_t p = s->px[sy * sd + sx];
+            uint8_t* o = out + ((size_t)y * dd + x) * 3;
+            o[0] = (uint8_t)(p >> 16);
+            o[1] = (uint8_t)(p >> 8);
+            o[2] = (uint8_t)p;
+            while (w_err >= 0) {
+                sx++;
+                w_err -= 2 * dd;
+            }
+            w_err += 2 * sd;
+        }
+        while (h_err >= 0) {
+            sy++;
+            h_err -= 2 * dd;
+        }
+        h_err += 2 * sd;
+    }
+    mgo_surf_free(s);
+    return 0;
+}
+
 double mgo_get(mgo_env* e, const char* field, int* ok) {
     int k = 0;
     double v = e->vt->get(e, field, &k);

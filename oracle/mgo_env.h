@@ -190,6 +190,8 @@ typedef struct mgo_vtbl {
     double (*get)(struct mgo_env*, const char* field, int* ok);
     int (*get_list)(struct mgo_env*, const char* name, double* out, int cap);
     void (*destroy)(struct mgo_env*);
+    /* render("debug_rgb_array"): _build_debug_surface before its final transform.scale; dst is screen_dim x screen_dim */
+    void (*debug)(struct mgo_env*, mgo_surf* dst);
 } mgo_vtbl;
 
 typedef struct mgo_env {

@@ -54,6 +54,7 @@ typedef struct {
     int num_commands, cmds_cap;
     int* vis; /* _command_visualization, entries 0..8 or 9 for "" */
     int vis_head, vis_len, vis_cap;
+    int dbg_lead; /* render(): _command_visualization_clone runs one entry ahead after an endless regeneration */
     int glyph; /* glyph drawn in the last frame (-1 none) */
     mgo_surf* glyph_surf[10];
     int tx, ty, cur_cmd, cmd_steps, verify_step, total_completed, t;
@@ -159,6 +160,36 @@ static void mm_draw_frame(mgo_env* e, mm_t* m, mgo_surf* agent_surf, const mgo_r
         mgo_blit(e->screen, m->glyph_surf[glyph], p, p);
     }
     m->glyph = glyph;
+}
+
+/* _build_debug_surface (mortar_mayhem_grid.py:104-135, mortar_mayhem.py:105-136, endless_mortar_mayhem.py:114-145): arena,
+ * agent, a command glyph and a green ring around the target tile.  The glyph comes from a CLONE of the visualisation list
+ * (copied when the list is made: reset :237/:257, endless regeneration :321) of which every debug render pops one entry
+ * while the real list is not empty.  With one render() per reset()/step() -- what a recording loop does, and what this
+ * restatement assumes -- that is entry (entries popped from the real list - 1 + lead), lead = 1 after a regeneration
+ * (the clone is copied in a step that pops nothing), shown only while the real list still holds entries. */
+static void mm_debug(mgo_env* e, mgo_surf* dst) {
+    mm_t* m = (mm_t*)e->impl;
+    mgo_fill(dst, 0);
+    mgo_blit(dst, m->arena_surf, m->arena_rect.x, m->arena_rect.y);
+    if (m->have_disp) {
+        const mgo_rect* r = m->disp_rect_is_agent ? &m->agent.rect : &m->disp_rect_store;
+        mgo_blit(dst, m->disp_surf, r->x, r->y);
+    } else {
+        mgo_blit(dst, m->agent.sprites[0], m->agent.rect.x, m->agent.rect.y);
+    }
+    if (m->vis_head < m->vis_len) {
+        int idx = m->vis_head - 1 + m->dbg_lead, g = idx >= 0 && idx < m->vis_len ? m->vis[idx] : 9;
+        if (g >= 0 && g < 9) { /* 9 = "" (delay frames) */
+            double rect_dim = 88 * e->scale;
+            int p = (int)((e->screen_dim / 2) - floor(rect_dim / 2));
+            mgo_blit(dst, m->glyph_surf[g], p, p);
+        }
+    }
+    /* translation = arena.rect.center[0] - arena.local_center[0] + tile_dim // 2 (floats); pos and radius truncate in draw.circle */
+    double tr = mgo_rect_cx(&m->arena_rect) - m->local_cx + floor(m->tile_dim / 2);
+    int px = (int)(m->tile_dim * m->tx + tr), py = (int)(m->tile_dim * m->ty + tr);
+    mgo_draw_circle(dst, MGO_RGB(0, 255, 0), px, py, (int)floor(m->tile_dim / 2), (int)(8 * e->scale));
 }
 
 static void mm_set_disp(mm_t* m, int sprite, int rect_is_agent) {
@@ -280,6 +311,7 @@ static void mm_reset(mgo_env* e) {
         m->show_dur = (int)mm_choice(e, m->show_duration, m->n_show_duration);
         m->show_delay_v = (int)mm_choice(e, m->show_delay, m->n_show_delay);
         mm_gen_vis(m, m->cmds, m->num_commands, m->show_dur, m->show_delay_v);
+        m->dbg_lead = 0;
         glyph = mm_vis_pop(m);
     }
 
@@ -354,6 +386,7 @@ static void mm_step(mgo_env* e, const int action[2]) {
                     m->cmd_steps = 0;
                     m->verify_step = 0;
                     mm_gen_vis(m, &nc, 1, m->show_dur, m->show_delay_v);
+                    m->dbg_lead = 1;
                 } else {
                     done = 1;
                     success = 1;
@@ -497,11 +530,11 @@ static void mm_destroy(mgo_env* e) {
 }
 
 static const mgo_vtbl MM_VT[5] = {
-    {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
-    {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
-    {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
-    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
-    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy},
+    {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
+    {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
+    {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
+    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
+    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
 };
 
 int mgo_mortar_create(mgo_env* e, int variant) {

@@ -561,6 +561,54 @@ static void emp_step(mgo_env* e, const int action_in[2]) {
     e->done = done;
 }
 
+/* _build_debug_surface, finite (mystery_path.py:103-117, mystery_path_grid.py:102-116): MysteryPath.draw_to_surface with
+ * origin, goal, path AND walls shown (pygame_assets.py:738-762: path[0] green, path[-1] blue, the nodes between white,
+ * wall nodes red), the agent, the fall-off cross. */
+static void mpf_debug(mgo_env* e, mgo_surf* dst) {
+    mp_t* m = (mp_t*)e->impl;
+    int d = (int)m->tile_dim;
+    mgo_fill(dst, 0);
+    for (int i = 0; i < m->path_len; i++) {
+        int px = (int)(m->path[i].x * m->tile_dim), py = (int)(m->path[i].y * m->tile_dim);
+        uint32_t c = i == 0 ? MGO_RGB(0, 255, 0) : (i == m->path_len - 1 ? MGO_RGB(0, 0, 255) : MGO_RGB(255, 255, 255));
+        mgo_draw_rect(dst, c, px, py, d, d, 0);
+    }
+    for (int i = 0; i < m->n_walls; i++)
+        mgo_draw_rect(dst, MGO_RGB(255, 0, 0), (int)(m->walls[i][0] * m->tile_dim), (int)(m->walls[i][1] * m->tile_dim), d, d, 0);
+    mgo_blit(dst, m->agent.sprites[m->disp_sprite], m->agent.rect.x, m->agent.rect.y);
+    mgo_blit(dst, m->cross, m->cross_rect.x, m->cross_rect.y);
+}
+
+/* _build_debug_surface, endless (endless_mystery_path.py:162-182): scrolling background, the WHOLE path (EndlessMysteryPath.
+ * surface, regenerated whenever a segment is added: white tiles, colour key black, surface alpha 200, blitted at
+ * (-camera_x, 0)), the agent, the fall-off cross, the stamina bar (always, whatever show_stamina says). */
+static void emp_debug(mgo_env* e, mgo_surf* dst) {
+    mp_t* m = (mp_t*)e->impl;
+    double S = e->scale;
+    int td = (int)m->tile_dim, dim = e->screen_dim;
+    mgo_fill(dst, 0);
+    if (m->show_background) {
+        int ncol = (int)ceil((double)dim / td) + 2;
+        for (int i = 0; i < ncol; i++) mgo_blit(dst, m->column_surf, (int)(i * td + m->bg_scroll - td), 0);
+    }
+    mgo_surf* tile = mgo_surf_new(td, td);
+    mgo_fill(tile, MGO_RGB(255, 255, 255));
+    mgo_set_alpha(tile, 200);
+    int ox = (int)(-m->camera_x);
+    /* a tile may appear twice in the path list only at segment joints (the transition node is its own tile): draw each cell once */
+    for (int i = 0; i < m->epath_len; i++) {
+        int dup = 0;
+        for (int j = i - 1; j >= 0 && j >= i - 2 * (G + 1); j--)
+            if (m->epath[j].x == m->epath[i].x && m->epath[j].y == m->epath[i].y) dup = 1;
+        int px = m->epath[i].x * td + ox;
+        if (!dup && px > -td && px < dim) mgo_blit(dst, tile, px, m->epath[i].y * td);
+    }
+    mgo_surf_free(tile);
+    mgo_blit(dst, m->agent.sprites[m->disp_sprite], m->agent_draw_x, m->agent.rect.y);
+    mgo_blit(dst, m->cross, m->cross_rect.x, m->cross_rect.y);
+    mgo_blit(dst, m->stamina_surf, (int)(dim - 16 * S), 0);
+}
+
 static int mp_set_option(mgo_env* e, const char* k, const double* v, int n) {
     mp_t* m = (mp_t*)e->impl;
 #define D(name, field) if (!strcmp(k, name)) { m->field = v[0]; return 0; }
@@ -639,9 +687,9 @@ static void mp_destroy(mgo_env* e) {
 }
 
 static const mgo_vtbl MP_VT[3] = {
-    {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy},
-    {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy},
-    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy},
+    {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug},
+    {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy, emp_debug},
+    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug},
 };
 
 int mgo_mystery_create(mgo_env* e, int variant) {

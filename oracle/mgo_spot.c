@@ -274,6 +274,34 @@ static void sp_compose(mgo_env* e, sp_t* p, mgo_surf* agent_surf) {
     if (p->agent_visible) mgo_blit(e->screen, agent_surf, p->agent.rect.x, p->agent.rect.y);
 }
 
+/* _build_debug_surface (searing_spotlights.py:157-185, endless_searing_spotlights.py:150-177): board, spotlight layer,
+ * exit (finite), ALL coins on a fresh keyed surface, the agent (the stored (surface, rect) pair: stale after a reset
+ * until the first step), top bar -- i.e. everything the dark layer hides in the observation is drawn over it. */
+static void sp_debug(mgo_env* e, mgo_surf* dst) {
+    sp_t* p = (sp_t*)e->impl;
+    mgo_surf* coin = mgo_surf_new(p->dim, p->dim);
+    mgo_fill(coin, 255);
+    mgo_set_colorkey(coin, 255);
+    if (p->endless) {
+        if (p->coin_enabled && p->has_coin) sp_draw_coin(coin, p->coin_scale, p->coin_x[0], p->coin_y[0]);
+    } else {
+        for (int k = 0; k < p->n_coins; k++) sp_draw_coin(coin, p->coin_scale, p->coin_x[k], p->coin_y[k]);
+    }
+    mgo_fill(dst, 0);
+    mgo_blit(dst, p->bg_is_red ? p->bg_red : p->bg_blue, 0, 0);
+    mgo_blit(dst, p->spot_surf, 0, 0);
+    if (!p->endless) mgo_blit(dst, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
+    mgo_blit(dst, coin, 0, 0);
+    if (p->have_disp) {
+        const mgo_surf* sp = p->agent.sprites[p->disp_sprite];
+        mgo_blit(dst, sp, p->disp_x - sp->w / 2, p->disp_y - sp->h / 2);
+    } else {
+        mgo_blit(dst, p->agent.sprites[0], p->agent.rect.x, p->agent.rect.y);
+    }
+    mgo_blit(dst, p->top_bar, 0, 0);
+    mgo_surf_free(coin);
+}
+
 static void sp_reset(mgo_env* e) {
     sp_t* p = (sp_t*)e->impl;
     double S = e->scale;
@@ -648,8 +676,8 @@ static void sp_destroy(mgo_env* e) {
 }
 
 static const mgo_vtbl SP_VT[2] = {
-    {"SearingSpotlights-v0", 0, 0, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy},
-    {"Endless-SearingSpotlights-v0", 0, 4, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy},
+    {"SearingSpotlights-v0", 0, 0, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug},
+    {"Endless-SearingSpotlights-v0", 0, 4, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug},
 };
 
 int mgo_spot_create(mgo_env* e, int variant) {
