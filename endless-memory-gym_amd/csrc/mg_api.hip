@@ -1,4 +1,5 @@
 // mg_api.hip -- the C ABI of include/memgym.h on top of the per-family implementations.
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -144,6 +145,44 @@ int mg_render(mg_env* env, void* obs_dev, void* stream) {
     return guarded(env, [&] {
         if (!obs_dev) throw std::runtime_error("mg_render: obs_dev is NULL");
         env->fam->raster_only(obs_dev, nullptr, (hipStream_t)stream);
+    });
+}
+
+namespace {
+// pygame.transform.scale(surface, (336, 336)) of an 84x84 surface = every pixel four times per axis (transform.c stretch()),
+// then fliplr(rot90(array3d, 3)) = image order: out[n][y][x][c] = frame[n][x / 4][y / 4][c]
+__global__ __launch_bounds__(256) void debug_stretch_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out, int n) {
+    const size_t total = (size_t)n * 336 * 336;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % 336), y = (int)((p / 336) % 336);
+        const size_t e = p / (336 * 336);
+        const uint8_t* src = frames + e * MG_OBS_BYTES + ((size_t)(x >> 2) * 84 + (y >> 2)) * 3;
+        uint8_t* dst = out + p * 3;
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+    }
+}
+}  // namespace
+
+int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream) {
+    return guarded(env, [&] {
+        if (!rgb_dev) throw std::runtime_error("mg_render_debug: rgb_dev is NULL");
+        hipStream_t st = (hipStream_t)stream;
+        uint8_t* frames = nullptr;
+        MG_HIP(hipMalloc((void**)&frames, (size_t)env->num_envs * MG_OBS_BYTES));
+        try {
+            env->fam->raster_debug(frames, st);
+            const size_t total = (size_t)env->num_envs * 336 * 336;
+            const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+            hipLaunchKernelGGL(debug_stretch_kernel, dim3(grid), dim3(256), 0, st, frames, rgb_dev, env->num_envs);
+            MG_HIP(hipGetLastError());
+            MG_HIP(hipStreamSynchronize(st));
+        } catch (...) {
+            (void)hipFree(frames);
+            throw;
+        }
+        MG_HIP(hipFree(frames));
     });
 }
 

@@ -132,6 +132,9 @@ class Family {
                       const mg_info_buffers* info, int autoreset, hipStream_t s) = 0;
     // rasterise the CURRENT frame descriptors of the instances with only[i] != 0 into `obs` (others untouched)
     virtual void raster_only(void* obs, const uint8_t* only, hipStream_t s) = 0;
+    // render("debug_rgb_array") before its final x4 stretch: the debug surface of every instance (the reference's
+    // _build_debug_surface, e.g. mortar_mayhem_grid.py:104-135) as uint8 [num_envs][84 x][84 y][3], the observation layout
+    virtual void raster_debug(void* frames, hipStream_t s) = 0;
     // checkpoint: list of (device pointer, bytes) making up the state
     virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;
     // called by mg_set_state after the blobs were restored: the instances now carry seeded RNG streams

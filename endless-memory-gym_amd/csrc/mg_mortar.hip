@@ -56,7 +56,8 @@ struct __attribute__((aligned(16))) MortarState {
     uint8_t show_dur, show_delay, expl_dur, expl_delay;
     uint8_t gx, gy;          // grid controller position
     int32_t ep_len, t, total_completed;
-    uint32_t pad0;
+    uint32_t dbg_lead;       // debug view only: the reference's clone of the display schedule runs one entry ahead after an
+                             // endless regeneration (endless_mortar_mayhem.py:320-321)
     double ep_sum;
 };
 static_assert(sizeof(MortarState) == 64, "MortarState must be 64 bytes");
@@ -68,10 +69,11 @@ struct __attribute__((aligned(16))) MortarDesc {
     uint8_t sprite;    // 0..7, 0xFF none
     uint8_t glyph;     // 0..9 (9 = blank), 0xFF none
     int16_t glyph_x0;  // blit position of the glyph (x == y)
-    uint16_t pad[3];
+    int16_t ring_x, ring_y;  // debug view only: top-left of the target ring stamp
+    uint16_t ring_on;
 };
 static_assert(sizeof(MortarDesc) == 16, "MortarDesc must be 16 bytes");
-constexpr int STAMP_SPRITE0 = 0, STAMP_GLYPH0 = 8;
+constexpr int STAMP_SPRITE0 = 0, STAMP_GLYPH0 = 8, STAMP_RING = 18;
 
 struct MortarComposer {
     typedef MortarDesc Desc;
@@ -85,6 +87,17 @@ struct MortarComposer {
             __syncthreads();
             stamp(R, STAMP_GLYPH0 + d.glyph, d.glyph_x0, d.glyph_x0);
         }
+    }
+};
+
+// _build_debug_surface (mortar_mayhem_grid.py:104-135): the observation's layers plus a green ring around the target tile
+struct MortarDebugComposer {
+    typedef MortarDesc Desc;
+    static __device__ __forceinline__ bool skip(const Desc*) { return false; }
+    static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
+        MortarComposer::compose(dp, R);
+        __syncthreads();
+        if (dp->ring_on) stamp(R, STAMP_RING, dp->ring_x, dp->ring_y);
     }
 };
 
@@ -157,6 +170,7 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
     s.vis_len = (uint16_t)(n * (s.show_dur + s.show_delay));
     s.vis_base = 0;
     s.vis_pos = 1;  // reset pops the first entry for its own frame
+    s.dbg_lead = 0;
     int first = cmds[0];
     uint8_t glyph = s.show_dur > 0 ? (uint8_t)first : (uint8_t)9;
     if (P.variant == V_ENDLESS) {
@@ -356,6 +370,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
                     s.verify_step = 0;
                     s.vis_pos = 0;
                     s.vis_len = (uint16_t)(s.show_dur + s.show_delay);
+                    s.dbg_lead = 1;
                 } else {
                     done = true;
                     success = 1;
@@ -434,6 +449,40 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     if (rng_loaded) g.store(io.rng, i);
     io.state[i] = s;
     io.desc[i] = d;
+}
+
+// Debug view: the frame descriptors of the current frames with (a) the glyph the reference's CLONE of the display schedule
+// yields -- entry (entries popped - 1 + lead), only while the real schedule still holds entries (oracle/mgo_mortar.c
+// mm_debug) -- and (b) the ring around the target tile.
+__global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P, int n, MortarIO io, MortarDesc* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MortarState s = io.state[i];
+    const uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
+    MortarDesc d = io.desc[i];
+    {   // the agent the debug view shows is the stored (rotated_agent_surface, rotated_agent_rect) pair, which no reset clears
+        // (mortar_mayhem_grid.py:115-118): stale from the previous episode until the first step; sprite 0 before any step
+        const bool have = s.disp_sprite != 0xFF;
+        const int cx = (have && !s.disp_is_agent) ? s.disp_x : s.ax, cy = (have && !s.disp_is_agent) ? s.disp_y : s.ay;
+        d.sx = (int16_t)(cx - P.sprite_dim / 2);
+        d.sy = (int16_t)(cy - P.sprite_dim / 2);
+        d.sprite = have ? s.disp_sprite : (uint8_t)0;
+        d.tmpl = (uint16_t)((s.tiles_on && P.visual_feedback) ? 1 + s.tx * P.N + s.ty : 0);
+        d.glyph_x0 = (int16_t)P.glyph_x0;
+    }
+    d.glyph = 0xFF;
+    if (s.vis_pos < s.vis_len) {
+        const int idx = (int)s.vis_pos - 1 + (int)s.dbg_lead, period = s.show_dur + s.show_delay;
+        if (idx >= 0 && idx < (int)s.vis_len && period > 0) {
+            const int k = idx / period, w = idx % period;
+            d.glyph = (w < s.show_dur) ? cmds[s.vis_base + k] : (uint8_t)9;
+        }
+    }
+    const int r = P.tile / 2;  // pygame.draw.circle(surface, green, tile centre, tile_dim // 2, int(8 * SCALE))
+    d.ring_x = (int16_t)(P.arena_x0 + P.tile * s.tx + P.tile / 2 - r);
+    d.ring_y = (int16_t)(P.arena_x0 + P.tile * s.ty + P.tile / 2 - r);
+    d.ring_on = 1;
+    out[i] = d;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -595,6 +644,12 @@ class MortarFamily : public Family {
         atlas_.reset(new Atlas());
         for (auto& sp : sprites) atlas_->add_stamp(sp);   // ids 0..7
         for (auto& g : glyphs) atlas_->add_stamp(g);      // ids 8..17
+        {   // id 18: the debug view's ring around the target tile (box 2r x 2r, centre (r, r), like the coin)
+            const int r = P_.tile / 2;
+            Stamp ring_stamp(2 * r, 2 * r);
+            circle(ring_stamp, r, r, r, (int)(8 * SCALE), 6);  // palette 6 = (0, 255, 0)
+            atlas_->add_stamp(ring_stamp);
+        }
         atlas_->set_templates(build_mortar_templates(P_.N, SCALE, SCREEN));
         atlas_->upload();
         P_.glyph_x0 = (int)((SCREEN / 2) - std::floor(88 * SCALE / 2));
@@ -610,6 +665,19 @@ class MortarFamily : public Family {
         launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s);
         MG_HIP(hipGetLastError());
     }
+
+   public:
+    void raster_debug(void* frames, hipStream_t s) override {
+        if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next render");
+        DevArray<MortarDesc> dbg;
+        dbg.alloc(n_, false);
+        hipLaunchKernelGGL(mortar_debug_desc_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), dbg.p);
+        launch_raster<MortarDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+        MG_HIP(hipGetLastError());
+        MG_HIP(hipStreamSynchronize(s));  // dbg is released on return
+    }
+
+   private:
 
     int n_;
     MortarParams P_;

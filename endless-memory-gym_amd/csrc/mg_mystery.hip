@@ -110,6 +110,63 @@ struct MysteryComposer {
     }
 };
 
+// _build_debug_surface (mystery_path.py:103-117, endless_mystery_path.py:162-182).  The descriptor is a debug one
+// (mystery_debug_desc_kernel): pad8[0] = 1 finite -- tile_mask[0] = the path between its ends (white), tile_mask[1] = the walls
+// (red), goal / origin always on; pad8[0] = 2 endless -- tile_mask = EVERY path cell of the 16-column window, drawn as the
+// reference's path surface: white with surface alpha 200 over the background; the stamina bar always.
+__device__ __forceinline__ void rect_blend_white(const RasterCtx& R, int x, int y, int w, int h, uint32_t alpha) {
+    for (int p = R.tid; p < w * h; p += 256) {
+        const int px = p / h, py = p - px * h, X = x + px, Y = y + py;
+        if ((unsigned)X < (unsigned)SCREEN && (unsigned)Y < (unsigned)SCREEN) {
+            uint8_t* q = R.frame + X * COL_BYTES + Y * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = (uint8_t)(q[c] + ((255 - (int)q[c]) * (int)alpha) / 255);  // SDL: d += (s - d) * A / 255
+        }
+    }
+}
+struct MysteryDebugComposer {
+    typedef MysteryDesc Desc;
+    static __device__ __forceinline__ bool skip(const Desc*) { return false; }
+    static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
+        const Desc& d = *dp;
+        const bool endless = d.pad8[0] == 2;
+        StampRegs<4> sprite = stamp_fetch<4>(R, d.sprite);
+        StampRegs<1> cross;
+        if (d.cross_on) cross = stamp_fetch<1>(R, ST_CROSS);
+        if (d.bg_on) fill_template(R, d.bg_phase);
+        else fill_clear(R);
+        __syncthreads();
+        for (int h = 0; h < 2; ++h) {  // distinct cells: no overlap, no barrier
+            uint64_t m = d.tile_mask[h];
+            while (m) {
+                const int b = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const int cell = endless ? h * 64 + b : b, col = cell / G, row = cell - col * G;
+                if (endless) rect_blend_white(R, d.tile_x0 + TILE * col, TILE * row, TILE, TILE, 200u);
+                else rect(R, TILE * col, TILE * row, TILE, TILE, h == 0 ? C_WHITE : C_RED, false);
+            }
+        }
+        if (!endless) {  // path[0] (the END node) green, path[-1] (the start) blue: they are not in tile_mask[0]
+            rect(R, d.goal_x * TILE, d.goal_y * TILE, TILE, TILE, C_GREEN, false);
+            rect(R, d.origin_x * TILE, d.origin_y * TILE, TILE, TILE, C_BLUE, false);
+        }
+        __syncthreads();
+        stamp_apply<4>(R, sprite, d.sx, d.sy);
+        if (d.cross_on) {
+            __syncthreads();
+            stamp_apply<1>(R, cross, d.cross_x, d.cross_y);
+        }
+        if (d.stamina_on) {
+            __syncthreads();
+            rect(R, SCREEN - STAMINA_W, 0, STAMINA_W, SCREEN, C_GREEN, false);
+            if (d.stamina_red) {
+                __syncthreads();
+                rect(R, SCREEN - STAMINA_W, 0, STAMINA_W, d.stamina_red, C_RED, false);
+            }
+        }
+    }
+};
+
 struct MysteryIO {
     MysteryCore* core;
     uint8_t* segs;      // endless: [N][MAX_SEG][SEG_STRIDE]; node byte = x_rel | y<<3 | rvis<<6 | svis<<7
@@ -118,6 +175,7 @@ struct MysteryIO {
     MysteryDesc* desc;
     int* err;
     int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
+    uint64_t* walls;  // finite: [N] wall cells of the current path generation (bit x*7+y), read by the debug view only
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
 };
 constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_WORDS = 96;  // one 128-byte line each
@@ -182,7 +240,7 @@ __device__ __forceinline__ Pcg bcast(const Pcg& g, int lane) {
 // MysteryPath.__init__ (pygame_assets.py:606-724) + Node (:438-493), every argument wave-uniform, called by all 64
 // lanes.  Returns the path length (-1 = "No valid path found"); lane k < len receives the k-th path node (flat index
 // x*7+y, END FIRST like the reference's list) in out_node, path_mask has one bit per path node.
-__device__ int coop_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey, int& out_node, uint64_t& path_mask) {
+__device__ int coop_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey, int& out_node, uint64_t& path_mask, uint64_t& wall_out) {
     const int lane = threadIdx.x & 63;
     uint64_t wall = 0, closed = 0, in_open = 0;
     for (int i = 0; i < G; ++i)
@@ -218,6 +276,7 @@ __device__ int coop_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey
             --n_outer;
         }
     }
+    wall_out = wall;  // (the debug view draws the walls)
     // per-node record in lane n; f = g_cost + h is only ever evaluated for nodes in the open set, and the reference's
     // `neighbor.g = g` typo means g_cost never changes once a node has entered it
     int gval = 0, prev = -1;
@@ -356,7 +415,7 @@ __device__ __forceinline__ void mp_post_reset(const MysteryParams& P, MysteryCor
 }
 // All 64 lanes, converged: one path per requesting lane, generated by the whole wave on a broadcast copy of that
 // lane's RNG stream; the requester receives the stream back together with the path mask and length.
-__device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, int& len_out, uint64_t& pm_out) {
+__device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, int& len_out, uint64_t& pm_out, uint64_t* walls, int inst) {
     const int lane = threadIdx.x & 63;
     uint64_t todo = __ballot(req.need != 0);
     while (todo) {
@@ -365,7 +424,8 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
         Pcg bg = bcast(g, L);
         int node = 0;
         uint64_t pm = 0;
-        int len = coop_path(bg, W, bcast(req.sx, L), bcast(req.sy, L), bcast(req.ex, L), bcast(req.ey, L), node, pm);
+        uint64_t wl = 0;
+        int len = coop_path(bg, W, bcast(req.sx, L), bcast(req.sy, L), bcast(req.ex, L), bcast(req.ey, L), node, pm, wl);
         if (len < 0) {
             if (lane == 0) raise_error(err, 2);
             len = 0;
@@ -375,6 +435,7 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
             g = bg;
             len_out = len;
             pm_out = pm;
+            if (walls) walls[inst] = wl;  // only the debug view reads them
         }
     }
 }
@@ -508,7 +569,8 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
         const int ey = bg.integers(0, G);
         int node = 0;
         uint64_t pm = 0;
-        int len = coop_path(bg, W, 0, sy, G - 1, ey, node, pm);
+        uint64_t walls_unused = 0;
+        int len = coop_path(bg, W, 0, sy, G - 1, ey, node, pm, walls_unused);
         if (len < 0) {
             if (lane == 0) raise_error(io.err, 2);
             len = 0;
@@ -796,6 +858,48 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     return false;
 }
 
+// Debug descriptors from the state and the current frame descriptors (see MysteryDebugComposer; oracle/mgo_mystery.c
+// mpf_debug / emp_debug).
+__global__ __launch_bounds__(256) void mystery_debug_desc_kernel(MysteryParams P, MysteryIO io, MysteryDesc* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const MysteryCore s = io.core[i];
+    MysteryDesc d = io.desc[i];
+    d.valid = 1;
+    d.tile_mask[0] = d.tile_mask[1] = 0;
+    if (!P.endless) {
+        d.pad8[0] = 1;
+        const uint64_t ends = (1ull << (s.sx * G + s.sy)) | (1ull << (s.ex * G + s.ey));
+        d.tile_mask[0] = s.path_mask & ~ends;
+        d.tile_mask[1] = io.walls[i];
+        d.goal_on = d.origin_on = 1;
+        d.goal_x = s.ex; d.goal_y = s.ey;
+        d.origin_x = s.sx; d.origin_y = s.sy;
+        d.tile_x0 = 0;
+        d.cross_on = s.cross_on;  // the cross surface keeps its alpha: the observation's visibility
+    } else {
+        d.pad8[0] = 2;
+        const int x0 = floordiv_pos(s.camera_x, P.tile);
+        d.tile_x0 = x0 * P.tile - s.camera_x;
+        const int seg_lo = x0 / (G + 1) - 1, seg_hi = (x0 + 16) / (G + 1) + 1;
+        for (int seg = seg_lo < 0 ? 0 : seg_lo; seg <= seg_hi && seg < s.num_seg; ++seg) {
+            const uint8_t* sp = seg_ptr(io, i, seg);
+            const int cnt = sp[0];
+            for (int k = 1; k <= cnt; ++k) {
+                const int col = node_x(seg, sp[k]) - x0, y = node_y(sp[k]);
+                if (col >= 0 && col < 16) {
+                    const int cell = col * G + y;
+                    d.tile_mask[cell >> 6] |= 1ull << (cell & 63);
+                }
+            }
+        }
+        d.stamina_on = 1;  // blitted whatever show_stamina says
+        const int st = s.stamina < P.stamina_level ? s.stamina : P.stamina_level;
+        d.stamina_red = (uint8_t)(int)(SCREEN * (1 - ((double)st / P.stamina_level)));
+    }
+    out[i] = d;
+}
+
 __global__ __launch_bounds__(256) void mystery_init_kernel(int n, MysteryCore* core) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -844,7 +948,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
         if (active) req = mp_pre_reset(P, s, g);
         int len = 0;
         uint64_t pm = 0;
-        serve_mp(W, req, g, io.err, len, pm);
+        serve_mp(W, req, g, io.err, len, pm, io.walls, i);
         if (active) mp_post_reset(P, s, req, len, pm, d);
     }
     if (active) {
@@ -881,7 +985,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         if (reset_me) req = mp_pre_reset(P, s, g);
         int len = 0;
         uint64_t pm = 0;
-        serve_mp(W, req, g, io.err, len, pm);
+        serve_mp(W, req, g, io.err, len, pm, io.walls, i);
         if (reset_me) mp_post_reset(P, s, req, len, pm, d);
     }
     if (active) {
@@ -1007,6 +1111,7 @@ class MysteryFamily : public Family {
             P_.r_goal = 1.0;
         }
         core_.alloc(n);
+        walls_.alloc(n);
         desc_.alloc(n);
         rng_.alloc(n);
         err_.alloc();
@@ -1097,7 +1202,8 @@ class MysteryFamily : public Family {
     }
 
     std::vector<std::pair<void*, size_t>> state_blobs() override {
-        std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {segs_.p, segs_.bytes()}, {falloff_.p, falloff_.bytes()}};
+        std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {segs_.p, segs_.bytes()}, {falloff_.p, falloff_.bytes()},
+                                                  {walls_.p, walls_.bytes()}};
         rng_.blobs(v);
         return v;
     }
@@ -1138,6 +1244,7 @@ class MysteryFamily : public Family {
         o.desc = desc_.p;
         o.err = err_.dev;
         o.queue = queue_.p;
+        o.walls = P_.endless ? nullptr : walls_.p;
         o.qctr = queue_.p + ((n_ + 31) & ~31);
         return o;
     }
@@ -1197,6 +1304,7 @@ class MysteryFamily : public Family {
 
    public:
     void on_state_loaded() override { seeded_ = true; }
+    void raster_debug(void* frames, hipStream_t s) override;
 
    private:
     std::unique_ptr<Atlas> atlas_;
@@ -1205,9 +1313,20 @@ class MysteryFamily : public Family {
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
+    DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
     RngStore rng_;
 };
+
+void MysteryFamily::raster_debug(void* frames, hipStream_t s) {
+    if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next render");
+    DevArray<MysteryDesc> dbg;
+    dbg.alloc(n_, false);
+    hipLaunchKernelGGL(mystery_debug_desc_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
+    launch_raster<MysteryDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+    MG_HIP(hipGetLastError());
+    MG_HIP(hipStreamSynchronize(s));  // dbg is released on return
+}
 
 Family* make_mystery(int variant, int num_envs) { return new MysteryFamily(variant, num_envs); }
 

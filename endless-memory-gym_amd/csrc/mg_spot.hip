@@ -60,7 +60,7 @@ struct __attribute__((aligned(16))) SpotCore {
     int32_t num_coins, ep_len;
     double health, ep_sum;
     uint64_t order;  // spotlight list: nibble k = slot of the k-th element
-    uint32_t free_mask, pad;
+    uint32_t free_mask, pad;  // pad: debug view, bit 31 = a sprite has been shown, 18..16 sprite, 15..8 y + 128, 7..0 x + 128
 };
 static_assert(sizeof(SpotCore) == 80, "SpotCore must be 80 bytes");
 
@@ -166,6 +166,43 @@ struct SpotComposer {
         if (lf & LAYER_AGENT_TOP) {
             __syncthreads();
             stamp_apply_lit<1>(R, agent, d.sx, d.sy, 0u, never_skip);
+        }
+    }
+};
+
+// _build_debug_surface (searing_spotlights.py:157-185, endless_searing_spotlights.py:150-177): board, spotlight layer, then
+// exit, coins and agent OVER it (undarkened), top bar last.  Same descriptor, prefetch and hole mask as the observation.
+struct SpotDebugComposer {
+    typedef SpotDesc Desc;
+    typedef SpotComposer::Pre Pre;
+    static __device__ __forceinline__ bool skip(cptr<Desc>) { return false; }
+    static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) { SpotComposer::prefetch(dp, R, P); }
+    static __device__ __forceinline__ void recycle(const RasterCtx& R) { zero_mask(R); }
+    static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
+        const Desc MG_CONST_AS& d = *dp;
+        const uint32_t alpha = d.alpha;
+        if (alpha) {
+            if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
+            else hole_mask(R, d.holes, d.n_holes);
+            __syncthreads();
+        }
+        templ_apply_dark(R, P.bg, alpha);
+        __syncthreads();
+        auto under_bar = [&](int X, int Y) { return Y < BAR_H && SpotComposer::bar_covers(d, X); };
+        if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, P.exitp, d.exit_x, d.exit_y, 0u, under_bar);
+        for (int k = 0; k < d.n_coins; ++k)
+            stamp_apply_lit<1>(R, P.coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
+        __syncthreads();
+        stamp_apply_lit<1>(R, P.agent, d.sx, d.sy, 0u, under_bar);
+        if (R.tid < SCREEN) {
+            uint32_t c = 0u;
+            if (SpotComposer::bar_colour(d, R.T, R.tid, &c)) {
+                const uint32_t r = c & 0xFFu, g = (c >> 8) & 0xFFu, b = (c >> 16) & 0xFFu;
+                uint32_t* p = reinterpret_cast<uint32_t*>(R.frame) + R.tid * (COL_BYTES / 4);
+                p[0] = r | (g << 8) | (b << 16) | (r << 24);
+                p[1] = g | (b << 8) | (r << 16) | (g << 24);
+                p[2] = b | (r << 8) | (g << 16) | (b << 24);
+            }
         }
     }
 };
@@ -736,6 +773,9 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         done_out[i] = done ? 1 : 0;
     }
 
+    // debug view only: the (rotated_agent_surface, rotated_agent_rect) pair of this step -- a reset leaves it alone, and the
+    // reference's debug render shows that stale pair until the first step of the next episode
+    s.pad = 0x80000000u | ((uint32_t)s.rot8 << 16) | (uint32_t)((ax + 128) & 0xFF) | ((uint32_t)((ay + 128) & 0xFF) << 8);
     if (__builtin_expect(done && autoreset, 0)) {  // cold: keep the reset code out of the hot instruction stream
         spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh);
     } else {
@@ -783,6 +823,22 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         io.core[i] = s;
         store_desc_head(&io.desc[i], d);
     }
+}
+
+// Debug view: the current descriptors with the agent the reference's debug render shows -- the stored (sprite, rect) pair of
+// the last STEP (stale right after a reset; oracle/mgo_spot.c sp_debug), sprite 0 at the agent's rect before any step.
+__global__ __launch_bounds__(256) void spot_debug_desc_kernel(SpotParams P, SpotIO io, SpotDesc* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    SpotDesc d = io.desc[i];
+    const SpotCore s = io.core[i];
+    d.valid = 1;
+    if (s.pad >> 31) {
+        d.sprite = (s.pad >> 16) & 7u;
+        d.sx = (int16_t)((int)(s.pad & 0xFFu) - 128 - P.sprite_half);
+        d.sy = (int16_t)((int)((s.pad >> 8) & 0xFFu) - 128 - P.sprite_half);
+    }
+    out[i] = d;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1031,6 +1087,7 @@ class SpotFamily : public Family {
 
    public:
     void on_state_loaded() override { seeded_ = true; }
+    void raster_debug(void* frames, hipStream_t s) override;
 
    private:
     std::unique_ptr<Atlas> atlas_;
@@ -1042,6 +1099,16 @@ class SpotFamily : public Family {
     ErrorWord err_;
     RngStore rng_;
 };
+
+void SpotFamily::raster_debug(void* frames, hipStream_t s) {
+    if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next render");
+    DevArray<SpotDesc> dbg;
+    dbg.alloc(n_, false);
+    hipLaunchKernelGGL(spot_debug_desc_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
+    launch_raster<SpotDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+    MG_HIP(hipGetLastError());
+    MG_HIP(hipStreamSynchronize(s));  // dbg is released on return
+}
 
 Family* make_spot(int endless, int num_envs) { return new SpotFamily(endless, num_envs); }
 

@@ -55,6 +55,7 @@ def _load():
     L.mg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
                           C.c_int, C.c_void_p]
     L.mg_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mg_render_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mg_state_size.argtypes = [C.c_void_p]
     L.mg_state_size.restype = C.c_size_t
     L.mg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

@@ -108,6 +108,14 @@ int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, voi
  * Python mirror (the store stream is 8-13 % faster into some allocations than into others: profiles/r01l_placement.md). */
 int mg_render(mg_env* env, void* obs_dev, void* stream);
 
+/* Env.render() with render_mode "debug_rgb_array" (e.g. mortar_mayhem_grid.py:403-405 -> _build_debug_surface :104-135)
+ * for every instance: the ground-truth view (target tile ring / whole path and walls / everything the spotlight layer
+ * hides drawn over it), stretched to 336 x 336 like pygame.transform.scale, in IMAGE order:
+ * rgb_dev uint8 [num_envs][336 y][336 x][3].  No state changes.  The command glyph of the mortar family follows the
+ * reference's clone of the visualisation list under the assumption of one render per reset / step (what a recording
+ * loop does).  Synchronous (allocates and frees a scratch buffer); not a hot path. */
+int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream);
+
 /* Env.step(action) (e.g. mortar_mayhem_grid.py:280-375) for all instances.
  * actions_dev: int32 [num_envs] (Discrete) or [num_envs][2] (MultiDiscrete).
  * reward_dev: float32 [num_envs] (the reference's Python float, rounded once to float32);

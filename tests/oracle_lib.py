@@ -36,6 +36,7 @@ def lib():
         L.mgo_get_list.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.mgo_get_gt.argtypes = [C.c_void_p, C.c_void_p]
         L.mgo_rng_words.argtypes = [C.c_void_p, C.c_void_p]
+        L.mgo_render_debug.argtypes = [C.c_void_p, C.c_void_p]
         L.mgo_test_rng.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mgo_batch_create.restype = C.c_void_p
         L.mgo_batch_create.argtypes = [C.c_char_p, C.c_int, C.c_double]
@@ -122,6 +123,12 @@ class OracleEnv:
         w = np.zeros(6, np.uint64)
         self.L.mgo_rng_words(self.h, w.ctypes.data)
         return w
+
+    def debug_view(self):
+        """render() with render_mode "debug_rgb_array": uint8 [336][336][3], image order"""
+        out = np.zeros((336, 336, 3), np.uint8)
+        assert self.L.mgo_render_debug(self.h, out.ctypes.data) == 0
+        return out
 
 
 class OracleBatch:
