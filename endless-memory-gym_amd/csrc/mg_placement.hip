@@ -30,6 +30,7 @@ constexpr size_t MiB = 1ull << 20, GiB = 1ull << 30;
 constexpr size_t PIECE = 304 * MiB;         // = one window of the probe: 14,336 frames of 21,168 B (64-MiB pieces measured the
                                             // same, 16 MiB +6 %, 2 MiB +12 %: profiles/r02_zones.md)
 constexpr size_t SPACER = 16 * GiB;
+constexpr size_t ZONE = 96 * GiB;            // a third of the 288 GB
 constexpr int PROBE_GRID = 14336;
 constexpr double CROSS_ZONE_TBPS = 5.85;    // different zones 6.1-6.5 ...
 constexpr double SAME_ZONE_TBPS = 5.35;     // ... same zone 4.9-5.3 (profiles/r02_zones.md); in between: a piece that straddles
@@ -85,6 +86,7 @@ struct Piece {
 struct Mapping {
     size_t va_bytes = 0;
     std::vector<std::pair<size_t, Piece>> pieces;  // (offset, piece)
+    std::vector<int> piece_class;                  // zone class of every piece (index into the device's references)
     bool plain = false;                            // hipMalloc fallback
     int device = 0;
 };
@@ -193,6 +195,28 @@ double probe_tbps(void* a, void* b) {
 
 }  // namespace
 
+// Per device, for the life of the process: one dedicated reference piece per zone class found so far (mapped, never part
+// of a buffer: the probe writes into it) and a bounded pool of spare pieces whose class is known -- pieces a search
+// classified but did not need, and the pieces of buffers that were freed.  The second buffer of a process is assembled
+// from the pool or with a handful of probes instead of another walk.
+struct ZoneCache {
+    std::vector<Cand> refs;                 // class j = "slow together with refs[j]"
+    std::vector<std::vector<Piece>> pool;   // spare pieces by class
+    size_t pooled = 0;
+};
+constexpr size_t POOL_CAP = 10;             // pieces (3 GiB) kept at most
+std::map<int, ZoneCache> g_zones;
+
+void pool_put(ZoneCache& Z, int cls, Piece p) {
+    if (cls >= 0 && cls < (int)Z.refs.size() && Z.pooled < POOL_CAP) {
+        if (Z.pool.size() < Z.refs.size()) Z.pool.resize(Z.refs.size());
+        Z.pool[cls].push_back(p);
+        Z.pooled++;
+    } else {
+        release_piece(p);
+    }
+}
+
 extern "C" {
 
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out, mg_obs_alloc_info* info) {
@@ -214,10 +238,9 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         *out = nullptr;
         size_t free_b = 0, total_b = 0;
         MG_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 5 * 2, 128 * GiB);
+        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 2, 144 * GiB);
         const size_t k = (bytes + PIECE - 1) / PIECE;
-        // buffers of one piece or less (the 256-MB Infinity Cache absorbs most of those) and boxes without room: plain
-        if (k < 2 || search_budget_bytes < PIECE || free_b < (k + 4) * PIECE) {
+        auto plain = [&](int zones) {
             void* p = nullptr;
             MG_HIP(hipMalloc(&p, bytes));
             Mapping m;
@@ -226,44 +249,58 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             std::lock_guard<std::mutex> lk(g_mu);
             g_live[p] = m;
             *out = p;
+            I.zones = zones;
+            I.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (info) *info = I;
+        };
+        std::unique_lock<std::mutex> lock(g_mu);
+        ZoneCache& Z = g_zones[device];
+        // buffers of one piece or less (the 256-MB Infinity Cache absorbs most of those) and boxes without room: plain
+        if (k < 2 || (Z.pooled < k && (search_budget_bytes < PIECE || free_b < (k + 4) * PIECE))) {
+            lock.unlock();
+            plain(0);
             return 0;
         }
-        // Classes of pieces that are slow together (= one zone each), found by probing every new piece against the first
-        // piece of each class.  Done when k pieces can be taken with no class contributing more than half (rounded up).
-        const size_t half = (k + 1) / 2;
-        std::vector<std::vector<Cand>> cls;
-        std::vector<Cand> leftover;  // unclear pieces and pieces of a class that is full: they keep the allocator moving
-        std::vector<Piece> spacers;
-        size_t walked = 0;
-        auto drop_all = [&] {
-            for (auto& v : cls)
-                for (auto& c : v) c.drop();
-            for (auto& c : leftover) c.drop();
-            for (auto& s : spacers) release_piece(s);
-        };
+        // chosen[j] = pieces of class j for this buffer; no class may contribute more than half (rounded up) -- relaxed to
+        // "at least a quarter from other zones" once a walk would be needed (one in five measured within 2 % of an even split)
+        const size_t half = (k + 1) / 2, loose_cap = k - std::max<size_t>(1, k / 4);
+        std::vector<std::vector<Piece>> chosen(3);
         auto usable = [&](size_t cap) {
             size_t u = 0;
-            for (auto& v : cls) u += std::min(v.size(), cap);
+            for (auto& v : chosen) u += std::min(v.size(), cap);
             return u;
         };
-        // good enough to stop walking: two zones, and the smaller one(s) hold at least one piece in four (one in five
-        // measured within 2 % of an even split: profiles/r02_zones.md)
-        const size_t loose_cap = k - std::max<size_t>(1, k / 4);
-        bool exportable = false;  // flavour of the next piece; toggled whenever a piece was of no use
-        int restarts = 0;
-        while ((usable(half) < k || cls.size() < 2) && walked <= search_budget_bytes) {
+        auto classes_used = [&] {
+            int c = 0;
+            for (auto& v : chosen) c += !v.empty();
+            return c;
+        };
+        // 1. from the pool
+        for (size_t j = 0; j < Z.pool.size() && j < 3; ++j)
+            while (!Z.pool[j].empty() && chosen[j].size() < half && usable(half) < k) {
+                chosen[j].push_back(Z.pool[j].back());
+                Z.pool[j].pop_back();
+                Z.pooled--;
+            }
+        // 2. new pieces, classified against the references (a piece that is fast with all of them founds a new class and
+        //    becomes its dedicated reference); pieces of no use and spacers keep the driver's allocator moving
+        std::vector<Cand> unclear;
+        std::vector<std::pair<int, Cand>> surplus;
+        std::vector<Piece> spacers;
+        size_t walked = 0;
+        bool exportable = false;
+        while ((usable(half) < k || classes_used() < 2) && walked <= search_budget_bytes) {
             Cand c;
             if (!c.make(device, exportable)) break;
             int home = -1;
-            bool unclear = false;
-            for (size_t j = 0; j < cls.size() && home < 0; ++j) {
-                c.tbps = probe_tbps(cls[j][0].va, c.va);
+            bool odd = false;
+            for (size_t j = 0; j < Z.refs.size() && home < 0; ++j) {
+                c.tbps = probe_tbps(Z.refs[j].va, c.va);
                 if (c.tbps < SAME_ZONE_TBPS) {
                     home = (int)j;
                     I.probe_same_tbps = std::max(I.probe_same_tbps, c.tbps);
                 } else if (c.tbps <= CROSS_ZONE_TBPS) {
-                    unclear = true;
+                    odd = true;
                     break;
                 } else {
                     I.probe_cross_tbps = I.probe_cross_tbps == 0 ? c.tbps : std::min(I.probe_cross_tbps, c.tbps);
@@ -271,82 +308,105 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             }
             if (debug)
                 fprintf(stderr, "mg_obs_alloc: %5.1f GiB walked, %s piece: last probe %.2f TB/s -> %s\n", walked / (double)GiB,
-                        exportable ? "exportable" : "ordinary", c.tbps, unclear ? "unclear" : home < 0 ? "new class" : "known class");
-            if (!unclear && home < 0 && cls.size() < 3) {
-                cls.push_back({c});
+                        exportable ? "exportable" : "ordinary", c.tbps, odd ? "unclear" : home < 0 ? "new class" : "known class");
+            if (!odd && home < 0 && Z.refs.size() < 3) {  // a new zone: this piece stays mapped as its reference
+                Z.refs.push_back(c);
+                Z.pool.resize(Z.refs.size());
                 continue;
             }
-            if (!unclear && home >= 0 && cls[home].size() < half) {
-                cls[home].push_back(c);
+            if (!odd && home >= 0 && chosen[home].size() < half) {
+                c.unmap();
+                chosen[home].push_back(c.piece);
                 continue;
             }
-            // of no use (unclear, a fourth class, or its class is full): keep it out of the way and move on
-            leftover.push_back(c);
+            // of no use right now (unclear, or its class is full): keep it out of the way and move on
+            if (odd || home < 0) unclear.push_back(c);
+            else surplus.push_back({home, c});
             walked += PIECE;
-            if (cls.size() >= 2 && usable(loose_cap) >= k) break;
-            // a first piece that straddles a zone boundary makes every partner look half-way: start over without it
-            if (unclear && cls.size() == 1 && cls[0].size() == 1 && leftover.size() >= 3 && restarts < 2) {
-                ++restarts;
-                leftover.push_back(cls[0][0]);
-                cls.clear();
-                continue;
-            }
+            if (classes_used() >= 2 && usable(loose_cap) >= k) break;
             exportable = !exportable;
-            if (!exportable) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed
+            if (!exportable) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed.
+                // The first step is one zone long (a pristine VRAM hands out ~100 GiB of one zone in a row); then 16 GiB.
                 Piece sp;
-                if (walked + SPACER > search_budget_bytes || !create_piece(device, SPACER, &sp)) break;
+                size_t step = spacers.empty() ? ZONE : SPACER;
+                if (walked + step > search_budget_bytes) step = SPACER;
+                if (walked + step > search_budget_bytes || !create_piece(device, step, &sp)) break;
                 spacers.push_back(sp);
-                walked += SPACER;
+                walked += step;
             }
         }
         I.searched_bytes = walked;
-        I.zones = (int)cls.size();
-        // order: round-robin over the classes, largest first; then whatever else is there, then fresh pieces
-        std::sort(cls.begin(), cls.end(), [](const std::vector<Cand>& x, const std::vector<Cand>& y) { return x.size() > y.size(); });
-        std::vector<Cand> order;
-        for (size_t round = 0; order.size() < k; ++round) {
+        for (auto& sp : spacers) release_piece(sp);
+        for (auto& c : unclear) c.drop();
+        auto surplus_to_pool = [&] {
+            for (auto& sc : surplus) {
+                sc.second.unmap();
+                pool_put(Z, sc.first, sc.second.piece);
+            }
+            surplus.clear();
+        };
+        I.zones = classes_used();
+        if (I.zones < 2) {  // one zone only: an assembled buffer has nothing over an ordinary allocation (measured: slower)
+            for (size_t j = 0; j < chosen.size(); ++j)
+                for (auto& p : chosen[j]) pool_put(Z, (int)j, p);
+            surplus_to_pool();
+            lock.unlock();
+            if (debug) fprintf(stderr, "mg_obs_alloc: one zone only after %.1f GiB: plain allocation\n", walked / (double)GiB);
+            plain(1);
+            return 0;
+        }
+        // the rest (if the strict balance was not reached): surplus pieces of any class, then fresh ones of unknown class
+        std::vector<Piece> unknown;
+        while (usable(k) + unknown.size() < k) {
+            if (!surplus.empty()) {
+                surplus.back().second.unmap();
+                chosen[surplus.back().first].push_back(surplus.back().second.piece);
+                surplus.pop_back();
+                continue;
+            }
+            Piece p;
+            if (!create_piece(device, PIECE, &p)) {
+                for (size_t j = 0; j < chosen.size(); ++j)
+                    for (auto& q : chosen[j]) pool_put(Z, (int)j, q);
+                for (auto& q : unknown) release_piece(q);
+                throw std::runtime_error("mg_obs_alloc: out of device memory");
+            }
+            unknown.push_back(p);
+        }
+        surplus_to_pool();
+        // order: round-robin over the classes, largest first
+        std::vector<int> by_size = {0, 1, 2};
+        std::sort(by_size.begin(), by_size.end(), [&](int x, int y) { return chosen[x].size() > chosen[y].size(); });
+        std::vector<std::pair<Piece, int>> order;
+        for (size_t round = 0; order.size() + unknown.size() < k; ++round) {
             bool any = false;
-            for (auto& v : cls)
-                if (round < v.size() && order.size() < k) {
-                    order.push_back(v[round]);
+            for (int j : by_size)
+                if (round < chosen[j].size() && order.size() + unknown.size() < k) {
+                    order.push_back({chosen[j][round], j});
                     any = true;
                 }
             if (!any) break;
         }
-        for (auto& v : cls)
-            for (size_t i = 0; i < v.size(); ++i) {
+        for (auto& q : unknown) order.push_back({q, -1});
+        for (int j : by_size)  // pieces beyond k (cannot happen with the caps above; kept for safety)
+            for (size_t r = 0; r < chosen[j].size(); ++r) {
                 bool used = false;
-                for (auto& o : order) used = used || o.piece.h == v[i].piece.h;
-                if (!used) leftover.push_back(v[i]);
+                for (auto& o : order) used = used || o.first.h == chosen[j][r].h;
+                if (!used) pool_put(Z, j, chosen[j][r]);
             }
-        while (order.size() < k) {
-            Cand c;
-            if (!leftover.empty()) {
-                c = leftover.back();
-                leftover.pop_back();
-            } else if (!c.make(device)) {
-                for (auto& o : order) o.drop();
-                for (auto& s2 : spacers) release_piece(s2);
-                throw std::runtime_error("mg_obs_alloc: out of device memory");
-            }
-            order.push_back(c);
-        }
-        for (auto& c : leftover) c.drop();
-        for (auto& s2 : spacers) release_piece(s2);
-        (void)drop_all;
         // one contiguous virtual range
         void* va = nullptr;
         if (hipMemAddressReserve(&va, k * PIECE, 2 * MiB, nullptr, 0) != hipSuccess) {
-            for (auto& c : order) c.drop();
+            for (auto& o : order) pool_put(Z, o.second, o.first);
             throw std::runtime_error("mg_obs_alloc: hipMemAddressReserve failed");
         }
         Mapping m;
         m.va_bytes = k * PIECE;
         m.device = device;
         for (size_t i = 0; i < k; ++i) {
-            order[i].unmap();
-            map_at((char*)va + i * PIECE, order[i].piece, device);
-            m.pieces.push_back({i * PIECE, order[i].piece});
+            map_at((char*)va + i * PIECE, order[i].first, device);
+            m.pieces.push_back({i * PIECE, order[i].first});
+            m.piece_class.push_back(order[i].second);
         }
         // belt and braces: what one kernel writes through the new range, the next one must read
         if (const unsigned long long bad = verify_range(va, k * PIECE, 0x5EEDu)) {
@@ -357,16 +417,14 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             throw std::runtime_error("mg_obs_alloc: " + std::to_string(bad) + " of " + std::to_string(k * PIECE / 16) +
                                      " vectors of the assembled range did not read back (stale translations?)");
         }
-        {
-            std::lock_guard<std::mutex> lk(g_mu);
-            g_live[va] = m;
-        }
+        g_live[va] = m;
         *out = va;
         I.pieces = (int)k;
         I.piece_bytes = PIECE;
         I.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (debug)
-            fprintf(stderr, "mg_obs_alloc: %zu pieces, zones %d, %.1f GiB walked, %.0f ms\n", k, I.zones, walked / (double)GiB, I.search_ms);
+            fprintf(stderr, "mg_obs_alloc: %zu pieces, zones %d, %.1f GiB walked, %.0f ms, %zu spare pieces pooled\n", k, I.zones,
+                    walked / (double)GiB, I.search_ms, Z.pooled);
         if (info) *info = I;
         return 0;
     } catch (const std::exception& e) {
@@ -397,9 +455,11 @@ int mg_obs_free(void* p) {
     } restore{prev};
     if (m.plain) return hipFree(p) == hipSuccess ? 0 : -1;
     (void)hipDeviceSynchronize();
-    for (auto& op : m.pieces) {
-        (void)hipMemUnmap((char*)p + op.first, op.second.bytes);
-        (void)hipMemRelease(op.second.h);
+    std::lock_guard<std::mutex> lk(g_mu);
+    ZoneCache& Z = g_zones[m.device];
+    for (size_t i = 0; i < m.pieces.size(); ++i) {
+        (void)hipMemUnmap((char*)p + m.pieces[i].first, m.pieces[i].second.bytes);
+        pool_put(Z, i < m.piece_class.size() ? m.piece_class[i] : -1, m.pieces[i].second);  // spare pieces of a known zone
     }
     va_free(p, m.va_bytes);
     return 0;

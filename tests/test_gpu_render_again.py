@@ -40,7 +40,8 @@ def test_balanced_obs_buffer_is_transparent():
         a = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0, obs_placement="balanced", obs_format=fmt)
         b = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0, obs_placement="plain", obs_format=fmt)
         info = a.obs_placement_info
-        assert info is not None and info["zones"] in (1, 2, 3) and info["pieces"] * info["piece_bytes"] >= a.obs.numel() * a.obs.element_size()
+        assert info is not None and info["zones"] in (1, 2, 3)
+        assert info["zones"] == 1 or info["pieces"] * info["piece_bytes"] >= a.obs.numel() * a.obs.element_size()  # 1: plain allocation
         assert b.obs_placement_info is None
         oa, _ = a.reset(seed=3)
         ob, _ = b.reset(seed=3)
