@@ -32,7 +32,7 @@ constexpr size_t PIECE = 304 * MiB;         // = one window of the probe: 14,336
 constexpr size_t SPACER = 16 * GiB;
 constexpr size_t ZONE = 96 * GiB;            // a third of the 288 GB
 constexpr int PROBE_GRID = 14336;
-constexpr double CROSS_ZONE_TBPS = 5.85;    // different zones 6.1-6.5 ...
+static const double CROSS_ZONE_TBPS = getenv("MEMGYM_OBS_CROSS_TBPS") ? atof(getenv("MEMGYM_OBS_CROSS_TBPS")) : 5.85;  // different zones 6.1-6.5 ...
 constexpr double SAME_ZONE_TBPS = 5.35;     // ... same zone 4.9-5.3 (profiles/r02_zones.md); in between: a piece that straddles
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -238,7 +238,7 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         *out = nullptr;
         size_t free_b = 0, total_b = 0;
         MG_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 2, 144 * GiB);
+        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 20 * 11, 160 * GiB);
         const size_t k = (bytes + PIECE - 1) / PIECE;
         auto plain = [&](int zones) {
             void* p = nullptr;
@@ -308,11 +308,17 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             }
             if (debug)
                 fprintf(stderr, "mg_obs_alloc: %5.1f GiB walked, %s piece: last probe %.2f TB/s -> %s\n", walked / (double)GiB,
-                        exportable ? "exportable" : "ordinary", c.tbps, odd ? "unclear" : home < 0 ? "new class" : "known class");
+                        exportable ? "exportable" : "ordinary", c.tbps,
+                        odd ? "unclear" : home >= 0 ? "known class" : Z.refs.size() < 3 ? "new class" : "fast with every reference");
             if (!odd && home < 0 && Z.refs.size() < 3) {  // a new zone: this piece stays mapped as its reference
                 Z.refs.push_back(c);
                 Z.pool.resize(Z.refs.size());
                 continue;
+            }
+            if (!odd && home < 0) {  // fast with all three references: as good a partner as any -- counted with the emptiest class
+                home = 0;
+                for (int j = 1; j < 3; ++j)
+                    if (chosen[j].size() < chosen[home].size()) home = j;
             }
             if (!odd && home >= 0 && chosen[home].size() < half) {
                 c.unmap();

@@ -163,8 +163,8 @@ int mg_peek_errors(mg_env* env, int* flags);
  * probe, half of them from the first piece's zone and half from elsewhere, mapped alternately into one contiguous
  * virtual range (rounded up to whole pieces).  Pieces it does not need and spacer allocations of 8 GiB that are never
  * mapped or written keep the driver's allocator moving during the search and are released before the call returns (at
- * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = half of the free memory, at most 144 GiB -- a pristine
- * VRAM hands out up to 96 GiB of ONE zone in a row, so the first spacer is that long; 0 = no
+ * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = 55 % of the free memory, at most 160 GiB -- a pristine
+ * VRAM hands out 100-130 GiB of ONE zone in a row, so the first spacer is 96 GiB long; 0 = no
  * search).  Buffers of 304 MiB or less are plain hipMalloc.  Synchronous; 2 ms when the first pieces already differ,
  * 1-2 s for the longest search.  mg_obs_free releases a buffer obtained here (after synchronising the device). */
 typedef struct mg_obs_alloc_info {
