@@ -86,7 +86,7 @@ struct Piece {
 struct Mapping {
     size_t va_bytes = 0;
     std::vector<std::pair<size_t, Piece>> pieces;  // (offset, piece)
-    std::vector<int> piece_class;                  // zone class of every piece (index into the device's references)
+    std::vector<int> piece_class;                  // group id of every piece (pieces of one id are slow together)
     bool plain = false;                            // hipMalloc fallback
     int device = 0;
 };
@@ -195,27 +195,30 @@ double probe_tbps(void* a, void* b) {
 
 }  // namespace
 
-// Per device, for the life of the process: one dedicated reference piece per zone class found so far (mapped, never part
-// of a buffer: the probe writes into it) and a bounded pool of spare pieces whose class is known -- pieces a search
-// classified but did not need, and the pieces of buffers that were freed.  The second buffer of a process is assembled
-// from the pool or with a handful of probes instead of another walk.
+// Per device, for the life of the process: a bounded pool of spare pieces in GROUPS of pieces that are slow together (one
+// zone each) -- pieces a search classified but did not need, and the pieces of buffers that were freed.  The next buffer
+// starts from the pool: often no new piece, let alone a walk, is needed.
 struct ZoneCache {
-    std::vector<Cand> refs;                 // class j = "slow together with refs[j]"
-    std::vector<std::vector<Piece>> pool;   // spare pieces by class
+    std::map<int, std::vector<Piece>> pool;  // group id -> spare pieces
     size_t pooled = 0;
+    int next_id = 0;
 };
-constexpr size_t POOL_CAP = 10;             // pieces (3 GiB) kept at most
+constexpr size_t POOL_CAP = 10;  // pieces (3 GiB) kept at most
 std::map<int, ZoneCache> g_zones;
 
-void pool_put(ZoneCache& Z, int cls, Piece p) {
-    if (cls >= 0 && cls < (int)Z.refs.size() && Z.pooled < POOL_CAP) {
-        if (Z.pool.size() < Z.refs.size()) Z.pool.resize(Z.refs.size());
-        Z.pool[cls].push_back(p);
+void pool_put(ZoneCache& Z, int group, Piece p) {
+    if (group >= 0 && Z.pooled < POOL_CAP) {
+        Z.pool[group].push_back(p);
         Z.pooled++;
     } else {
         release_piece(p);
     }
 }
+
+struct Group {
+    int id = -1;
+    std::vector<Cand> pcs;  // pcs[0] is the group's reference during a search (mapped on its own while the search runs)
+};
 
 extern "C" {
 
@@ -240,7 +243,7 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         MG_HIP(hipMemGetInfo(&free_b, &total_b));
         if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 20 * 11, 160 * GiB);
         const size_t k = (bytes + PIECE - 1) / PIECE;
-        auto plain = [&](int zones) {
+        auto plain = [&](int zones) {  // (called without the lock)
             void* p = nullptr;
             MG_HIP(hipMalloc(&p, bytes));
             Mapping m;
@@ -261,145 +264,133 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             plain(0);
             return 0;
         }
-        // chosen[j] = pieces of class j for this buffer; no class may contribute more than half (rounded up) -- relaxed to
-        // "at least a quarter from other zones" once a walk would be needed (one in five measured within 2 % of an even split)
+        // No group may contribute more than half of the pieces (rounded up); once a walk would be needed, "at least a
+        // quarter of the pieces from other groups" is good enough (one in five measured within 2 % of an even split).
         const size_t half = (k + 1) / 2, loose_cap = k - std::max<size_t>(1, k / 4);
-        std::vector<std::vector<Piece>> chosen(3);
+        std::vector<Group> groups;
+        for (auto& kv : Z.pool) {  // start from the pool
+            if (kv.second.empty()) continue;
+            Group g;
+            g.id = kv.first;
+            for (auto& p : kv.second) {
+                Cand c;
+                c.piece = p;
+                g.pcs.push_back(c);
+            }
+            groups.push_back(g);
+        }
+        Z.pool.clear();
+        Z.pooled = 0;
         auto usable = [&](size_t cap) {
             size_t u = 0;
-            for (auto& v : chosen) u += std::min(v.size(), cap);
+            for (auto& g : groups) u += std::min(g.pcs.size(), cap);
             return u;
         };
-        auto classes_used = [&] {
-            int c = 0;
-            for (auto& v : chosen) c += !v.empty();
-            return c;
-        };
-        // 1. from the pool
-        for (size_t j = 0; j < Z.pool.size() && j < 3; ++j)
-            while (!Z.pool[j].empty() && chosen[j].size() < half && usable(half) < k) {
-                chosen[j].push_back(Z.pool[j].back());
-                Z.pool[j].pop_back();
-                Z.pooled--;
+        auto ref_va = [&](Group& g) {  // the group's reference, mapped on its own
+            Cand& r = g.pcs[0];
+            if (!r.va) {
+                if (hipMemAddressReserve(&r.va, PIECE, 2 * MiB, nullptr, 0) != hipSuccess) throw std::runtime_error("mg_obs_alloc: hipMemAddressReserve failed");
+                map_at(r.va, r.piece, device);
             }
-        // 2. new pieces, classified against the references (a piece that is fast with all of them founds a new class and
-        //    becomes its dedicated reference); pieces of no use and spacers keep the driver's allocator moving
+            return r.va;
+        };
         std::vector<Cand> unclear;
-        std::vector<std::pair<int, Cand>> surplus;
         std::vector<Piece> spacers;
         size_t walked = 0;
         bool exportable = false;
-        while ((usable(half) < k || classes_used() < 2) && walked <= search_budget_bytes) {
-            Cand c;
-            if (!c.make(device, exportable)) break;
-            int home = -1;
-            bool odd = false;
-            for (size_t j = 0; j < Z.refs.size() && home < 0; ++j) {
-                c.tbps = probe_tbps(Z.refs[j].va, c.va);
-                if (c.tbps < SAME_ZONE_TBPS) {
-                    home = (int)j;
-                    I.probe_same_tbps = std::max(I.probe_same_tbps, c.tbps);
-                } else if (c.tbps <= CROSS_ZONE_TBPS) {
-                    odd = true;
-                    break;
+        auto give_back = [&] {  // everything that is not part of the buffer
+            for (auto& g : groups)
+                for (auto& c : g.pcs) {
+                    c.unmap();
+                    pool_put(Z, g.id, c.piece);
+                }
+            groups.clear();
+            for (auto& c : unclear) c.drop();
+            unclear.clear();
+            for (auto& sp : spacers) release_piece(sp);
+            spacers.clear();
+        };
+        try {
+            while ((usable(half) < k || groups.size() < 2) && walked <= search_budget_bytes) {
+                Cand c;
+                if (!c.make(device, exportable)) break;
+                int home = -1;
+                bool odd = false;
+                for (size_t j = 0; j < groups.size() && home < 0; ++j) {
+                    c.tbps = probe_tbps(ref_va(groups[j]), c.va);
+                    if (c.tbps < SAME_ZONE_TBPS) {
+                        home = (int)j;
+                        I.probe_same_tbps = std::max(I.probe_same_tbps, c.tbps);
+                    } else if (c.tbps <= CROSS_ZONE_TBPS) {
+                        odd = true;
+                        break;
+                    } else {
+                        I.probe_cross_tbps = I.probe_cross_tbps == 0 ? c.tbps : std::min(I.probe_cross_tbps, c.tbps);
+                    }
+                }
+                if (debug)
+                    fprintf(stderr, "mg_obs_alloc: %5.1f GiB walked, %s piece: last probe %.2f TB/s -> %s\n", walked / (double)GiB,
+                            exportable ? "exportable" : "ordinary", c.tbps, odd ? "unclear" : home >= 0 ? "known group" : "new group");
+                bool useful = false;
+                if (odd) {
+                    unclear.push_back(c);
+                } else if (home < 0) {  // fast with every group so far: a piece of another zone
+                    Group g;
+                    g.id = Z.next_id++;
+                    g.pcs.push_back(c);
+                    groups.push_back(g);
+                    useful = true;
                 } else {
-                    I.probe_cross_tbps = I.probe_cross_tbps == 0 ? c.tbps : std::min(I.probe_cross_tbps, c.tbps);
+                    useful = groups[home].pcs.size() < half;
+                    c.unmap();  // only references stay mapped
+                    groups[home].pcs.push_back(c);
+                }
+                if (useful) continue;
+                walked += PIECE;
+                if (groups.size() >= 2 && usable(loose_cap) >= k) break;
+                exportable = !exportable;
+                if (!exportable) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed.
+                    // The first step is long (a pristine VRAM hands out 100-130 GiB of one zone in a row), then 16 GiB at a time.
+                    Piece sp;
+                    size_t step = spacers.empty() ? ZONE : SPACER;
+                    if (walked + step > search_budget_bytes) step = SPACER;
+                    if (walked + step > search_budget_bytes || !create_piece(device, step, &sp)) break;
+                    spacers.push_back(sp);
+                    walked += step;
                 }
             }
-            if (debug)
-                fprintf(stderr, "mg_obs_alloc: %5.1f GiB walked, %s piece: last probe %.2f TB/s -> %s\n", walked / (double)GiB,
-                        exportable ? "exportable" : "ordinary", c.tbps,
-                        odd ? "unclear" : home >= 0 ? "known class" : Z.refs.size() < 3 ? "new class" : "fast with every reference");
-            if (!odd && home < 0 && Z.refs.size() < 3) {  // a new zone: this piece stays mapped as its reference
-                Z.refs.push_back(c);
-                Z.pool.resize(Z.refs.size());
-                continue;
-            }
-            if (!odd && home < 0) {  // fast with all three references: as good a partner as any -- counted with the emptiest class
-                home = 0;
-                for (int j = 1; j < 3; ++j)
-                    if (chosen[j].size() < chosen[home].size()) home = j;
-            }
-            if (!odd && home >= 0 && chosen[home].size() < half) {
-                c.unmap();
-                chosen[home].push_back(c.piece);
-                continue;
-            }
-            // of no use right now (unclear, or its class is full): keep it out of the way and move on
-            if (odd || home < 0) unclear.push_back(c);
-            else surplus.push_back({home, c});
-            walked += PIECE;
-            if (classes_used() >= 2 && usable(loose_cap) >= k) break;
-            exportable = !exportable;
-            if (!exportable) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed.
-                // The first step is one zone long (a pristine VRAM hands out ~100 GiB of one zone in a row); then 16 GiB.
-                Piece sp;
-                size_t step = spacers.empty() ? ZONE : SPACER;
-                if (walked + step > search_budget_bytes) step = SPACER;
-                if (walked + step > search_budget_bytes || !create_piece(device, step, &sp)) break;
-                spacers.push_back(sp);
-                walked += step;
-            }
+        } catch (...) {
+            give_back();
+            throw;
         }
         I.searched_bytes = walked;
-        for (auto& sp : spacers) release_piece(sp);
-        for (auto& c : unclear) c.drop();
-        auto surplus_to_pool = [&] {
-            for (auto& sc : surplus) {
-                sc.second.unmap();
-                pool_put(Z, sc.first, sc.second.piece);
-            }
-            surplus.clear();
-        };
-        I.zones = classes_used();
-        if (I.zones < 2) {  // one zone only: an assembled buffer has nothing over an ordinary allocation (measured: slower)
-            for (size_t j = 0; j < chosen.size(); ++j)
-                for (auto& p : chosen[j]) pool_put(Z, (int)j, p);
-            surplus_to_pool();
+        I.zones = (int)std::min<size_t>(groups.size(), 3);
+        if (groups.size() < 2 || usable(k) < k) {  // one zone only (or out of memory half-way): an assembled buffer has nothing
+            const bool one = groups.size() < 2;       // over an ordinary allocation (measured: slower)
+            give_back();
             lock.unlock();
-            if (debug) fprintf(stderr, "mg_obs_alloc: one zone only after %.1f GiB: plain allocation\n", walked / (double)GiB);
+            if (debug) fprintf(stderr, "mg_obs_alloc: %s after %.1f GiB: plain allocation\n", one ? "one zone only" : "not enough pieces", walked / (double)GiB);
             plain(1);
             return 0;
         }
-        // the rest (if the strict balance was not reached): surplus pieces of any class, then fresh ones of unknown class
-        std::vector<Piece> unknown;
-        while (usable(k) + unknown.size() < k) {
-            if (!surplus.empty()) {
-                surplus.back().second.unmap();
-                chosen[surplus.back().first].push_back(surplus.back().second.piece);
-                surplus.pop_back();
-                continue;
-            }
-            Piece p;
-            if (!create_piece(device, PIECE, &p)) {
-                for (size_t j = 0; j < chosen.size(); ++j)
-                    for (auto& q : chosen[j]) pool_put(Z, (int)j, q);
-                for (auto& q : unknown) release_piece(q);
-                throw std::runtime_error("mg_obs_alloc: out of device memory");
-            }
-            unknown.push_back(p);
-        }
-        surplus_to_pool();
-        // order: round-robin over the classes, largest first
-        std::vector<int> by_size = {0, 1, 2};
-        std::sort(by_size.begin(), by_size.end(), [&](int x, int y) { return chosen[x].size() > chosen[y].size(); });
+        // choose: round-robin over the groups, largest first, under the strictest cap that still yields k pieces
+        const size_t cap = usable(half) >= k ? half : (usable(loose_cap) >= k ? loose_cap : k);
+        std::sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.pcs.size() > y.pcs.size(); });
         std::vector<std::pair<Piece, int>> order;
-        for (size_t round = 0; order.size() + unknown.size() < k; ++round) {
-            bool any = false;
-            for (int j : by_size)
-                if (round < chosen[j].size() && order.size() + unknown.size() < k) {
-                    order.push_back({chosen[j][round], j});
-                    any = true;
+        for (size_t round = 0; round < cap && order.size() < k; ++round)
+            for (auto& g : groups)
+                if (round < g.pcs.size() && order.size() < k) {
+                    g.pcs[round].unmap();
+                    order.push_back({g.pcs[round].piece, g.id});
+                    g.pcs[round].piece.h = nullptr;  // taken
                 }
-            if (!any) break;
+        for (auto& g : groups) {
+            std::vector<Cand> rest;
+            for (auto& c : g.pcs)
+                if (c.piece.h) rest.push_back(c);
+            g.pcs.swap(rest);
         }
-        for (auto& q : unknown) order.push_back({q, -1});
-        for (int j : by_size)  // pieces beyond k (cannot happen with the caps above; kept for safety)
-            for (size_t r = 0; r < chosen[j].size(); ++r) {
-                bool used = false;
-                for (auto& o : order) used = used || o.first.h == chosen[j][r].h;
-                if (!used) pool_put(Z, j, chosen[j][r]);
-            }
+        give_back();
         // one contiguous virtual range
         void* va = nullptr;
         if (hipMemAddressReserve(&va, k * PIECE, 2 * MiB, nullptr, 0) != hipSuccess) {
@@ -428,9 +419,12 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         I.pieces = (int)k;
         I.piece_bytes = PIECE;
         I.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (debug)
-            fprintf(stderr, "mg_obs_alloc: %zu pieces, zones %d, %.1f GiB walked, %.0f ms, %zu spare pieces pooled\n", k, I.zones,
+        if (debug) {
+            std::string lay;
+            for (auto& o : order) lay += (char)('A' + (o.second % 26));
+            fprintf(stderr, "mg_obs_alloc: %zu pieces %s, %.1f GiB walked, %.0f ms, %zu spare pieces pooled\n", k, lay.c_str(),
                     walked / (double)GiB, I.search_ms, Z.pooled);
+        }
         if (info) *info = I;
         return 0;
     } catch (const std::exception& e) {
