@@ -248,6 +248,8 @@ def self_launch(args):
     import torch
 
     have = torch.cuda.device_count()
+    if os.environ.get("MEMGYM_BENCH_ONE_DEVICE"):  # plumbing test: every rank on GPU 0 (tests/test_gpu_bench_ranks.py)
+        have = args.gpus
     if have < args.gpus:
         print("bench.py: --gpus %d but this host shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
         return 2
@@ -288,6 +290,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5 measurements")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every N-th step with HIP events (each bracketed step costs ~15 us)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only for plumbing tests with all ranks on one GPU)")
     ap.add_argument("--cpu-worker", nargs=3, metavar=("ENV", "THREADS", "SECONDS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -301,11 +305,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MEMGYM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
