@@ -958,9 +958,13 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
     }
 }
 
+// defer != 0: an instance that resets in this call gets everything but its path here (the draws in front of it, the agent's
+// start, the frame descriptor -- a reset frame shows nothing of the path) and is queued; the queue is served by the first
+// workgroups of the raster launch that follows (mystery_raster_paths_kernel).  The launch no longer lasts as long as one noisy A* (23 us) whenever any of
+// its instances resets (MysteryPath-Grid: 0.5 % of them per step).
 __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions,
                                                            float* reward_out, uint8_t* done_out, float* gt,
-                                                           mg_info_buffers info, int autoreset, int lpw) {
+                                                           mg_info_buffers info, int autoreset, int lpw, int defer) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
     const PathWS W{smem};
@@ -985,13 +989,81 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         if (reset_me) req = mp_pre_reset(P, s, g);
         int len = 0;
         uint64_t pm = 0;
-        serve_mp(W, req, g, io.err, len, pm, io.walls, i);
-        if (reset_me) mp_post_reset(P, s, req, len, pm, d);
+        if (!defer) serve_mp(W, req, g, io.err, len, pm, io.walls, i);
+        if (reset_me) {
+            mp_post_reset(P, s, req, len, pm, d);  // (deferred: path_mask / path_len are filled in by mp_path_kernel)
+            if (defer) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+        }
     }
     if (active) {
         g.store(io.rng, i);  // unchanged streams are rewritten with the same words
         io.core[i] = s;
         io.desc[i] = d;
+    }
+}
+
+// The queued resets of a deferred step are served INSIDE the raster launch: its first PATH_WGS workgroups do not draw frames
+// but drain the queue, one wave per entry (entry w is wave w's first job, later ones come from a shared counter, the
+// last of them out clears the counters: see emp_serve_kernel), then leave their slots to frame workgroups.  Lane 0 plays the
+// instance: its stream stands right behind the draws of mp_pre_reset, the path's ends are in its record; the path, the walls
+// and the stream come back.  No second stream, no events: a fork/join around a side-stream kernel cost 10 us per step.
+constexpr int PATH_WGS = 128;
+template <int FMT>
+__global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs,
+                                                                      int n, MysteryParams P, MysteryIO io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (blockIdx.x < PATH_WGS) {
+        path_ws_init(smem);
+        const PathWS W{smem};
+        const bool me = (threadIdx.x & 63) == 0;
+        const int count = io.qctr[QC_COUNT];
+        const int waves = PATH_WGS * (blockDim.x >> 6);
+        int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
+        while (idx < count) {
+            const int i = bcast(io.queue[idx], 0);
+            Pcg g;
+            PathReq req;
+            req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
+            if (me) {
+                g.load(io.rng, i);
+                const MysteryCore c = io.core[i];
+                req.need = 1; req.sx = c.sx; req.sy = c.sy; req.ex = c.ex; req.ey = c.ey;
+            } else {
+                g.state = g.inc = 0; g.buf = 0; g.has = false;
+            }
+            int len = 0;
+            uint64_t pm = 0;
+            serve_mp(W, req, g, io.err, len, pm, io.walls, i);
+            if (me) {
+                io.core[i].path_mask = pm;
+                io.core[i].path_len = (uint8_t)len;
+                g.store(io.rng, i);
+                idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
+            }
+            idx = bcast(idx, 0);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == PATH_WGS - 1) {  // last service workgroup out
+            io.qctr[QC_COUNT] = 0;
+            io.qctr[QC_HEAD] = 0;
+            io.qctr[QC_LEFT] = 0;
+        }
+        return;
+    }
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = A.tables;
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x, stride = (int)gridDim.x - PATH_WGS;
+    for (int env = (int)blockIdx.x - PATH_WGS; env < n; env += stride) {
+        const MysteryDesc* d = descs + env;
+        if (MysteryComposer::skip(d)) continue;
+        MysteryComposer::compose(d, R);
+        __syncthreads();
+        store_frame<FMT>(smem, obs, env, tid);
+        __syncthreads();
     }
 }
 
@@ -1192,8 +1264,16 @@ class MysteryFamily : public Family {
             hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
                                reward, done, gt, ib, autoreset);
         } else {
+            const int defer = (autoreset && defer_paths()) ? 1 : 0;
             hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
-                               (float*)nullptr, ib, autoreset, lpw());
+                               (float*)nullptr, ib, autoreset, lpw(), defer);
+            if (defer) {  // the paths of this step's resets are generated by the first workgroups of the raster launch
+                prof.end(0, s);
+                prof.begin(1, s);
+                raster_with_paths(obs, s);
+                prof.end(1, s);
+                return;
+            }
         }
         prof.end(0, s);
         prof.begin(1, s);
@@ -1235,6 +1315,29 @@ class MysteryFamily : public Family {
         return want < cap ? want : cap;
     }
     int blocks() const { const int per_block = 4 * lpw(); return (n_ + per_block - 1) / per_block; }
+    // finite variants: generate the paths of auto-resets on a side stream under the raster (MEMGYM_MYSTERY_DEFER=0: in the step kernel)
+    // Measured (MysteryPath-Grid, 32,768 instances, 0.5 % of them reset per step): logic 32.7 -> 12.1 us, 231 -> 252 M
+    // env-steps/s; MysteryPath-v0 with its default 512-step episodes resets too rarely to pay for the 128 service workgroups
+    // (280 -> 275 M), so only the grid variant defers by default.  MEMGYM_MYSTERY_DEFER=0 / 1 forces it off / on.
+    bool defer_paths() const {
+        static const int forced = [] {
+            const char* e = getenv("MEMGYM_MYSTERY_DEFER");
+            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        }();
+        return forced >= 0 ? forced == 1 : P_.grid != 0;
+    }
+    void raster_with_paths(void* obs, hipStream_t s) {
+        const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + PATH_WGS;
+        if (obs_format == MG_OBS_F32_CYX)
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+        else if (obs_format == MG_OBS_BF16_CYX)
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+        else if (obs_format == MG_OBS_F16_CYX)
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+        else
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+        MG_HIP(hipGetLastError());
+    }
     MysteryIO io() {
         MysteryIO o;
         o.core = core_.p;
