@@ -175,6 +175,7 @@ struct MysteryIO {
     MysteryDesc* desc;
     int* err;
     int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
+    uint8_t* queued;  // endless: [N] 1 = this step's frame of the instance is drawn by the workgroup that serves its queue entry
     uint64_t* walls;  // finite: [N] wall cells of the current path generation (bit x*7+y), read by the debug view only
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
 };
@@ -1086,11 +1087,13 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryI
     if (emp_step_a(P, i, s, actions, nx, ny)) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         io.core[i] = s;
         io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i | EMP_Q_SEGMENT;
+        io.queued[i] = 1;
         return;
     }
     MysteryDesc d;
-    if (emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d))
-        io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+    const bool q = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+    if (q) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+    io.queued[i] = q ? 1 : 0;
     io.core[i] = s;
     io.desc[i] = d;
 }
@@ -1100,6 +1103,45 @@ __global__ __launch_bounds__(256) void emp_enqueue_kernel(int n, MysteryIO io, c
     if (i >= n) return;
     if (mask[i]) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
     else io.desc[i].valid = 0;
+}
+
+// One queue entry, served by one converged wave whose lane 0 plays the instance's lane: "append a segment, finish the step"
+// and / or "reset" (three segments), state, stream and frame descriptor written back.
+__device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int entry, const int64_t* seeds, float* reward_out,
+                                uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc* d_out = nullptr) {
+    const bool me = (threadIdx.x & 63) == 0;
+    const int i = entry & (EMP_Q_SEGMENT - 1);
+    float* gti = gt ? gt + 3 * i : nullptr;
+    Pcg g;
+    MysteryCore s;
+    MysteryDesc d;
+    if (me) {
+        if (seeds) g.seed((uint64_t)seeds[i]);
+        else g.load(io.rng, i);
+        s = io.core[i];
+    } else {
+        g.state = g.inc = 0; g.buf = 0; g.has = false;
+        memset(&s, 0, sizeof(s));
+    }
+    int reset_me = 1;
+    if (entry & EMP_Q_SEGMENT) {
+        serve_emp(io, W, i, me ? 1 : 0, s, g);
+        if (me)
+            reset_me = emp_step_b(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
+                                  gti, info, autoreset, d) ? 1 : 0;
+        reset_me = bcast(reset_me, 0);
+    }
+    if (reset_me) {
+        if (me) emp_pre_reset(s);
+        serve_emp(io, W, i, me ? 3 : 0, s, g);
+        if (me) emp_post_reset(P, io, i, s, d, gti);
+    }
+    if (me) {
+        io.core[i] = s;
+        g.store(io.rng, i);
+        io.desc[i] = d;
+        if (d_out) *d_out = d;  // (the fused kernel composes the frame from this copy)
+    }
 }
 
 // all != 0: mg_reset of every instance (entry k = instance k, seeds may be given); otherwise the queue is drained
@@ -1116,36 +1158,8 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
     int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
     while (idx < count) {
         const int entry = all ? idx : bcast(io.queue[idx], 0);
-        const int i = entry & (EMP_Q_SEGMENT - 1);
-        float* gti = gt ? gt + 3 * i : nullptr;
-        Pcg g;
-        MysteryCore s;
-        MysteryDesc d;
+        emp_serve_entry(P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
         if (me) {
-            if (seeds) g.seed((uint64_t)seeds[i]);
-            else g.load(io.rng, i);
-            s = io.core[i];
-        } else {
-            g.state = g.inc = 0; g.buf = 0; g.has = false;
-            memset(&s, 0, sizeof(s));
-        }
-        int reset_me = 1;
-        if (entry & EMP_Q_SEGMENT) {
-            serve_emp(io, W, i, me ? 1 : 0, s, g);
-            if (me)
-                reset_me = emp_step_b(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
-                                      gti, info, autoreset, d) ? 1 : 0;
-            reset_me = bcast(reset_me, 0);
-        }
-        if (reset_me) {
-            if (me) emp_pre_reset(s);
-            serve_emp(io, W, i, me ? 3 : 0, s, g);
-            if (me) emp_post_reset(P, io, i, s, d, gti);
-        }
-        if (me) {
-            io.core[i] = s;
-            g.store(io.rng, i);
-            io.desc[i] = d;
             idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
         }
         idx = bcast(idx, 0);
@@ -1155,6 +1169,80 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
         io.qctr[QC_COUNT] = 0;
         io.qctr[QC_HEAD] = 0;
         io.qctr[QC_LEFT] = 0;
+    }
+}
+
+// mg_step of the endless variant, second launch: raster AND queue service in one.  The first EMP_SVC_WGS workgroups do what
+// emp_serve_kernel does -- one queue entry per wave at a time -- and then draw the frames of the instances they served
+// themselves (from the descriptor their wave just produced, kept in LDS); all other workgroups walk the frames of the
+// instances that were NOT queued (io.queued, written by emp_step_kernel).  The 100 us of dependent path generation that a
+// reset costs no longer stand in front of the raster: they run next to it, on a quarter of the resident workgroups.
+// Measured (32,768 instances, us per step incl. the 26 us of emp_step_kernel; separate launches: 240): 384 / 512 / 768 /
+// 1,024 / 1,536 service workgroups at 7 workgroups per CU (72 VGPRs, the path generator spills) 218 / 217 / 216 / 224 / 234;
+// at 5 per CU (96 VGPRs) 212 / 211 / 215 / 224 / 227; at 4 per CU 210 / 212 / 213 / 219 / 223.
+constexpr int EMP_SVC_WGS = 512;
+template <int FMT>
+__global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
+                                                                  MysteryParams P, MysteryIO io, float* reward_out, uint8_t* done_out,
+                                                                  float* gt, mg_info_buffers info, int autoreset, int svc) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ MysteryDesc sdesc[4];
+    __shared__ int served[4];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = A.tables;
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if (blockIdx.x < svc) {
+        uint8_t* ws = smem + FRAME_BYTES;  // the path workspace lives in the (unused) mask words behind the frame
+        path_ws_init(ws);
+        const PathWS W{ws};
+        const int wv = tid >> 6;
+        const bool me = (tid & 63) == 0;
+        const int count = io.qctr[QC_COUNT];
+        const int waves = svc * 4;
+        int idx = bcast((int)(blockIdx.x * 4 + wv), 0);
+        for (;;) {
+            int inst = -1;
+            if (idx < count) {
+                const int entry = bcast(io.queue[idx], 0);
+                emp_serve_entry(P, io, W, entry, nullptr, reward_out, done_out, gt, info, autoreset, &sdesc[wv]);
+                inst = entry & (EMP_Q_SEGMENT - 1);
+                if (me) idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
+                idx = bcast(idx, 0);
+            }
+            if (me) served[wv] = inst;
+            __syncthreads();
+            bool any = false;
+            for (int w = 0; w < 4; ++w) {
+                const int e = served[w];
+                if (e < 0) continue;
+                any = true;
+                MysteryComposer::compose(&sdesc[w], R);
+                __syncthreads();
+                store_frame<FMT>(smem, obs, e, tid);
+                __syncthreads();
+            }
+            if (!any) break;
+        }
+        if (tid == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == svc - 1) {  // last service workgroup out
+            io.qctr[QC_COUNT] = 0;
+            io.qctr[QC_HEAD] = 0;
+            io.qctr[QC_LEFT] = 0;
+        }
+        return;
+    }
+    const int stride = (int)gridDim.x - svc;
+    for (int env = (int)blockIdx.x - svc; env < n; env += stride) {
+        if (io.queued[env]) continue;  // drawn by the workgroup that serves it
+        const MysteryDesc* d = descs + env;
+        if (MysteryComposer::skip(d)) continue;
+        MysteryComposer::compose(d, R);
+        __syncthreads();
+        store_frame<FMT>(smem, obs, env, tid);
+        __syncthreads();
     }
 }
 
@@ -1184,6 +1272,7 @@ class MysteryFamily : public Family {
         }
         core_.alloc(n);
         walls_.alloc(n);
+        queued_.alloc(n);
         desc_.alloc(n);
         rng_.alloc(n);
         err_.alloc();
@@ -1261,6 +1350,17 @@ class MysteryFamily : public Family {
         prof.begin(0, s);
         if (P_.endless) {
             hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+            if (fuse_serve() && obs_format == MG_OBS_U8_XYC) {  // the queue is served inside the raster launch
+                prof.end(0, s);
+                prof.begin(1, s);
+                const int svc = EMP_SVC_WGS;
+                const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + svc;
+                hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                   P_, io(), reward, done, gt, ib, autoreset, svc);
+                MG_HIP(hipGetLastError());
+                prof.end(1, s);
+                return;
+            }
             hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
                                reward, done, gt, ib, autoreset);
         } else {
@@ -1319,6 +1419,14 @@ class MysteryFamily : public Family {
     // Measured (MysteryPath-Grid, 32,768 instances, 0.5 % of them reset per step): logic 32.7 -> 12.1 us, 231 -> 252 M
     // env-steps/s; MysteryPath-v0 with its default 512-step episodes resets too rarely to pay for the 128 service workgroups
     // (280 -> 275 M), so only the grid variant defers by default.  MEMGYM_MYSTERY_DEFER=0 / 1 forces it off / on.
+    // MEMGYM_EMP_FUSE=0: separate queue-server launch in front of the raster (the round-1 arrangement)
+    bool fuse_serve() const {
+        static const bool on = [] {
+            const char* e = getenv("MEMGYM_EMP_FUSE");
+            return !(e && atoi(e) == 0);
+        }();
+        return on;
+    }
     bool defer_paths() const {
         static const int forced = [] {
             const char* e = getenv("MEMGYM_MYSTERY_DEFER");
@@ -1348,6 +1456,7 @@ class MysteryFamily : public Family {
         o.err = err_.dev;
         o.queue = queue_.p;
         o.walls = P_.endless ? nullptr : walls_.p;
+        o.queued = queued_.p;
         o.qctr = queue_.p + ((n_ + 31) & ~31);
         return o;
     }
@@ -1416,6 +1525,7 @@ class MysteryFamily : public Family {
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
+    DevArray<uint8_t> queued_;  // endless: per-instance flag of emp_step_kernel (see emp_raster_serve_kernel)
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
     RngStore rng_;
