@@ -1144,6 +1144,208 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
     }
 }
 
+// ---- Lane-per-job path generation ---------------------------------------------------------------------------------
+// The wave-cooperative generator above finishes ONE path in ~25-33 us, as a chain of ~10,000 wave-uniform (scalar)
+// instructions; a full reset of 32,768 instances (98,304 paths) keeps every SIMD's scalar issue busy for 1.25 ms.  Here
+// every LANE generates its own path: the same algorithm with the per-node records and the open list in LDS (one column
+// per lane) -- ~105 us per path (~1,100 vector instructions per expansion, one wave per SIMD), 64 paths per wave: a
+// full reset in three rounds of 512 waves.  Used where many paths are due at once and nothing else runs (mg_reset of all
+// instances); a step's few thousand queue entries stay with the cooperative generator, whose latency is lower
+// (profiles/r02_emp.md).
+//   * open list: every node enters it at most once and its f never changes afterwards (the reference's `neighbor.g = g`
+//     typo), so the list is append-only with a 64-bit mask of the positions still in it; "first i >= 1 with f[i] < f[0]"
+//     walks the set bits.
+//   * f = g_cost + sqrt(d2) is compared through an integer key (g_cost << 17) + round(sqrt(d2) * 2^17): over all g_cost
+//     <= 459 and all 27 values of d2 the keys order exactly like the doubles and are equal exactly where those are
+//     (distinct sums differ by >= 2.5e-3; tests/test_path_keys.py checks every pair).
+constexpr int LW_KEY = 0;                          // uint32 key[52][64]: (fkey << 6) | node, by list position; later the path
+constexpr int LW_NODE = LW_KEY + 52 * 64 * 4;      // uint16 rec[49][64]: g_cost | previous_node << 9 (63 = none), by node
+constexpr int LW_HFIX = LW_NODE + 49 * 64 * 2;     // uint32 hfix[80]
+constexpr int LW_BYTES = LW_HFIX + 80 * 4;
+struct LaneWS {
+    uint8_t* base;
+    int lane;
+    __device__ __forceinline__ uint32_t& key(int p) const { return reinterpret_cast<uint32_t*>(base + LW_KEY)[p * 64 + lane]; }
+    __device__ __forceinline__ uint16_t& rec(int n) const { return reinterpret_cast<uint16_t*>(base + LW_NODE)[n * 64 + lane]; }
+    __device__ __forceinline__ uint32_t hfix(int d2) const { return reinterpret_cast<const uint32_t*>(base + LW_HFIX)[d2]; }
+};
+__device__ __forceinline__ void lane_ws_init(uint8_t* smem) {  // all threads of the block
+    for (int d = threadIdx.x; d < 80; d += blockDim.x)
+        reinterpret_cast<uint32_t*>(smem + LW_HFIX)[d] = (uint32_t)__double2ll_rn(sqrt((double)d) * 131072.0);
+    __syncthreads();
+}
+constexpr uint64_t grid_mask(int which) {  // 0: y == 0, 1: y == 6, 2: border
+    uint64_t m = 0;
+    for (int x = 0; x < G; ++x)
+        for (int y = 0; y < G; ++y)
+            if ((which == 0 && y == 0) || (which == 1 && y == G - 1) || (which == 2 && (x == 0 || x == G - 1 || y == 0 || y == G - 1)))
+                m |= 1ull << (x * G + y);
+    return m;
+}
+constexpr uint64_t GM_Y0 = grid_mask(0), GM_Y6 = grid_mask(1), GM_BORDER = grid_mask(2), GM_ALL = (1ull << (G * G)) - 1;
+__device__ __forceinline__ uint64_t cells_around4(uint64_t m) {
+    return (((m << 1) & ~GM_Y0) | ((m >> 1) & ~GM_Y6) | (m << G) | (m >> G)) & GM_ALL;
+}
+__device__ __forceinline__ uint64_t cells_around8(uint64_t m) {  // m itself included
+    const uint64_t v = m | ((m << 1) & ~GM_Y0) | ((m >> 1) & ~GM_Y6);
+    return (v | (v << G) | (v >> G)) & GM_ALL;
+}
+
+// MysteryPath.__init__ (pygame_assets.py:606-724) by one lane.  Returns the path length (-1: none); W.key(k), k < len, is
+// the k-th path node (flat index x*7+y, END first like the reference's list).
+__device__ int lane_path(Pcg& g, const LaneWS& W, int sx, int sy, int ex, int ey, uint64_t& path_mask, uint64_t& wall_out) {
+    uint64_t wall = 0;
+    for (int i = 1; i < G - 2; ++i)
+        for (int j = 1; j < G - 2; ++j)
+            if (g.integers(0, 100) < 33) wall |= 1ull << (i * G + j);
+    const int start = sx * G + sy, end = ex * G + ey;
+    const uint64_t ends = (1ull << start) | (1ull << end);
+    uint64_t outer = GM_BORDER & ~ends & ~cells_around4(ends) & ~cells_around8(wall);
+    int n_outer = __popcll(outer);
+    const int n_iter = g.integers(0, 2) == 0 ? 4 : 8;  // rng.choice([4, 8])
+    for (int it = 0; it < n_iter; ++it) {
+        if (n_outer > 0) {
+            const int k = g.integers(0, n_outer);
+            uint64_t m = outer;
+            for (int q = 0; q < k; ++q) m &= m - 1;
+            const uint64_t bit = m & (~m + 1);
+            wall |= bit;
+            outer &= ~bit;
+            --n_outer;
+        }
+    }
+    wall_out = wall;
+    uint64_t closed = 0, in_open = 1ull << start, live = 1;
+    int n_pos = 1;
+    W.key(0) = (uint32_t)start;  // (only the order of the keys matters: the start is alone in the list when it is taken)
+    W.rec(start) = (uint16_t)(63u << 9);
+    // "first i >= 1 with f[i] < f[0], else 0": while open[0] stays, the positions before the last hit are known not to beat
+    // it (keys never change), so the walk resumes behind the hit; four keys are fetched per round trip to LDS
+    int head = -1, scan = 0;
+    uint32_t khead = 0;
+    for (;;) {
+        if (!live) return -1;
+        const int p0 = __ffsll((unsigned long long)live) - 1;
+        if (p0 != head) {
+            head = p0;
+            khead = W.key(p0);
+            scan = p0 + 1;
+        }
+        const uint32_t k0 = khead >> 6;
+        int w = p0;
+        uint32_t kw = khead;
+        for (int p = scan; p < n_pos && w == p0; p += 4) {
+            const uint32_t a[4] = {W.key(p), W.key(p + 1), W.key(p + 2), W.key(p + 3)};
+#pragma unroll
+            for (int q = 3; q >= 0; --q)  // the lowest qualifying position wins
+                if (p + q < n_pos && ((live >> (p + q)) & 1ull) && (a[q] >> 6) < k0) {
+                    w = p + q;
+                    kw = a[q];
+                }
+        }
+        scan = w != p0 ? w + 1 : n_pos;
+        const int cur = (int)(kw & 63u);
+        if (cur == end) {
+            int len = 0, t = cur;
+            path_mask = 0;
+            for (;;) {
+                path_mask |= 1ull << t;
+                const int pv = W.rec(t) >> 9;
+                W.key(len++) = (uint32_t)t;
+                if (pv == 63) break;
+                t = pv;
+            }
+            return len;
+        }
+        live &= ~(1ull << w);
+        in_open &= ~(1ull << cur);
+        closed |= 1ull << cur;
+        const int gcur = W.rec(cur) & 511;
+        const int cx = cur / G, cy = cur - cx * G;
+        const uint64_t blocked = closed | wall;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // Node.add_neighbors order x+1, x-1, y+1, y-1
+            const int nb = k == 0 ? (cx < G - 1 ? cur + G : -1) : k == 1 ? (cx > 0 ? cur - G : -1) : k == 2 ? (cy < G - 1 ? cur + 1 : -1) : (cy > 0 ? cur - 1 : -1);
+            if (nb < 0 || ((blocked >> nb) & 1ull)) continue;
+            const int cost = gcur + 1 + (int)(g.next32() >> 29);  // integers(1, 9): span 8, never rejects
+            if ((in_open >> nb) & 1ull) {
+                const uint16_t r = W.rec(nb);
+                if (cost < (int)(r & 511)) W.rec(nb) = (uint16_t)((r & 511) | (cur << 9));  // `neighbor.g = g` typo: g_cost stays
+            } else {
+                W.rec(nb) = (uint16_t)(cost | (cur << 9));
+                const int ax = nb / G - ex, ay = nb % G - ey;
+                W.key(n_pos) = ((((uint32_t)cost << 17) + W.hfix(ax * ax + ay * ay)) << 6) | (uint32_t)nb;
+                live |= 1ull << n_pos;
+                ++n_pos;
+                in_open |= 1ull << nb;
+            }
+        }
+    }
+}
+
+// EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604) by one lane
+__device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, MysteryCore& s, Pcg& g) {
+    const int sy = s.have_start ? (int)s.end_y : g.integers(0, G);
+    const int ey = g.integers(0, G);
+    uint64_t pm = 0, wl = 0;
+    int len = lane_path(g, W, 0, sy, G - 1, ey, pm, wl);
+    if (len < 0) {
+        raise_error(io.err, 2);
+        len = 0;
+    }
+    if (s.num_seg < MAX_SEG) {  // byte 0 = node count, then the path START first, then the transition node (see serve_emp)
+        uint32_t* dst = reinterpret_cast<uint32_t*>(seg_ptr(io, i, s.num_seg));
+        for (int j = 0; j < SEG_STRIDE / 4; ++j) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int p = 4 * j + b;
+                uint32_t v = 0;
+                if (p == 0) v = (uint32_t)(len + 1);
+                else if (p <= len) {
+                    const int nd = (int)W.key(len - p);
+                    v = (uint32_t)((nd / G) | ((nd % G) << 3));
+                } else if (p == len + 1) v = (uint32_t)(7 | (ey << 3));
+                word |= v << (8 * b);
+            }
+            dst[j] = word;
+        }
+        s.num_seg++;
+    } else {
+        raise_error(io.err, 4);
+    }
+    s.have_start = 1;
+    s.end_y = (int8_t)ey;
+}
+
+// mg_reset of every Endless-MysteryPath instance: one LANE per instance (emp_serve_kernel: one wave per instance)
+__global__ __launch_bounds__(64) void emp_reset_lanes_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds, float* gt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    lane_ws_init(smem);
+    const LaneWS W{smem, (int)threadIdx.x};
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool active = i < P.n;
+    Pcg g;
+    MysteryCore s;
+    g.state = g.inc = 0; g.buf = 0; g.has = false;
+    memset(&s, 0, sizeof(s));
+    if (active) {
+        s = io.core[i];
+        if (seeds) g.seed((uint64_t)seeds[i]);
+        else g.load(io.rng, i);
+        emp_pre_reset(s);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (active) lane_segment(io, W, i, s, g);
+    if (active) {
+        MysteryDesc d;
+        emp_post_reset(P, io, i, s, d, gt ? gt + 3 * i : nullptr);
+        io.core[i] = s;
+        g.store(io.rng, i);
+        io.desc[i] = d;
+    }
+}
+
 // all != 0: mg_reset of every instance (entry k = instance k, seeds may be given); otherwise the queue is drained
 __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds, int all, float* reward_out,
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
@@ -1332,9 +1534,16 @@ class MysteryFamily : public Family {
         if (P_.endless) {
             mg_info_buffers none;
             memset(&none, 0, sizeof(none));
-            if (mask) hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
-            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(!mask)), dim3(256), WS_BYTES, s, P_, io(), seeds, mask ? 0 : 1,
-                               (float*)nullptr, (uint8_t*)nullptr, gt, none, 0);
+            if (mask) {
+                hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
+                hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,
+                                   (uint8_t*)nullptr, gt, none, 0);
+            } else if (n_ >= 1024 && reset_by_lanes()) {  // many paths at once: one lane per instance
+                hipLaunchKernelGGL(emp_reset_lanes_kernel, dim3((n_ + 63) / 64), dim3(64), LW_BYTES, s, P_, io(), seeds, gt);
+            } else {
+                hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(true)), dim3(256), WS_BYTES, s, P_, io(), seeds, 1, (float*)nullptr,
+                                   (uint8_t*)nullptr, gt, none, 0);
+            }
         } else {
             hipLaunchKernelGGL(mystery_reset_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
         }
@@ -1423,6 +1632,14 @@ class MysteryFamily : public Family {
     bool fuse_serve() const {
         static const bool on = [] {
             const char* e = getenv("MEMGYM_EMP_FUSE");
+            return !(e && atoi(e) == 0);
+        }();
+        return on;
+    }
+    // MEMGYM_EMP_RESET_LANES=0: a full reset through the queue server, one wave per instance (round 1)
+    bool reset_by_lanes() const {
+        static const bool on = [] {
+            const char* e = getenv("MEMGYM_EMP_RESET_LANES");
             return !(e && atoi(e) == 0);
         }();
         return on;
