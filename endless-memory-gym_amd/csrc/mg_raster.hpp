@@ -159,6 +159,7 @@ __device__ __forceinline__ void stamp_apply_lit(const RasterCtx& R, const StampR
 __device__ __forceinline__ uint32_t pack_hole(int x, int y, int r) {
     return (uint32_t)(x + 128) | ((uint32_t)(y + 128) << 9) | ((uint32_t)r << 18);
 }
+__device__ __forceinline__ int hole_radius(uint32_t hv) { return (int)((hv >> 18) & 0x1FFFu); }  // bit 31: the disc has a white border
 
 // holes[i] = pack_hole(x, y, r): filled discs (pygame's even-diameter midpoint disc) that stay lit.
 // hole_mask: union of the discs as an 84x84 bit mask in LDS; tasks = (hole, column), 4 holes x 64 columns per round,
@@ -172,7 +173,7 @@ __device__ __forceinline__ void hole_mask(const RasterCtx& R, cptr<uint32_t> hol
         int hI = base + sub;
         if (hI >= nholes) continue;
         const uint32_t hv = holes[hI];
-        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
+        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
         for (int col = col0; col < 2 * r; col += 64) {
             int X = hx - r + col;
             int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
@@ -200,7 +201,7 @@ struct HoleRegs8 {
 };
 __device__ __forceinline__ bool holes_small(cptr<uint32_t> holes, int nholes) {
     bool ok = nholes <= 16;
-    for (int h = 0; h < nholes; ++h) ok = ok && (int)(holes[h] >> 18) <= 16;
+    for (int h = 0; h < nholes; ++h) ok = ok && hole_radius(holes[h]) <= 16;
     return ok;
 }
 __device__ __forceinline__ void hole_fetch8(const RasterCtx& R, cptr<uint32_t> holes, int nholes, HoleRegs8& H) {
@@ -211,7 +212,7 @@ __device__ __forceinline__ void hole_fetch8(const RasterCtx& R, cptr<uint32_t> h
         int hI = rnd * 8 + sub;
         if (hI < nholes) {
             const uint32_t hv = holes[hI];
-            const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = (int)(hv >> 18);
+            const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
             if (col < 2 * r) {
                 int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
                 int X = hx - r + col, y0 = hy + lo, y1 = hy + hi;

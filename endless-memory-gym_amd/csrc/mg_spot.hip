@@ -36,6 +36,8 @@ struct SpotParams {
     int endless, n;
     int max_steps, steps_per_coin, initial_spawns, spawn_interval, interval0, num_spawns;
     int visual_feedback, dim_duration, dim_step, light_threshold;
+    int black_background, hide_chessboard;  // repaint the instance's background surfaces for good (see BG_MODE_SHIFT)
+    int ordered_holes;              // a spotlight with a border has been possible: hole words in LIST order, border composer
     int layer_flags;                // LAYER_EXIT_ABOVE (exit_visible) | LAYER_AGENT_TOP (agent_visible), OR-ed into SpotDesc::coin_above
     int coin_enabled, coin_show_duration, coins_visible, sample_agent_position, show_last_action, show_last_positive_reward;
     int r_lo, r_hi;                 // radius = integers(r_lo, r_hi)
@@ -60,7 +62,9 @@ struct __attribute__((aligned(16))) SpotCore {
     int32_t num_coins, ep_len;
     double health, ep_sum;
     uint64_t order;  // spotlight list: nibble k = slot of the k-th element
-    uint32_t free_mask, pad;  // pad: debug view, bit 31 = a sprite has been shown, 18..16 sprite, 15..8 y + 128, 7..0 x + 128
+    // pad: debug view, bit 31 = a sprite has been shown, 18..16 sprite, 15..8 y + 128, 7..0 x + 128;
+    //      bits 21..20 / 23..22 = what the blue / red background surface of this instance looks like (BG_CHESS / WHITE / BLACK)
+    uint32_t free_mask, pad;
 };
 static_assert(sizeof(SpotCore) == 80, "SpotCore must be 80 bytes");
 
@@ -79,9 +83,103 @@ struct __attribute__((aligned(16))) SpotDesc {
 static_assert(sizeof(SpotDesc) == 160, "SpotDesc must be 160 bytes");
 
 constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
+// hide_chessboard / black_background paint over the two background surfaces an environment object keeps for its lifetime
+// (searing_spotlights.py:349-351, 234-235, 420-421; endless :313-315, 223-224, 376-377): per instance, sticky across
+// episodes and option changes.  Templates: 0 blue board, 1 red board, 2 white, 3 black.
+constexpr uint32_t BG_CHESS = 0, BG_WHITE = 1, BG_BLACK = 2, BG_MODE_SHIFT = 20, BG_MODE_MASK = 0xFu << BG_MODE_SHIFT;
+__device__ __forceinline__ uint32_t bg_mode(uint32_t pad, int red) { return (pad >> (BG_MODE_SHIFT + 2 * red)) & 3u; }
+__device__ __forceinline__ uint32_t bg_set(uint32_t pad, int red, uint32_t m) {
+    return (pad & ~(3u << (BG_MODE_SHIFT + 2 * red))) | (m << (BG_MODE_SHIFT + 2 * red));
+}
+__device__ __forceinline__ uint8_t bg_template(uint32_t pad, int red) {
+    const uint32_t m = bg_mode(pad, red);
+    return (uint8_t)(m == BG_CHESS ? (uint32_t)red : 1u + m);
+}
 constexpr int BAR_H = 4;  // top bar height: int(16 * SCALE)
 
-struct SpotComposer {
+// ---- spotlights with a border (Spotlight.draw: filled disc, then pygame's 1-px circle in white, pygame_assets.py:110-113) ----
+// The spotlight surface ends up with three kinds of pixels: black (the dark layer), the colour key (a hole) and white (a
+// border pixel, blended over what lies below with the layer's alpha).  Spotlights are drawn in list order, so a pixel shows
+// a border iff the LAST disc covering it has one and the pixel lies on it.  One lane per column walks the hole words in
+// order: a disc clears the ring bits of its column span, a border sets its own (draw_circle_bresenham_thin: the end points
+// of the spans draw_circle_filled walks, for every x step).  Only the border composer does this.
+__device__ __forceinline__ void ring_mask(const RasterCtx& R, cptr<uint32_t> holes, int nholes, uint32_t* ring) {
+    if (R.tid >= SCREEN) return;
+    const int X = R.tid;
+    uint32_t rg[MASK_WORDS] = {0u, 0u, 0u};
+    for (int h = 0; h < nholes; ++h) {
+        const uint32_t hv = holes[h];
+        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
+        const int col = X - (hx - r);
+        if (col < 0 || col >= 2 * r) continue;
+        const int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
+        int y0 = hy + lo, y1 = hy + hi;
+        y0 = y0 < 0 ? 0 : y0;
+        y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) {
+            int a0 = y0 - 32 * w, a1 = y1 - 32 * w;
+            a0 = a0 < 0 ? 0 : a0;
+            a1 = a1 > 31 ? 31 : a1;
+            if (a0 <= a1) rg[w] &= ~((a1 - a0 == 31) ? 0xFFFFFFFFu : (((1u << (a1 - a0 + 1)) - 1u) << a0));
+        }
+        if (!(hv >> 31)) continue;
+        auto put = [&](int px, int py) {
+            if (px == X && (unsigned)py < (unsigned)SCREEN) {
+                const uint32_t bit = 1u << (py & 31);
+#pragma unroll
+                for (int w = 0; w < MASK_WORDS; ++w) rg[w] |= (py >> 5) == w ? bit : 0u;
+            }
+        };
+        int f = 1 - r, ddx = 0, ddy = -2 * r, x = 0, y = r;
+        while (x < y) {
+            if (f >= 0) {
+                --y;
+                ddy += 2;
+                f += ddy;
+            }
+            ++x;
+            ddx += 2;
+            f += ddx + 1;
+            put(hx + x - 1, hy + y - 1);
+            put(hx - x, hy + y - 1);
+            put(hx + x - 1, hy - y);
+            put(hx - x, hy - y);
+            put(hx + y - 1, hy + x - 1);
+            put(hx + y - 1, hy - x);
+            put(hx - y, hy + x - 1);
+            put(hx - y, hy - x);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < MASK_WORDS; ++w) ring[X * MASK_WORDS + w] = rg[w];
+}
+// the border pixels over everything drawn so far: d += (255 - d) * A / 255 (SDL ALPHA_BLEND_RGB, source white)
+__device__ __forceinline__ void ring_apply(const RasterCtx& R, const uint32_t* ring, uint32_t alpha) {
+    if (R.tid >= SCREEN * MASK_WORDS) return;
+    const int X = R.tid / MASK_WORDS, w = R.tid - X * MASK_WORDS;
+    uint32_t bits = ring[R.tid];
+    while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        uint8_t* p = R.frame + (X * SCREEN + 32 * w + b) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = (uint8_t)(p[c] + ((255u - p[c]) * alpha) / 255u);
+    }
+}
+
+template <bool BORDER>
+__device__ __forceinline__ uint32_t* ring_words() {  // LDS of the border composers only
+    if constexpr (BORDER) {
+        __shared__ uint32_t ring[SCREEN * MASK_WORDS];
+        return ring;
+    } else {
+        return nullptr;
+    }
+}
+
+template <bool BORDER>
+struct SpotComposerT {
     typedef SpotDesc Desc;
     static __device__ __forceinline__ bool skip(cptr<Desc> dp) { return dp->valid == 0; }
     // top bar (rows y < BAR_H of every column); priority reward bar > action rects > red > green > base.
@@ -97,6 +195,19 @@ struct SpotComposer {
     }
     static __device__ __forceinline__ bool bar_covers(const Desc MG_CONST_AS& d, int x) {
         return d.c_base != 0xFF || x < 2 * d.quarter || d.c_act0 != 0xFF || (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w);
+    }
+    static __device__ __forceinline__ void bar_columns(const Desc MG_CONST_AS& d, cptr<AtlasTables> T, const RasterCtx& R) {
+        static_assert(BAR_H == 4, "one bar column = 4 pixels = 3 dwords");
+        if (R.tid < SCREEN) {
+            uint32_t c = 0u;
+            if (bar_colour(d, T, R.tid, &c)) {
+                const uint32_t r = c & 0xFFu, g = (c >> 8) & 0xFFu, b = (c >> 16) & 0xFFu;
+                uint32_t* p = reinterpret_cast<uint32_t*>(R.frame) + R.tid * (COL_BYTES / 4);
+                p[0] = r | (g << 8) | (b << 16) | (r << 24);
+                p[1] = g | (b << 8) | (r << 16) | (g << 24);
+                p[2] = b | (r << 8) | (g << 16) | (b << 24);
+            }
+        }
     }
     // Order of the reference's _draw_surfaces (endless_searing_spotlights.py:464-479, searing_spotlights.py:524-545):
     // board, coins (unless drawn above), exit, agent, spotlight layer, coins above, top bar.  The spotlight layer is
@@ -124,14 +235,41 @@ struct SpotComposer {
         const cptr<AtlasTables> T = R.T;
         const uint32_t alpha = d.alpha;
         const StampRegs<1>&agent = P.agent, &coin = P.coin, &exitp = P.exitp;
+        uint32_t* const ring = ring_words<BORDER>();
         if (alpha) {  // the hole mask is zero on entry (recycle())
             if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
             else hole_mask(R, d.holes, d.n_holes);  // radii beyond the reference's range: span table read in place
+            if constexpr (BORDER) ring_mask(R, d.holes, d.n_holes, ring);
             __syncthreads();
         }
         templ_apply_dark(R, P.bg, alpha);
         __syncthreads();
         auto under_bar = [&](int X, int Y) { return Y < BAR_H && bar_covers(d, X); };
+        if constexpr (BORDER) {  // the same layers, with the border pixels blended in where the spotlight layer sits
+            const uint32_t lfb = d.coin_above;
+            const bool exit_b = d.exit_stamp != 0xFF;
+            if (!(lfb & LAYER_COIN_ABOVE))
+                for (int k = 0; k < d.n_coins; ++k)
+                    stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, alpha, never_skip);
+            if (exit_b && !(lfb & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
+            __syncthreads();
+            if (!(lfb & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, never_skip);
+            __syncthreads();
+            if (alpha) {
+                ring_apply(R, ring, alpha);
+                __syncthreads();
+            }
+            if (lfb & LAYER_COIN_ABOVE)
+                for (int k = 0; k < d.n_coins; ++k)
+                    stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
+            if (exit_b && (lfb & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, 0u, under_bar);
+            bar_columns(d, T, R);
+            if (lfb & LAYER_AGENT_TOP) {
+                __syncthreads();
+                stamp_apply_lit<1>(R, agent, d.sx, d.sy, 0u, never_skip);
+            }
+            return;
+        }
         // coins keep their distance from each other and from the exit (sampler block radius): no overlap among them.
         // coins_visible / exit_visible / agent_visible move a layer from below the dark layer to above it (the agent:
         // to the very top, over the bar -- the reference's list.insert index is past the end of its surface list).
@@ -152,60 +290,55 @@ struct SpotComposer {
                     stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
             if (exit_here && (lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, 0u, under_bar);
         }
-        static_assert(BAR_H == 4, "one bar column = 4 pixels = 3 dwords");
-        if (R.tid < SCREEN) {
-            uint32_t c = 0u;
-            if (bar_colour(d, T, R.tid, &c)) {
-                const uint32_t r = c & 0xFFu, g = (c >> 8) & 0xFFu, b = (c >> 16) & 0xFFu;
-                uint32_t* p = reinterpret_cast<uint32_t*>(R.frame) + R.tid * (COL_BYTES / 4);
-                p[0] = r | (g << 8) | (b << 16) | (r << 24);
-                p[1] = g | (b << 8) | (r << 16) | (g << 24);
-                p[2] = b | (r << 8) | (g << 16) | (b << 24);
-            }
-        }
+        bar_columns(d, T, R);
         if (lf & LAYER_AGENT_TOP) {
             __syncthreads();
             stamp_apply_lit<1>(R, agent, d.sx, d.sy, 0u, never_skip);
         }
     }
 };
+typedef SpotComposerT<false> SpotComposer;
+typedef SpotComposerT<true> SpotBorderComposer;  // black_background has been on: spotlights may have a border
 
 // _build_debug_surface (searing_spotlights.py:157-185, endless_searing_spotlights.py:150-177): board, spotlight layer, then
 // exit, coins and agent OVER it (undarkened), top bar last.  Same descriptor, prefetch and hole mask as the observation.
-struct SpotDebugComposer {
+template <bool BORDER>
+struct SpotDebugComposerT {
     typedef SpotDesc Desc;
-    typedef SpotComposer::Pre Pre;
+    typedef SpotComposerT<false> Obs;
+    typedef Obs::Pre Pre;
     static __device__ __forceinline__ bool skip(cptr<Desc>) { return false; }
-    static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) { SpotComposer::prefetch(dp, R, P); }
+    static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) { Obs::prefetch(dp, R, P); }
     static __device__ __forceinline__ void recycle(const RasterCtx& R) { zero_mask(R); }
     static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
         const Desc MG_CONST_AS& d = *dp;
         const uint32_t alpha = d.alpha;
+        uint32_t* const ring = ring_words<BORDER>();
         if (alpha) {
             if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
             else hole_mask(R, d.holes, d.n_holes);
+            if constexpr (BORDER) ring_mask(R, d.holes, d.n_holes, ring);
             __syncthreads();
         }
         templ_apply_dark(R, P.bg, alpha);
         __syncthreads();
-        auto under_bar = [&](int X, int Y) { return Y < BAR_H && SpotComposer::bar_covers(d, X); };
+        if constexpr (BORDER) {
+            if (alpha) {
+                ring_apply(R, ring, alpha);
+                __syncthreads();
+            }
+        }
+        auto under_bar = [&](int X, int Y) { return Y < BAR_H && Obs::bar_covers(d, X); };
         if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, P.exitp, d.exit_x, d.exit_y, 0u, under_bar);
         for (int k = 0; k < d.n_coins; ++k)
             stamp_apply_lit<1>(R, P.coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
         __syncthreads();
         stamp_apply_lit<1>(R, P.agent, d.sx, d.sy, 0u, under_bar);
-        if (R.tid < SCREEN) {
-            uint32_t c = 0u;
-            if (SpotComposer::bar_colour(d, R.T, R.tid, &c)) {
-                const uint32_t r = c & 0xFFu, g = (c >> 8) & 0xFFu, b = (c >> 16) & 0xFFu;
-                uint32_t* p = reinterpret_cast<uint32_t*>(R.frame) + R.tid * (COL_BYTES / 4);
-                p[0] = r | (g << 8) | (b << 16) | (r << 24);
-                p[1] = g | (b << 8) | (r << 16) | (g << 24);
-                p[2] = b | (r << 8) | (g << 16) | (b << 24);
-            }
-        }
+        Obs::bar_columns(d, R.T, R);
     }
 };
+typedef SpotDebugComposerT<false> SpotDebugComposer;
+typedef SpotDebugComposerT<true> SpotBorderDebugComposer;
 
 struct SpotIO {
     SpotCore* core;
@@ -347,7 +480,7 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, S
     if (slot != ls) return;
     size_t k = (size_t)i * SLOTS + slot;
     double R = P.half_diag + (double)radius, c = SCREEN / 2;
-    io.sp_r[k] = (uint8_t)radius;
+    io.sp_r[k] = (uint8_t)(radius | (P.black_background ? 0x80 : 0));  // bit 7: Spotlight.has_border
     io.sp_done[k] = 0;
     io.sp_t[k] = 0.0;
     io.sp_speed[k] = speed;
@@ -459,12 +592,14 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         s.exit_y = (int16_t)ey;
     }
     s.bg_red = 0;
+    if (P.hide_chessboard) s.pad = bg_set(bg_set(s.pad, 0, BG_WHITE), 1, BG_WHITE);  // (the reference does this first thing: no draw depends on it)
+    if (P.black_background) s.pad = bg_set(s.pad, 0, BG_BLACK);
 
     // reset frame: blue board, sprite index 0 (not the sampled rotation), dark layer at the reset alpha with the hole
     // pattern the previous frame left, coin(s) shown above the dark layer while coin_t < coin_show_duration
     memset(&d, 0, sizeof(d));
     d.valid = 1;
-    d.bg = 0;
+    d.bg = bg_template(s.pad, 0);
     d.sprite = 0;
     d.sx = (int16_t)(ax - P.sprite_half);
     d.sy = (int16_t)(ay - P.sprite_half);
@@ -565,7 +700,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     const size_t k = (size_t)i * SLOTS + ls;
     double p_t = io.sp_t[k], p_speed = io.sp_speed[k];
     double p_sx = io.sp_sx[k], p_sy = io.sp_sy[k], p_tx = io.sp_tx[k], p_ty = io.sp_ty[k], p_ox = io.sp_ox[k], p_oy = io.sp_oy[k];
-    int p_r = io.sp_r[k];
+    int p_r = io.sp_r[k];  // bit 7: has_border
     bool p_done = io.sp_done[k] != 0;
     const uint32_t free_before = s.free_mask;
 
@@ -646,9 +781,17 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         double t = p_t;
         double lx = p_tx * (1 - t) + p_ox * t, ly = p_ty * (1 - t) + p_oy * t;
         double cx = p_sx * (1 - t) + lx * t, cy = p_sy * (1 - t) + ly * t;
-        int radius = p_r;
+        const int radius = p_r & 127;
         int rank = __popc(processed & ((1u << ls) - 1u));
-        io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius);
+        if (P.ordered_holes) {  // a border is drawn over the discs before it and under the discs after it: list order
+            rank = 0;
+            for (int pos = 0; pos < (int)s.n_spots; ++pos) {
+                const int slot = (int)((s.order >> (4 * pos)) & 15u);
+                if (slot == ls) break;
+                rank += (int)((processed >> slot) & 1u);
+            }
+        }
+        io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius) | ((uint32_t)(p_r >> 7) << 31);
         t += p_speed;
         if (t >= 1.0) {
             t = 1.0;
@@ -669,6 +812,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         s.bg_red = 0;
         r += P.r_outside;
     }
+    if (P.black_background) s.pad = bg_set(s.pad, s.bg_red, BG_BLACK);  // bg.fill(0): that surface stays black
     if (s.health <= 0) {
         spot_done = true;
         r += P.r_death;
@@ -775,11 +919,11 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
 
     // debug view only: the (rotated_agent_surface, rotated_agent_rect) pair of this step -- a reset leaves it alone, and the
     // reference's debug render shows that stale pair until the first step of the next episode
-    s.pad = 0x80000000u | ((uint32_t)s.rot8 << 16) | (uint32_t)((ax + 128) & 0xFF) | ((uint32_t)((ay + 128) & 0xFF) << 8);
+    s.pad = (s.pad & BG_MODE_MASK) | 0x80000000u | ((uint32_t)s.rot8 << 16) | (uint32_t)((ax + 128) & 0xFF) | ((uint32_t)((ay + 128) & 0xFF) << 8);
     if (__builtin_expect(done && autoreset, 0)) {  // cold: keep the reset code out of the hot instruction stream
         spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh);
     } else {
-        d.bg = s.bg_red;
+        d.bg = bg_template(s.pad, s.bg_red);
         d.sprite = s.rot8;
         d.sx = (int16_t)(ax - P.sprite_half);
         d.sy = (int16_t)(ay - P.sprite_half);
@@ -872,6 +1016,7 @@ class SpotFamily : public Family {
         for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) a->alloc((size_t)SLOTS * n);
         sp_r_.alloc((size_t)SLOTS * n);
         sp_done_.alloc((size_t)SLOTS * n);
+        flags_.alloc(4);
         coins_.alloc((size_t)MAX_COINS * n);
         desc_.alloc(n);
         rng_.alloc(n);
@@ -917,7 +1062,15 @@ class SpotFamily : public Family {
         else if (key == "spot_max_speed") P_.speed_hi = v[0];
         else if (key == "spot_damage") P_.damage = v[0];
         else if (key == "visual_feedback") B(P_.visual_feedback);
-        else if (key == "black_background" || key == "hide_chessboard") must_be(v[0] == 0.0);
+        else if (key == "black_background") {
+            B(P_.black_background);
+            if (P_.black_background && !P_.ordered_holes) {  // from now on spotlights may carry a border (sticky, kept in the state)
+                P_.ordered_holes = 1;
+                const int one = 1;
+                MG_HIP(hipMemcpy(flags_.p, &one, sizeof(int), hipMemcpyHostToDevice));
+            }
+        }
+        else if (key == "hide_chessboard") B(P_.hide_chessboard);
         else if (key == "light_dim_off_duration") { I(dim_duration_); dirty_ = true; }
         else if (key == "light_threshold") I(P_.light_threshold);
         else if (key == "coin_scale") { coin_scale_ = v[0]; dirty_ = true; }
@@ -1003,6 +1156,7 @@ class SpotFamily : public Family {
         std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {coins_.p, coins_.bytes()}, {sp_r_.p, sp_r_.bytes()},
                                                   {sp_done_.p, sp_done_.bytes()}};
         for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) v.push_back({a->p, a->bytes()});
+        v.push_back({flags_.p, flags_.bytes()});
         rng_.blobs(v);
         return v;
     }
@@ -1069,14 +1223,12 @@ class SpotFamily : public Family {
     }
 
     void raster_only(void* obs, const uint8_t* only, hipStream_t s) override {
-        launch_raster<SpotComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
+        if (P_.ordered_holes) launch_raster<SpotBorderComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
+        else launch_raster<SpotComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
         MG_HIP(hipGetLastError());
     }
 
-    void raster(void* obs, hipStream_t s) {
-        launch_raster<SpotComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s);
-        MG_HIP(hipGetLastError());
-    }
+    void raster(void* obs, hipStream_t s) { raster_only(obs, nullptr, s); }
 
     int n_;
     SpotParams P_;
@@ -1086,7 +1238,12 @@ class SpotFamily : public Family {
     bool dirty_ = true, seeded_ = false;
 
    public:
-    void on_state_loaded() override { seeded_ = true; }
+    void on_state_loaded() override {
+        seeded_ = true;
+        int f = 0;
+        MG_HIP(hipMemcpy(&f, flags_.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (f) P_.ordered_holes = 1;
+    }
     void raster_debug(void* frames, hipStream_t s) override;
 
    private:
@@ -1094,6 +1251,7 @@ class SpotFamily : public Family {
     DevArray<SpotCore> core_;
     DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;
     DevArray<uint8_t> sp_r_, sp_done_;
+    DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)
     DevArray<uint32_t> coins_;
     DevArray<SpotDesc> desc_;
     ErrorWord err_;
@@ -1105,7 +1263,8 @@ void SpotFamily::raster_debug(void* frames, hipStream_t s) {
     DevArray<SpotDesc> dbg;
     dbg.alloc(n_, false);
     hipLaunchKernelGGL(spot_debug_desc_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
-    launch_raster<SpotDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+    if (P_.ordered_holes) launch_raster<SpotBorderDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+    else launch_raster<SpotDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
     MG_HIP(hipGetLastError());
     MG_HIP(hipStreamSynchronize(s));  // dbg is released on return
 }

@@ -308,11 +308,12 @@ inline Stamp build_coin(double coin_scale) {
     return s;
 }
 
-// Chessboard backgrounds (pygame_assets.py:222-239) as frame templates [x][y][c]: 0 = white/blue, 1 = white/red.
+// Chessboard backgrounds (pygame_assets.py:222-239) as frame templates [x][y][c]: 0 = white/blue, 1 = white/red; then what
+// hide_chessboard / black_background leave of them: 2 = all white, 3 = all black.
 inline std::vector<uint8_t> build_chessboards(double scale, int screen) {
     int ts = (int)(50 * scale);
     size_t frame = (size_t)screen * screen * 3;
-    std::vector<uint8_t> out(2 * frame, 0);
+    std::vector<uint8_t> out(4 * frame, 0);
     for (int t = 0; t < 2; ++t)
         for (int x = 0; x < screen; ++x)
             for (int y = 0; y < screen; ++y) {
@@ -322,6 +323,7 @@ inline std::vector<uint8_t> build_chessboards(double scale, int screen) {
                 p[1] = white ? 255 : 0;
                 p[2] = white ? 255 : (t == 0 ? 255 : 0);
             }
+    std::fill(out.begin() + 2 * frame, out.begin() + 3 * frame, (uint8_t)255);
     return out;
 }
 

@@ -96,6 +96,35 @@ static inline void mgo_circle_filled(mgo_surf* s, uint32_t c, int x0, int y0, in
     }
 }
 
+/* pygame 2.4.0 draw.c draw_circle_bresenham_thin (width == 1): the end points of the spans draw_circle_filled walks, for
+ * every x step.  Only reachable through Spotlight.draw's border (black_background = True, pygame_assets.py:112-113); no
+ * recording or fixture of the reference shows such a frame: PARITY UNPINNED for this routine (restated from the
+ * published pygame source). */
+static inline void mgo_put(mgo_surf* s, uint32_t c, int x, int y) {
+    if (x >= 0 && x < s->w && y >= 0 && y < s->h) s->px[y * s->w + x] = c;
+}
+static inline void mgo_circle_thin(mgo_surf* s, uint32_t c, int x0, int y0, int radius) {
+    int f = 1 - radius, ddx = 0, ddy = -2 * radius, x = 0, y = radius;
+    while (x < y) {
+        if (f >= 0) {
+            y--;
+            ddy += 2;
+            f += ddy;
+        }
+        x++;
+        ddx += 2;
+        f += ddx + 1;
+        mgo_put(s, c, x0 + x - 1, y0 + y - 1);
+        mgo_put(s, c, x0 - x, y0 + y - 1);
+        mgo_put(s, c, x0 + x - 1, y0 - y);
+        mgo_put(s, c, x0 - x, y0 - y);
+        mgo_put(s, c, x0 + y - 1, y0 + x - 1);
+        mgo_put(s, c, x0 + y - 1, y0 - x);
+        mgo_put(s, c, x0 - y, y0 + x - 1);
+        mgo_put(s, c, x0 - y, y0 - x);
+    }
+}
+
 /* pygame draw.c draw_circle_bresenham (thick ring, 1 < thickness < radius) */
 static inline void mgo_circle_thick(mgo_surf* s, uint32_t c, int x0, int y0, int radius, int thickness) {
     long long x = 0, y = radius, r2 = (long long)radius * radius, D = 2 * r2;
@@ -209,8 +238,7 @@ static inline void mgo_draw_circle(mgo_surf* s, uint32_t c, int x0, int y0, int 
     if (width == 0 || width == radius) {
         mgo_circle_filled(s, c, x0, y0, radius);
     } else if (width == 1) {
-        /* draw_circle_bresenham_thin -- not reachable with the reference's parameters at SCALE .25/1.0 */
-        mgo_circle_thick(s, c, x0, y0, radius, 1);
+        mgo_circle_thin(s, c, x0, y0, radius);
     } else {
         mgo_circle_thick(s, c, x0, y0, radius, width);
     }

@@ -9,8 +9,12 @@
  * get_tiled_background_surface :222-239 of memory_gym/pygame_assets.py.
  * Pinned by tests/golden/logic_{Endless_,}SearingSpotlights_v0.npz (logic) and docs/assets/ess_0.gif (pixels,
  * SCALE 1.0).  Exit's rounded rectangle (finite variant only) has NO reference fixture: parity unpinned for that stamp.
- * Options that permanently mutate shared surfaces in the reference (hide_chessboard, black_background)
- * are rejected.
+ * hide_chessboard / black_background repaint the two background surfaces an environment object keeps for its lifetime
+ * (searing_spotlights.py:349-351, 234-235, 420-421; endless :313-315, 223-224, 376-377), so they stick to the INSTANCE
+ * across episodes and option changes; black_background also gives every spotlight spawned under it a white 1-px border
+ * (pygame_assets.py:62, 112-113).  Logic under these options is pinned by tests/golden/fuzz_*.npz; their pixels have no
+ * reference artefact (no recording uses them, pygame is absent here): PARITY UNPINNED for the border ring
+ * (mgo_raster.h: mgo_circle_thin) -- the fills and the blend are the routines the recordings do pin.
  */
 #include "mgo_env.h"
 
@@ -20,7 +24,7 @@
 
 typedef struct {
     double radius, speed, t;
-    int done;
+    int done, has_border;
     double spawn_x, spawn_y, target_x, target_y, offset_x, offset_y, cur_x, cur_y;
 } spot_t;
 
@@ -30,7 +34,7 @@ typedef struct {
     int max_steps, steps_per_coin, initial_spawns, spawn_interval, num_spawns;
     double initial_spawn_interval, spawn_interval_threshold, spawn_interval_decay;
     double spot_min_radius, spot_max_radius, spot_min_speed, spot_max_speed, spot_damage;
-    int visual_feedback, light_dim_off_duration, light_threshold;
+    int visual_feedback, light_dim_off_duration, light_threshold, black_background, hide_chessboard;
     int coin_enabled, coin_show_duration, coins_visible, use_exit, exit_visible, agent_visible, sample_agent_position;
     int show_last_action, show_last_positive_reward;
     double num_coins_list[SP_MAXLIST];
@@ -112,6 +116,7 @@ static void sp_new_spot(mgo_env* e, sp_t* p) {
     s->speed = mgo_uniform(&e->rng, p->spot_min_speed, p->spot_max_speed);
     s->t = 0;
     s->done = 0;
+    s->has_border = p->black_background;
     int dim = p->dim;
     double cx = dim / 2, cy = dim / 2;
     double diagonal = sqrt(pow(dim, 2) + pow(dim, 2));
@@ -309,6 +314,10 @@ static void sp_reset(mgo_env* e) {
     p->has_info = 0;
     p->t = 0;
     p->coin_t = 0;
+    if (p->hide_chessboard) { /* both surfaces turn white for the rest of the object's life */
+        mgo_fill(p->bg_blue, MGO_RGB(255, 255, 255));
+        mgo_fill(p->bg_red, MGO_RGB(255, 255, 255));
+    }
     memset(p->spawn_mask, 0, (size_t)dim * dim);
     e->ep_sum = 0;
     e->ep_len = 0;
@@ -405,6 +414,7 @@ static void sp_reset(mgo_env* e) {
         sp_exit_draw(e, p, 0);
     }
     p->bg_is_red = 0;
+    if (p->black_background) mgo_fill(p->bg_blue, 0);
     sp_compose(e, p, p->agent.sprites[0]); /* reset frame always shows sprite index 0 (App. D.19) */
     e->reward = 0;
     e->done = 0;
@@ -471,6 +481,7 @@ static void sp_step(mgo_env* e, const int action[2]) {
             s->cur_x = s->spawn_x * (1 - s->t) + lx * s->t;
             s->cur_y = s->spawn_y * (1 - s->t) + ly * s->t;
             mgo_draw_circle(p->spot_surf, MGO_RGB(255, 0, 0), (int)s->cur_x, (int)s->cur_y, (int)s->radius, 0);
+            if (s->has_border) mgo_draw_circle(p->spot_surf, MGO_RGB(255, 255, 255), (int)s->cur_x, (int)s->cur_y, (int)s->radius, 1);
             s->t += s->speed;
             if (s->t >= 1.0) {
                 s->t = 1.0;
@@ -489,6 +500,7 @@ static void sp_step(mgo_env* e, const int action[2]) {
         p->bg_is_red = 0;
         r += p->reward_outside;
     }
+    if (p->black_background) mgo_fill(p->bg_is_red ? p->bg_red : p->bg_blue, 0); /* bg.fill(0): the surface stays black */
     if (p->health <= 0) {
         spot_done = 1;
         r += p->reward_death;
@@ -589,7 +601,7 @@ static int sp_set_option(mgo_env* e, const char* k, const double* v, int n) {
     D("spot_min_radius", spot_min_radius) D("spot_max_radius", spot_max_radius)
     D("spot_min_speed", spot_min_speed) D("spot_max_speed", spot_max_speed) D("spot_damage", spot_damage)
     I("visual_feedback", visual_feedback)
-    if (!strcmp(k, "black_background") || !strcmp(k, "hide_chessboard")) return v[0] != 0.0 ? -3 : 0;
+    I("black_background", black_background) I("hide_chessboard", hide_chessboard)
     I("light_dim_off_duration", light_dim_off_duration) I("light_threshold", light_threshold)
     D("coin_scale", coin_scale) I("coins_visible", coins_visible)
     D("agent_speed", agent_speed) D("agent_health", agent_health) D("agent_scale", agent_scale)
@@ -613,6 +625,13 @@ static int sp_set_option(mgo_env* e, const char* k, const double* v, int n) {
     return -1;
 }
 
+static int sp_board_mode(const mgo_surf* b, int ts) { /* pixel (0,0) is a white tile, (ts,0) a coloured one */
+    uint32_t c0 = b->px[0], c1 = b->px[ts];
+    if (c0 == MGO_RGB(255, 255, 255) && c1 == MGO_RGB(255, 255, 255)) return 1;
+    if (c0 == 0 && c1 == 0) return 2;
+    return 0;
+}
+
 static double sp_get(mgo_env* e, const char* f, int* ok) {
     sp_t* p = (sp_t*)e->impl;
     *ok = 1;
@@ -623,6 +642,8 @@ static double sp_get(mgo_env* e, const char* f, int* ok) {
     F("health", p->health) F("alpha", p->spot_surf->alpha) F("spawn_timer", p->spawn_timer) F("n_spots", p->n_spots)
     F("t", p->t) F("la0", p->last_action[0]) F("la1", p->last_action[1]) F("last_reward", p->last_reward)
     F("bg_red", p->bg_is_red) F("coins_collected", p->coins_collected)
+    /* what hide_chessboard / black_background have left of the two boards: 0 chessboard, 1 white, 2 black */
+    F("bg_blue_mode", sp_board_mode(p->bg_blue, (int)(50 * e->scale))) F("bg_red_mode", sp_board_mode(p->bg_red, (int)(50 * e->scale)))
     if (p->endless) {
         F("coin_t", p->coin_t) F("coin_x", p->coin_x[0]) F("coin_y", p->coin_y[0])
         F("gt0", e->gt[0]) F("gt1", e->gt[1]) F("gt2", e->gt[2]) F("gt3", e->gt[3])
@@ -652,6 +673,11 @@ static int sp_get_list(mgo_env* e, const char* name, double* out, int cap) {
                 if (n < cap) out[n] = v[k];
         }
         return n;
+    }
+    if (!strcmp(name, "borders")) { /* Spotlight.has_border, list order */
+        for (int i = 0; i < p->n_spots; i++)
+            if (i < cap) out[i] = p->spots[i].has_border;
+        return p->n_spots;
     }
     if (!strcmp(name, "coins") && !p->endless) {
         int n = 0;

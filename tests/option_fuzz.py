@@ -61,6 +61,8 @@ def spot_opts(rng, env_id):
         # which only exists when the flag is set, :343); the finite env guards the use (:465)
         o.update(max_steps=int(rng.integers(60, 300)), num_spawns=int(rng.integers(0, 12)), num_coins=_lst(rng, 1, 4), reward_exit=_rew(rng),
                  show_last_action=bool(rng.integers(0, 2)), exit_visible=bool(rng.integers(0, 2)))
+    # drawn last, so that the other values of a trial are the ones earlier fixtures had
+    o.update(black_background=bool(rng.integers(0, 4) == 0), hide_chessboard=bool(rng.integers(0, 4) == 0))
     return o
 
 

@@ -143,6 +143,11 @@ class OracleBatch:
         self.envs = [OracleEnv(env_id, scale, _handle=self.L.mgo_batch_env(self.h, i)) for i in range(n)]
         self.dim = self.envs[0].dim
         self.discrete = self.envs[0].discrete
+        self.set_options(options)
+
+    def set_options(self, options):
+        """Like the reference's reset(options=...): the caller passes the complete dictionary (defaults included) if
+        earlier values are to be forgotten."""
         for k, v in (options or {}).items():
             vals = _opt_values(v)
             arr = (C.c_double * len(vals))(*vals)
