@@ -348,7 +348,14 @@ struct SpotIO {
     RngSoA rng;
     SpotDesc* desc;
     int* err;
+    // resets put off by the step kernel and served inside the raster launch (spot_raster_serve_kernel)
+    int* queue;  // [N] instances
+    int* qctr;   // SQ_COUNT entries, SQ_LEFT service workgroups that have finished (the last one clears both)
 };
+constexpr int SQ_COUNT = 0, SQ_LEFT = 32, SQ_WORDS = 64;  // one 128-byte line each
+// SpotDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = a reset is queued, 3 = reset and drawn by a service
+// workgroup.  The frame workgroups of the fused launch draw 1 only, everything else (raster_only, debug view) draws != 0.
+constexpr uint32_t DESC_QUEUED = 2, DESC_SERVED = 3;
 
 __device__ __forceinline__ int isqrt_floor(int v) {
     int r = (int)sqrt((double)v);
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
 
 template <bool EN>
 __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io, const int32_t* actions, float* reward_out,
-                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
+                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset, int defer) {
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int i = gid >> 4, ls = gid & 15;
     if (i >= P.n) return;
@@ -920,7 +927,13 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     // debug view only: the (rotated_agent_surface, rotated_agent_rect) pair of this step -- a reset leaves it alone, and the
     // reference's debug render shows that stale pair until the first step of the next episode
     s.pad = (s.pad & BG_MODE_MASK) | 0x80000000u | ((uint32_t)s.rot8 << 16) | (uint32_t)((ax + 128) & 0xFF) | ((uint32_t)((ay + 128) & 0xFF) << 8);
-    if (__builtin_expect(done && autoreset, 0)) {  // cold: keep the reset code out of the hot instruction stream
+    // defer: the reset (position sampling on 84x84 masks: ~30 us for the 16 lanes of the instance, the tail of this launch
+    // whenever any instance finishes) is queued and done by a service workgroup of the raster launch, which also draws the
+    // frame; state, stream and the descriptor head (its n_holes are the reset frame's stale holes) are stored as after
+    // any other step, exactly what a masked mg_reset(seed = None) would find.
+    const bool reset_me = done && autoreset;
+    if (defer && reset_me && leader) io.queue[atomicAdd(&io.qctr[SQ_COUNT], 1)] = i;
+    if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
         spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh);
     } else {
         d.bg = bg_template(s.pad, s.bg_red);
@@ -952,6 +965,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
             d.exit_x = (int16_t)(s.exit_x - P.exit_half);
             d.exit_y = (int16_t)(s.exit_y - P.exit_half);
         }
+        if (reset_me) d.valid = DESC_QUEUED;
         SpotCore tb = s;
         tb.last_pos = shown_last_pos;  // the bar shows whether the PREVIOUS reward was positive
         fill_topbar<EN>(P, tb, d, false, shown0, shown1);
@@ -966,6 +980,79 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         g.store(io.rng, i);
         io.core[i] = s;
         store_desc_head(&io.desc[i], d);
+    }
+}
+
+// The step's raster launch with the put-off resets served inside it: the first workgroups take the queue entries, eight
+// each (the 16 lanes of a quarter wave reset one instance, like spot_reset_kernel; waves 2 and 3 wait), then draw those
+// eight frames; all other workgroups walk the frames of the instances that were not queued (SpotDesc::valid == 1).  The
+// descriptors a service workgroup has just written are read back through the scalar cache like every descriptor: release,
+// barrier, s_dcache_inv first.  Service workgroups without an entry leave at once and issue no atomic (thousands of them on
+// one address: 22 ns each, in series).  What bounds the launch is a reset's latency next to the raster's waves (~45-80 us)
+// plus the frames that follow it in the same workgroup; variants measured: profiles/r02_spot_resets.md.
+constexpr int SPOT_SVC_WGS = 512, SPOT_SVC_BATCH = 8;
+// (five workgroups per CU: what the 28-KiB LDS request of the uint8 raster allows anyway -- and the reset code needs the 96 VGPRs)
+template <bool EN, bool BORDER>
+__global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
+                                                                   SpotParams P, SpotIO io, float* gt) {
+    typedef SpotComposerT<BORDER> Composer;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = as_const(A.tables);
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const cptr<SpotDesc> cdescs = as_const(descs);
+    const bool service = (int)blockIdx.x < SPOT_SVC_WGS;
+    const int count = service ? io.qctr[SQ_COUNT] : 0;
+    if (service && (int)blockIdx.x * SPOT_SVC_BATCH >= count) return;
+    Composer::recycle(R);
+    __syncthreads();
+    auto draw = [&](int env) {
+        typename Composer::Pre Pq;
+        Composer::prefetch(cdescs + env, R, Pq);
+        Composer::compose(cdescs + env, Pq, R);
+        __syncthreads();
+        Composer::recycle(R);
+        store_frame<MG_OBS_U8_XYC>(smem, obs, env, tid);
+        __syncthreads();
+    };
+    if (service) {
+        for (int base = blockIdx.x * SPOT_SVC_BATCH; base < count; base += SPOT_SVC_WGS * SPOT_SVC_BATCH) {
+            const int e = base + (tid >> 4), ls = tid & 15;
+            if (tid < 16 * SPOT_SVC_BATCH && e < count) {
+                const int i = io.queue[e];
+                Pcg g;
+                g.load(io.rng, i);
+                SpotCore s = io.core[i];
+                SpotDesc d;
+                const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);
+                spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes);
+                d.valid = DESC_SERVED;
+                if (ls == 0) {
+                    io.core[i] = s;
+                    g.store(io.rng, i);
+                    store_desc_head(&io.desc[i], d);
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            __builtin_amdgcn_s_dcache_inv();
+            for (int k = 0; k < SPOT_SVC_BATCH && base + k < count; ++k) draw(io.queue[base + k]);
+        }
+        const int busy = (count + SPOT_SVC_BATCH - 1) / SPOT_SVC_BATCH < SPOT_SVC_WGS ? (count + SPOT_SVC_BATCH - 1) / SPOT_SVC_BATCH : SPOT_SVC_WGS;
+        if (tid == 0 && atomicAdd(&io.qctr[SQ_LEFT], 1) == busy - 1) {  // last service workgroup out
+            io.qctr[SQ_COUNT] = 0;
+            io.qctr[SQ_LEFT] = 0;
+        }
+        return;
+    }
+    const int stride = (int)gridDim.x - SPOT_SVC_WGS;
+    for (int env = (int)blockIdx.x - SPOT_SVC_WGS; env < n; env += stride) {
+        if (cdescs[env].valid != 1u) continue;  // masked, or drawn by the workgroup that serves its reset
+        draw(env);
     }
 }
 
@@ -1017,6 +1104,8 @@ class SpotFamily : public Family {
         sp_r_.alloc((size_t)SLOTS * n);
         sp_done_.alloc((size_t)SLOTS * n);
         flags_.alloc(4);
+        queue_.alloc((size_t)n + SQ_WORDS);
+
         coins_.alloc((size_t)MAX_COINS * n);
         desc_.alloc(n);
         rng_.alloc(n);
@@ -1144,11 +1233,21 @@ class SpotFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
-        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+        const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets()) ? 1 : 0;
+        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
+        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
         prof.end(0, s);
         prof.begin(1, s);
-        raster(obs, s);
+        if (defer) {
+            const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + SPOT_SVC_WGS;
+#define SPOT_FUSED(EN, BO) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO>), dim3(grid), dim3(256), RASTER_LDS_REQUEST, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), gt)
+            if (P_.endless) { if (P_.ordered_holes) SPOT_FUSED(true, true); else SPOT_FUSED(true, false); }
+            else { if (P_.ordered_holes) SPOT_FUSED(false, true); else SPOT_FUSED(false, false); }
+#undef SPOT_FUSED
+            MG_HIP(hipGetLastError());
+        } else {
+            raster(obs, s);
+        }
         prof.end(1, s);
     }
 
@@ -1178,6 +1277,8 @@ class SpotFamily : public Family {
         o.rng = rng_.view();
         o.desc = desc_.p;
         o.err = err_.dev;
+        o.queue = queue_.p + SQ_WORDS;
+        o.qctr = queue_.p;
         return o;
     }
 
@@ -1230,6 +1331,17 @@ class SpotFamily : public Family {
 
     void raster(void* obs, hipStream_t s) { raster_only(obs, nullptr, s); }
 
+    // Resets served inside the raster launch: on for the finite variant (147 -> 173 M env-steps/s: more instances finish
+    // per step and their resets place up to five objects), off for the endless one (188 vs 190 M: its step kernel's tail
+    // is shorter than what the fused launch adds).  MEMGYM_SPOT_FUSE=0 / 1 forces it off / on for both.
+    bool fuse_resets() const {
+        static const int forced = [] {
+            const char* e = getenv("MEMGYM_SPOT_FUSE");
+            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        }();
+        return forced >= 0 ? forced != 0 : !P_.endless;
+    }
+
     int n_;
     SpotParams P_;
     double spot_min_radius_, spot_max_radius_, coin_scale_, agent_speed_, agent_scale_, exit_scale_;
@@ -1251,6 +1363,7 @@ class SpotFamily : public Family {
     DevArray<SpotCore> core_;
     DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;
     DevArray<uint8_t> sp_r_, sp_done_;
+    DevArray<int> queue_;  // deferred resets: the counters + n entries
     DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)
     DevArray<uint32_t> coins_;
     DevArray<SpotDesc> desc_;
