@@ -85,7 +85,8 @@ struct Piece {
 
 struct Mapping {
     size_t va_bytes = 0;
-    std::vector<std::pair<size_t, Piece>> pieces;  // (offset, piece)
+    void* base = nullptr;                          // start of the virtual range (the caller's pointer lies lead bytes into it)
+    std::vector<std::pair<size_t, Piece>> pieces;  // (offset from base, piece)
     std::vector<int> piece_class;                  // group id of every piece (pieces of one id are slow together)
     bool plain = false;                            // hipMalloc fallback
     int device = 0;
@@ -414,8 +415,13 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             throw std::runtime_error("mg_obs_alloc: " + std::to_string(bad) + " of " + std::to_string(k * PIECE / 16) +
                                      " vectors of the assembled range did not read back (stale translations?)");
         }
-        g_live[va] = m;
-        *out = va;
+        // The buffer sits in the MIDDLE of the range: what the pieces hold beyond `bytes` is split between the first and
+        // the last piece, so that a buffer of 1.1 pieces is half in one zone and half in the other, not 10 : 1.
+        const size_t lead = ((k * PIECE - bytes) / 2) & ~(size_t)(2 * MiB - 1);
+        m.base = va;
+        void* user = (char*)va + lead;
+        g_live[user] = m;
+        *out = user;
         I.pieces = (int)k;
         I.piece_bytes = PIECE;
         I.search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -458,10 +464,10 @@ int mg_obs_free(void* p) {
     std::lock_guard<std::mutex> lk(g_mu);
     ZoneCache& Z = g_zones[m.device];
     for (size_t i = 0; i < m.pieces.size(); ++i) {
-        (void)hipMemUnmap((char*)p + m.pieces[i].first, m.pieces[i].second.bytes);
+        (void)hipMemUnmap((char*)m.base + m.pieces[i].first, m.pieces[i].second.bytes);
         pool_put(Z, i < m.piece_class.size() ? m.piece_class[i] : -1, m.pieces[i].second);  // spare pieces of a known zone
     }
-    va_free(p, m.va_bytes);
+    va_free(m.base, m.va_bytes);
     return 0;
 }
 
