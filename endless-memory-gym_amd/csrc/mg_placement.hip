@@ -29,8 +29,7 @@ namespace {
 constexpr size_t MiB = 1ull << 20, GiB = 1ull << 30;
 constexpr size_t PIECE = 304 * MiB;         // = one window of the probe: 14,336 frames of 21,168 B (64-MiB pieces measured the
                                             // same, 16 MiB +6 %, 2 MiB +12 %: profiles/r02_zones.md)
-constexpr size_t SPACER = 16 * GiB;
-constexpr size_t ZONE = 96 * GiB;            // a third of the 288 GB
+constexpr int FILL_STEP = 32;               // filler handles per step of the walk
 constexpr int PROBE_GRID = 14336;
 static const double CROSS_ZONE_TBPS = getenv("MEMGYM_OBS_CROSS_TBPS") ? atof(getenv("MEMGYM_OBS_CROSS_TBPS")) : 5.85;  // different zones 6.1-6.5 ...
 constexpr double SAME_ZONE_TBPS = 5.35;     // ... same zone 4.9-5.3 (profiles/r02_zones.md); in between: a piece that straddles
@@ -351,13 +350,18 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
                 if (groups.size() >= 2 && usable(loose_cap) >= k) break;
                 exportable = !exportable;
                 if (!exportable) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed.
-                    // The first step is long (a pristine VRAM hands out 100-130 GiB of one zone in a row), then 16 GiB at a time.
-                    Piece sp;
-                    size_t step = spacers.empty() ? ZONE : SPACER;
-                    if (walked + step > search_budget_bytes) step = SPACER;
-                    if (walked + step > search_budget_bytes || !create_piece(device, step, &sp)) break;
-                    spacers.push_back(sp);
-                    walked += step;
+                    // With piece-sized handles of the ordinary kind, 32 at a time (9.5 GiB): the driver serves requests of
+                    // different sizes from different lists (big spacers -- 96 GiB, then 16 GiB at a time, the first version --
+                    // moved the pieces' list on some boxes and not at all on others: 158 GiB walked, every piece from one zone),
+                    // and a pristine VRAM hands out 100-130 GiB of one zone in a row.
+                    const size_t before = spacers.size();
+                    for (int f = 0; f < FILL_STEP && walked + PIECE <= search_budget_bytes; ++f) {
+                        Piece sp;
+                        if (!create_piece(device, PIECE, &sp)) break;
+                        spacers.push_back(sp);
+                        walked += PIECE;
+                    }
+                    if (spacers.size() == before) break;
                 }
             }
         } catch (...) {
