@@ -175,11 +175,13 @@ struct MysteryIO {
     MysteryDesc* desc;
     int* err;
     int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
-    uint8_t* queued;  // endless: [N] 1 = this step's frame of the instance is drawn by the workgroup that serves its queue entry
     uint64_t* walls;  // finite: [N] wall cells of the current path generation (bit x*7+y), read by the debug view only
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
 };
 constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_WORDS = 96;  // one 128-byte line each
+// MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
+// the fused launch, drawn by the workgroup that served it).  Only emp_raster_serve_kernel's frame workgroups tell 1 from 2 / 3.
+constexpr uint8_t DESC_QUEUED = 2, DESC_SERVED = 3;
 
 // ---- MysteryPath.__init__: walls + noisy A* on a 7x7 grid.  Returns the path length; out[] = flat indices
 // (x*7+y), END FIRST like the reference's list.  -1 = "No valid path found".
@@ -1087,13 +1089,15 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryI
     if (emp_step_a(P, i, s, actions, nx, ny)) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         io.core[i] = s;
         io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i | EMP_Q_SEGMENT;
-        io.queued[i] = 1;
+        io.desc[i].valid = DESC_QUEUED;  // (the rest of the descriptor is last step's)
         return;
     }
     MysteryDesc d;
     const bool q = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
-    if (q) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
-    io.queued[i] = q ? 1 : 0;
+    if (q) {
+        io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+        d.valid = DESC_QUEUED;
+    }
     io.core[i] = s;
     io.desc[i] = d;
 }
@@ -1137,6 +1141,7 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
         if (me) emp_post_reset(P, io, i, s, d, gti);
     }
     if (me) {
+        d.valid = DESC_SERVED;
         io.core[i] = s;
         g.store(io.rng, i);
         io.desc[i] = d;
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 // mg_step of the endless variant, second launch: raster AND queue service in one.  The first EMP_SVC_WGS workgroups do what
 // emp_serve_kernel does -- one queue entry per wave at a time -- and then draw the frames of the instances they served
 // themselves (from the descriptor their wave just produced, kept in LDS); all other workgroups walk the frames of the
-// instances that were NOT queued (io.queued, written by emp_step_kernel).  The 100 us of dependent path generation that a
+// instances that were NOT queued (MysteryDesc::valid == 1; emp_step_kernel marks the queued ones).  The 100 us of dependent path generation that a
 // reset costs no longer stand in front of the raster: they run next to it, on a quarter of the resident workgroups.
 // Measured (32,768 instances, us per step incl. the 26 us of emp_step_kernel; separate launches: 240): 384 / 512 / 768 /
 // 1,024 / 1,536 service workgroups at 7 workgroups per CU (72 VGPRs, the path generator spills) 218 / 217 / 216 / 224 / 234;
@@ -1438,9 +1443,8 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
     }
     const int stride = (int)gridDim.x - svc;
     for (int env = (int)blockIdx.x - svc; env < n; env += stride) {
-        if (io.queued[env]) continue;  // drawn by the workgroup that serves it
         const MysteryDesc* d = descs + env;
-        if (MysteryComposer::skip(d)) continue;
+        if (d->valid != 1) continue;  // masked, or drawn by the workgroup that serves its queue entry
         MysteryComposer::compose(d, R);
         __syncthreads();
         store_frame<FMT>(smem, obs, env, tid);
@@ -1474,7 +1478,6 @@ class MysteryFamily : public Family {
         }
         core_.alloc(n);
         walls_.alloc(n);
-        queued_.alloc(n);
         desc_.alloc(n);
         rng_.alloc(n);
         err_.alloc();
@@ -1673,7 +1676,6 @@ class MysteryFamily : public Family {
         o.err = err_.dev;
         o.queue = queue_.p;
         o.walls = P_.endless ? nullptr : walls_.p;
-        o.queued = queued_.p;
         o.qctr = queue_.p + ((n_ + 31) & ~31);
         return o;
     }
@@ -1742,7 +1744,6 @@ class MysteryFamily : public Family {
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
-    DevArray<uint8_t> queued_;  // endless: per-instance flag of emp_step_kernel (see emp_raster_serve_kernel)
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
     RngStore rng_;
