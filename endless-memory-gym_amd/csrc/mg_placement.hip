@@ -312,7 +312,14 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             spacers.clear();
         };
         try {
-            while ((usable(half) < k || groups.size() < 2) && walked <= search_budget_bytes) {
+            // also bounded in time (MEMGYM_OBS_SEARCH_MS, default 3,000): on memory a previous process dirtied the driver
+            // wipes what it hands out (~27 ms per GiB)
+            static const double max_ms = [] {
+                const char* e = getenv("MEMGYM_OBS_SEARCH_MS");
+                return e ? atof(e) : 3000.0;
+            }();
+            auto elapsed_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+            while ((usable(half) < k || groups.size() < 2) && walked <= search_budget_bytes && elapsed_ms() < max_ms) {
                 Cand c;
                 if (!c.make(device, exportable)) break;
                 int home = -1;
