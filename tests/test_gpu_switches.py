@@ -1,0 +1,31 @@
+"""The A/B switches of the library select whole launch arrangements (resets / path generation inside
+the raster launch or not, full resets by lanes or by waves).  The defaults are what the rest of the suite runs; this runs
+a lock-step parity check (HIP vs oracle, every frame) under the OTHER setting of each switch, in fresh processes."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = [
+    ("MEMGYM_EMP_FUSE", "0", "Endless-MysteryPath-v0", 160, 150),          # queue server as a launch of its own
+    ("MEMGYM_EMP_RESET_LANES", "0", "Endless-MysteryPath-v0", 1024, 30),    # full reset one wave per instance (lanes: n >= 1,024)
+    ("MEMGYM_MYSTERY_DEFER", "1", "MysteryPath-v0", 160, 150),              # reset paths inside the raster launch
+    ("MEMGYM_MYSTERY_DEFER", "0", "MysteryPath-Grid-v0", 160, 150),         # ... and not, for the grid variant
+    ("MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 200),    # resets inside the raster launch
+    ("MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 200),            # ... and not, for the finite variant
+]
+
+
+@pytest.mark.parametrize("var,value,env_id,n,steps", CASES)
+def test_other_setting_is_bit_exact_too(var, value, env_id, n, steps):
+    env = dict(os.environ)
+    env[var] = value
+    r = subprocess.run([sys.executable, os.path.join(HERE, "switch_worker.py"), env_id, str(n), str(steps)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "%s=%s, %s:\n%s\n%s" % (var, value, env_id, r.stdout[-2000:], r.stderr[-4000:])
+    assert "ok:" in r.stdout
