@@ -186,3 +186,16 @@ void mgo_batch_step(mgo_batch* b, const int32_t* actions, int autoreset, uint8_t
         }
     }
 }
+
+/* Test hook (tests/test_oracle_properties.py): pygame.draw.circle(surface, white, (cx, cy), radius, width) on a black dim x dim
+ * surface; out[y * dim + x] = 1 where a pixel was drawn. */
+int mgo_test_circle(int dim, int cx, int cy, int radius, int width, uint8_t* out) {
+    mgo_surf* s = mgo_surf_new(dim, dim);
+    if (!s) return -1;
+    mgo_fill(s, 0);
+    mgo_draw_circle(s, MGO_RGB(255, 255, 255), cx, cy, radius, width);
+    for (int i = 0; i < dim * dim; i++) out[i] = s->px[i] != 0;
+    mgo_surf_free(s);
+    return 0;
+}
+

@@ -80,3 +80,31 @@ def test_observation_is_a_pure_function_of_seed_and_actions(seed):
                 break
         a.close()
         b.close()
+
+
+def _circle(dim, cx, cy, radius, width):
+    import ctypes as C
+    L = oracle_lib.lib()
+    L.mgo_test_circle.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros((dim, dim), np.uint8)
+    assert L.mgo_test_circle(dim, cx, cy, radius, width, out.ctypes.data) == 0
+    return out.astype(bool)
+
+
+def test_one_pixel_circle_is_the_outline_of_the_filled_disc():
+    """The spotlight border (pygame.draw.circle(..., width=1), pygame_assets.py:112-113) has no reference artefact: no
+    recording shows one and pygame is absent here (unpinned).  What CAN be checked: the restated
+    draw_circle_bresenham_thin draws exactly the pixels of the filled disc that have a 4-neighbour outside it -- the
+    outline of the disc that the reference's recordings do pin (tests/test_oracle_gif.py) -- for every radius the
+    library accepts, also clipped at the surface's edges."""
+    for r in range(1, 65):
+        dim = 2 * r + 6
+        disc = _circle(dim, r + 3, r + 3, r, 0)
+        ring = _circle(dim, r + 3, r + 3, r, 1)
+        pad = np.pad(disc, 1)
+        inner = pad[1:-1, :-2] & pad[1:-1, 2:] & pad[:-2, 1:-1] & pad[2:, 1:-1]
+        assert np.array_equal(ring, disc & ~inner), r
+    for cx, cy in ((0, 0), (3, 40), (83, 83), (-5, 20), (90, 10)):  # clipping: the same outline, cut
+        big_d, big_r = _circle(84 + 64, cx + 32, cy + 32, 13, 0), _circle(84 + 64, cx + 32, cy + 32, 13, 1)
+        assert np.array_equal(_circle(84, cx, cy, 13, 1), big_r[32:-32, 32:-32])
+        assert np.array_equal(_circle(84, cx, cy, 13, 0), big_d[32:-32, 32:-32])
