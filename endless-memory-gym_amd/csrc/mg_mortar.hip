@@ -101,8 +101,17 @@ struct MortarDebugComposer {
     }
 };
 
-__constant__ int8_t kCmdDx[9] = {1, 0, -1, 0, 0, 1, 1, -1, -1};
-__constant__ int8_t kCmdDy[9] = {0, 1, 0, -1, 0, 1, -1, 1, -1};
+// (dx, dy) of command c: {1, 0, -1, 0, 0, 1, 1, -1, -1} / {0, 1, 0, -1, 0, 1, -1, 1, -1}, two bits each (value + 1) in a constant
+// -- a table in memory is a dependent load per command in the reset's serial loop, with a lane-dependent index
+constexpr uint32_t pack_deltas(const int (&v)[9]) {
+    uint32_t m = 0;
+    for (int c = 0; c < 9; ++c) m |= (uint32_t)(v[c] + 1) << (2 * c);
+    return m;
+}
+constexpr int kDxHost[9] = {1, 0, -1, 0, 0, 1, 1, -1, -1}, kDyHost[9] = {0, 1, 0, -1, 0, 1, -1, 1, -1};
+constexpr uint32_t CMD_DX_BITS = pack_deltas(kDxHost), CMD_DY_BITS = pack_deltas(kDyHost);
+__device__ __forceinline__ int cmd_dx(int c) { return (int)((CMD_DX_BITS >> (2 * c)) & 3u) - 1; }
+__device__ __forceinline__ int cmd_dy(int c) { return (int)((CMD_DY_BITS >> (2 * c)) & 3u) - 1; }
 
 __device__ __forceinline__ int floordiv(int a, int b) {  // b > 0
     int q = a / b;
@@ -148,16 +157,19 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
         n = choice(g, P.command_count);
         int px = nx, py = ny;
         for (int i = 0; i < n; ++i) {
-            int valid[9], nv = 0;
-            for (int c = 0; c < P.allowed; ++c) {
-                int qx = px + kCmdDx[c], qy = py + kCmdDy[c];
-                if (qx >= 0 && qx < P.N && qy >= 0 && qy < P.N) valid[nv++] = c;
+            uint32_t valid = 0;  // bit c: command c keeps the agent inside the arena (the reference's list, in order)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const int qx = px + cmd_dx(c), qy = py + cmd_dy(c);
+                if (c < P.allowed && qx >= 0 && qx < P.N && qy >= 0 && qy < P.N) valid |= 1u << c;
             }
-            int pick = g.integers(0, nv), c = valid[0];
-            for (int k = 1; k < 9; ++k) c = (k == pick) ? valid[k] : c;  // register-resident select
+            const int pick = g.integers(0, __popc(valid));
+            uint32_t m = valid;
+            for (int k = 0; k < pick; ++k) m &= m - 1;  // pick-th entry of the list
+            const int c = __ffs(m) - 1;
             cmds[i] = (uint8_t)c;
-            px += kCmdDx[c];
-            py += kCmdDy[c];
+            px += cmd_dx(c);
+            py += cmd_dy(c);
         }
     }
     s.num_cmds = (uint16_t)n;
@@ -174,11 +186,11 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
     int first = cmds[0];
     uint8_t glyph = s.show_dur > 0 ? (uint8_t)first : (uint8_t)9;
     if (P.variant == V_ENDLESS) {
-        s.tx = (int8_t)mod6(nx + kCmdDx[first]);
-        s.ty = (int8_t)mod6(ny + kCmdDy[first]);
+        s.tx = (int8_t)mod6(nx + cmd_dx(first));
+        s.ty = (int8_t)mod6(ny + cmd_dy(first));
     } else {
-        s.tx = (int8_t)(nx + kCmdDx[first]);
-        s.ty = (int8_t)(ny + kCmdDy[first]);
+        s.tx = (int8_t)(nx + cmd_dx(first));
+        s.ty = (int8_t)(ny + cmd_dy(first));
     }
     s.cur_cmd = 0;
     s.cmd_steps = 0;
@@ -386,11 +398,11 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
                 if (s.cur_cmd < s.num_cmds) {
                     int c = cmds[s.cur_cmd];
                     if (P.variant == V_ENDLESS) {
-                        s.tx = (int8_t)mod6(s.tx + kCmdDx[c]);
-                        s.ty = (int8_t)mod6(s.ty + kCmdDy[c]);
+                        s.tx = (int8_t)mod6(s.tx + cmd_dx(c));
+                        s.ty = (int8_t)mod6(s.ty + cmd_dy(c));
                     } else {
-                        s.tx = (int8_t)(s.tx + kCmdDx[c]);
-                        s.ty = (int8_t)(s.ty + kCmdDy[c]);
+                        s.tx = (int8_t)(s.tx + cmd_dx(c));
+                        s.ty = (int8_t)(s.ty + cmd_dy(c));
                     }
                 }
             } else {
