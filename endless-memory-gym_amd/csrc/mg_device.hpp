@@ -159,6 +159,14 @@ struct OptList {
     int n;
     int v[8];
 };
-__device__ __forceinline__ int choice(Pcg& g, const OptList& l) { return l.v[g.integers(0, l.n)]; }
+// (a select chain over the eight uniform entries: indexing the list with a lane's draw would be a load from the kernel
+// argument segment, one more dependent memory round trip in the reset's serial code)
+__device__ __forceinline__ int choice(Pcg& g, const OptList& l) {
+    const int k = g.integers(0, l.n);
+    int v = l.v[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v = k == j ? l.v[j] : v;
+    return v;
+}
 
 }  // namespace mg
