@@ -1,5 +1,6 @@
 // mg_api.hip -- the C ABI of include/memgym.h on top of the per-family implementations.
 #include <algorithm>
+#include <cstddef>
 #include <map>
 #include <mutex>
 
@@ -18,6 +19,34 @@ struct mg_env {
 };
 
 namespace {
+// mg_info_buffers as the caller's header laid it out (include/memgym.h: struct_size)
+constexpr size_t INFO_SIZE_MIN = offsetof(mg_info_buffers, final_obs_dev);  // the episode-record pointers every layout has
+mg_info_buffers read_info(const mg_info_buffers* info) {
+    mg_info_buffers ib;
+    memset(&ib, 0, sizeof(ib));
+    if (!info) return ib;
+    const size_t sz = info->struct_size;
+    if (sz < INFO_SIZE_MIN || sz % sizeof(void*) != 0)
+        throw std::runtime_error("mg_step: mg_info_buffers.struct_size = " + std::to_string(sz) + " is not a layout of include/memgym.h (" +
+                                 std::to_string(sizeof(mg_info_buffers)) + " in this build); set it to sizeof(mg_info_buffers)");
+    memcpy(&ib, info, sz < sizeof(ib) ? sz : sizeof(ib));  // a shorter (older) struct: the fields it lacks stay NULL
+    ib.struct_size = sizeof(ib);
+    return ib;
+}
+
+struct StateHeader {
+    char magic[8];
+    uint32_t version, num_envs;
+    uint64_t payload, id_hash;
+    uint8_t pad[32];
+};
+static_assert(sizeof(StateHeader) == 64, "state header is 64 bytes");
+uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+    return h;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int device) {
@@ -191,7 +220,9 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
     return guarded(env, [&] {
         if (!actions_dev || !obs_dev || !reward_dev || !done_dev) throw std::runtime_error("mg_step: NULL buffer");
         hipStream_t st = (hipStream_t)stream;
-        if (autoreset && info && info->final_obs_dev) {
+        const mg_info_buffers ib = read_info(info);
+        info = &ib;
+        if (autoreset && info->final_obs_dev) {
             // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
             // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
             // consumption and frames as the fused path (tests/test_gpu_vector_api.py)
@@ -206,16 +237,24 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
 
 size_t mg_state_size(const mg_env* env) {
     if (!env) return 0;
-    size_t t = 0;
+    size_t t = sizeof(StateHeader);
     for (auto& b : env->fam->state_blobs()) t += b.second;
     return t;
 }
 
 int mg_get_state(mg_env* env, void* host_buf, size_t size) {
     return guarded(env, [&] {
-        if (size < mg_state_size(env)) throw std::runtime_error("mg_get_state: buffer too small");
+        if (!host_buf || size < mg_state_size(env)) throw std::runtime_error("mg_get_state: buffer too small");
         MG_HIP(hipDeviceSynchronize());
-        char* p = (char*)host_buf;
+        StateHeader h;
+        memset(&h, 0, sizeof(h));
+        memcpy(h.magic, "MGSTATE1", 8);
+        h.version = MG_STATE_VERSION;
+        h.num_envs = (uint32_t)env->num_envs;
+        h.payload = mg_state_size(env) - sizeof(StateHeader);
+        h.id_hash = fnv1a(env->id);
+        memcpy(host_buf, &h, sizeof(h));
+        char* p = (char*)host_buf + sizeof(StateHeader);
         for (auto& b : env->fam->state_blobs()) {
             MG_HIP(hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost));
             p += b.second;
@@ -225,9 +264,21 @@ int mg_get_state(mg_env* env, void* host_buf, size_t size) {
 
 int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
     return guarded(env, [&] {
-        if (size < mg_state_size(env)) throw std::runtime_error("mg_set_state: buffer too small");
+        if (!host_buf || size < sizeof(StateHeader)) throw std::runtime_error("mg_set_state: buffer too small for a state header");
+        StateHeader h;
+        memcpy(&h, host_buf, sizeof(h));
+        if (memcmp(h.magic, "MGSTATE1", 8) != 0) throw std::runtime_error("mg_set_state: not a memgym state blob (bad magic)");
+        if (h.version != MG_STATE_VERSION)
+            throw std::runtime_error("mg_set_state: state version " + std::to_string(h.version) + ", this library reads version " +
+                                     std::to_string(MG_STATE_VERSION));
+        if (h.id_hash != fnv1a(env->id)) throw std::runtime_error("mg_set_state: the blob belongs to another env id than " + env->id);
+        if (h.num_envs != (uint32_t)env->num_envs)
+            throw std::runtime_error("mg_set_state: the blob holds " + std::to_string(h.num_envs) + " instances, the handle " +
+                                     std::to_string(env->num_envs));
+        if (h.payload != mg_state_size(env) - sizeof(StateHeader) || size < mg_state_size(env))
+            throw std::runtime_error("mg_set_state: payload size differs from this handle's state");
         MG_HIP(hipDeviceSynchronize());
-        const char* p = (const char*)host_buf;
+        const char* p = (const char*)host_buf + sizeof(StateHeader);
         for (auto& b : env->fam->state_blobs()) {
             MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
             p += b.second;

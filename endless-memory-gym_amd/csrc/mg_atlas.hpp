@@ -100,25 +100,4 @@ class Atlas {
     RasterAtlas dev_;
 };
 
-// Shared RNG SoA storage
-struct RngStore {
-    DevArray<uint64_t> s_hi, s_lo, i_hi, i_lo, buf;
-    void alloc(size_t n) { s_hi.alloc(n); s_lo.alloc(n); i_hi.alloc(n); i_lo.alloc(n); buf.alloc(n); }
-    RngSoA view() { return RngSoA{s_hi.p, s_lo.p, i_hi.p, i_lo.p, buf.p}; }
-    void blobs(std::vector<std::pair<void*, size_t>>& v) {
-        v.push_back({s_hi.p, s_hi.bytes()}); v.push_back({s_lo.p, s_lo.bytes()}); v.push_back({i_hi.p, i_hi.bytes()});
-        v.push_back({i_lo.p, i_lo.bytes()}); v.push_back({buf.p, buf.bytes()});
-    }
-    void debug(int i, uint64_t out[6]) {
-        uint64_t b;
-        MG_HIP(hipMemcpy(&out[0], s_hi.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&out[1], s_lo.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&out[2], i_hi.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&out[3], i_lo.p + i, 8, hipMemcpyDeviceToHost));
-        MG_HIP(hipMemcpy(&b, buf.p + i, 8, hipMemcpyDeviceToHost));
-        out[4] = (b >> 32) & 1;
-        out[5] = b & 0xFFFFFFFFull;
-    }
-};
-
 }  // namespace mg

@@ -154,19 +154,27 @@ __device__ __forceinline__ void free_move(int a0, int a1, int v_axis, int v_diag
     }
 }
 
-// "sample one per episode" option list (np_random.choice(list) == list[integers(0, len)])
+// "sample one per episode" option list (np_random.choice(list) == list[integers(0, len)], e.g.
+// mortar_mayhem_grid.py:181,253-254,268-269; mystery_path.py:154; searing_spotlights.py:408).  The reference accepts lists
+// of any length.  Entries are bytes (every list option of the reference is a small count or duration; hosts refuse values
+// outside 0..255).  Up to OPT_INLINE entries travel in the kernel arguments, four per dword: the word is picked with a
+// select chain over eight uniform (scalar) operands and the byte with a shift -- indexing the list with a lane's draw
+// would be a load from the kernel-argument segment, one more dependent memory round trip in the reset's serial code.
+// Longer lists (any length) live in a device array owned by the family (OptListStore, mg_family.hpp) and cost that load.
+constexpr int OPT_INLINE = 32;
 struct OptList {
     int n;
-    int v[8];
+    uint32_t w[OPT_INLINE / 4];
+    const uint8_t* ext;  // n > OPT_INLINE: all n entries, device memory
 };
-// (a select chain over the eight uniform entries: indexing the list with a lane's draw would be a load from the kernel
-// argument segment, one more dependent memory round trip in the reset's serial code)
 __device__ __forceinline__ int choice(Pcg& g, const OptList& l) {
     const int k = g.integers(0, l.n);
-    int v = l.v[0];
+    if (__builtin_expect(l.n > OPT_INLINE, 0)) return (int)l.ext[k];  // uniform branch
+    const int wi = k >> 2;
+    uint32_t w = l.w[0];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) v = k == j ? l.v[j] : v;
-    return v;
+    for (int j = 1; j < OPT_INLINE / 4; ++j) w = wi == j ? l.w[j] : w;
+    return (int)((w >> (8 * (k & 3))) & 0xFFu);
 }
 
 }  // namespace mg

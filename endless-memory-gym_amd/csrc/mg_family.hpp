@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/memgym.h"
+#include "mg_device.hpp"
 
 namespace mg {
 
@@ -47,6 +48,19 @@ struct ErrorWord {
 __device__ __forceinline__ void raise_error(int* err, int bit) {
     __hip_atomic_fetch_or(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Deferred-reset queues (`cap` entries + a counter that the serving launch zeroes when it has drained them): a push never
+// writes past the end.  The counter can only exceed `cap` if an earlier serving launch failed after its step kernel had
+// queued entries; that is flagged (bit 64) instead of becoming an out-of-bounds store, and the servers clamp the count.
+constexpr int ERR_QUEUE_OVERFLOW = 64;
+__device__ __forceinline__ void queue_push(int* queue, int* counter, int cap, int value, int* err) {
+    const int slot = atomicAdd(counter, 1);
+    if (__builtin_expect(slot < cap, 1)) queue[slot] = value;
+    else raise_error(err, ERR_QUEUE_OVERFLOW);
+}
+__device__ __forceinline__ int queue_count(const int* counter, int cap) {
+    const int c = *counter;
+    return c < cap ? c : cap;
+}
 #endif
 
 template <typename T>
@@ -73,6 +87,46 @@ struct DevArray {
         MG_HIP(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
     }
     size_t bytes() const { return sizeof(T) * n; }
+};
+
+// Per-instance RNG streams (mg::RngSoA, mg_device.hpp) as five device arrays; part of every family's checkpoint
+struct RngStore {
+    DevArray<uint64_t> s_hi, s_lo, i_hi, i_lo, buf;
+    void alloc(size_t n) { s_hi.alloc(n); s_lo.alloc(n); i_hi.alloc(n); i_lo.alloc(n); buf.alloc(n); }
+    RngSoA view() { return RngSoA{s_hi.p, s_lo.p, i_hi.p, i_lo.p, buf.p}; }
+    void blobs(std::vector<std::pair<void*, size_t>>& v) {
+        v.push_back({s_hi.p, s_hi.bytes()}); v.push_back({s_lo.p, s_lo.bytes()}); v.push_back({i_hi.p, i_hi.bytes()});
+        v.push_back({i_lo.p, i_lo.bytes()}); v.push_back({buf.p, buf.bytes()});
+    }
+    void debug(int i, uint64_t out[6]) {
+        uint64_t b;
+        MG_HIP(hipMemcpy(&out[0], s_hi.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&out[1], s_lo.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&out[2], i_hi.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&out[3], i_lo.p + i, 8, hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(&b, buf.p + i, 8, hipMemcpyDeviceToHost));
+        out[4] = (b >> 32) & 1;
+        out[5] = b & 0xFFFFFFFFull;
+    }
+};
+
+// Host side of an OptList (mg_device.hpp): packs the entries, owns the device copy of lists longer than OPT_INLINE.
+struct OptListStore {
+    DevArray<uint8_t> ext;
+    // values must already be validated to lie in 0..255
+    void set(OptList& l, const std::vector<int>& v) {
+        l.n = (int)v.size();
+        for (int j = 0; j < OPT_INLINE / 4; ++j) l.w[j] = 0u;
+        l.ext = nullptr;
+        for (int k = 0; k < l.n && k < OPT_INLINE; ++k) l.w[k >> 2] |= (uint32_t)(v[k] & 0xFF) << (8 * (k & 3));
+        if (l.n > OPT_INLINE) {
+            std::vector<uint8_t> b(v.begin(), v.end());
+            // the previous array may still be read by kernels in flight on some stream: synchronise before it goes
+            MG_HIP(hipDeviceSynchronize());
+            ext.upload(b);
+            l.ext = ext.p;
+        }
+    }
 };
 
 struct OptionError {

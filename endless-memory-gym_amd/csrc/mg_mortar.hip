@@ -56,8 +56,9 @@ struct __attribute__((aligned(16))) MortarState {
     uint8_t show_dur, show_delay, expl_dur, expl_delay;
     uint8_t gx, gy;          // grid controller position
     int32_t ep_len, t, total_completed;
-    uint32_t dbg_lead;       // debug view only: the reference's clone of the display schedule runs one entry ahead after an
-                             // endless regeneration (endless_mortar_mayhem.py:320-321)
+    uint32_t dbg_pops;       // debug view only: entries popped from the reference's CLONE of the display schedule (one per debug
+                             // render while the real schedule holds entries; copied anew at reset and at an endless regeneration,
+                             // mortar_mayhem_grid.py:122,257, endless_mortar_mayhem.py:321)
     double ep_sum;
 };
 static_assert(sizeof(MortarState) == 64, "MortarState must be 64 bytes");
@@ -182,7 +183,7 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
     s.vis_len = (uint16_t)(n * (s.show_dur + s.show_delay));
     s.vis_base = 0;
     s.vis_pos = 1;  // reset pops the first entry for its own frame
-    s.dbg_lead = 0;
+    s.dbg_pops = 0;
     int first = cmds[0];
     uint8_t glyph = s.show_dur > 0 ? (uint8_t)first : (uint8_t)9;
     if (P.variant == V_ENDLESS) {
@@ -225,7 +226,9 @@ struct MortarIO {
     RngSoA rng;
     MortarDesc* desc;
     float* vec;  // [N][180] caller buffer bound with mg_bind_vector_obs (MortarMayhemB*), or NULL
+    int* err;    // sticky error bits (mg_poll_errors / mg_peek_errors)
 };
+constexpr int ERR_CMD_OVERFLOW = 32;  // include/memgym.h: Endless Mortar Mayhem command list longer than its capacity
 
 __global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P, int n, MortarIO io, const int64_t* seeds,
                                                            const uint8_t* mask, float* gt) {
@@ -374,7 +377,9 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
                         cmds[s.num_cmds] = (uint8_t)nc;
                         s.vis_base = s.num_cmds;
                         s.num_cmds++;
-                    } else {  // capacity reached (not reachable by any realistic policy): end the episode
+                    } else {  // capacity reached (512 commands = 131,328 correct tile visits in one episode; the reference's
+                        // list is unbounded, endless_mortar_mayhem.py:316-318): end the episode AND say so
+                        raise_error(io.err, ERR_CMD_OVERFLOW);
                         done = true;
                         s.vis_base = (uint16_t)(s.num_cmds - 1);
                     }
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
                     s.verify_step = 0;
                     s.vis_pos = 0;
                     s.vis_len = (uint16_t)(s.show_dur + s.show_delay);
-                    s.dbg_lead = 1;
+                    s.dbg_pops = 0;
                 } else {
                     done = true;
                     success = 1;
@@ -464,8 +469,8 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
 }
 
 // Debug view: the frame descriptors of the current frames with (a) the glyph the reference's CLONE of the display schedule
-// yields -- entry (entries popped - 1 + lead), only while the real schedule still holds entries (oracle/mgo_mortar.c
-// mm_debug) -- and (b) the ring around the target tile.
+// yields -- its next entry, popped (dbg_pops, the only state a debug render changes), only while the real schedule still
+// holds entries (oracle/mgo_mortar.c mm_debug) -- and (b) the ring around the target tile.
 __global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P, int n, MortarIO io, MortarDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -484,7 +489,8 @@ __global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P, 
     }
     d.glyph = 0xFF;
     if (s.vis_pos < s.vis_len) {
-        const int idx = (int)s.vis_pos - 1 + (int)s.dbg_lead, period = s.show_dur + s.show_delay;
+        const int idx = (int)s.dbg_pops, period = s.show_dur + s.show_delay;
+        io.state[i].dbg_pops = s.dbg_pops + 1;
         if (idx >= 0 && idx < (int)s.vis_len && period > 0) {
             const int k = idx / period, w = idx % period;
             d.glyph = (w < s.show_dur) ? cmds[s.vis_base + k] : (uint8_t)9;
@@ -518,11 +524,11 @@ class MortarFamily : public Family {
         P_.max_steps = -1;
         P_.initial_count = 1;
         P_.cmd_cap = variant == V_ENDLESS ? 512 : 32;
-        set_list(P_.command_count, {10});
-        set_list(P_.show_dur, {3});
-        set_list(P_.show_delay, {1});
-        set_list(P_.expl_dur, {variant == V_GRID ? 2 : 6});
-        set_list(P_.expl_delay, {variant == V_GRID ? 6 : 18});
+        st_command_count_.set(P_.command_count, {10});
+        st_show_dur_.set(P_.show_dur, {3});
+        st_show_delay_.set(P_.show_delay, {1});
+        st_expl_dur_.set(P_.expl_dur, {variant == V_GRID ? 2 : 6});
+        st_expl_delay_.set(P_.expl_delay, {variant == V_GRID ? 6 : 18});
         P_.r_fail = 0.0;
         P_.r_succ = 0.1;
         P_.r_ep_succ = 0.0;
@@ -531,6 +537,7 @@ class MortarFamily : public Family {
         cmds_.alloc((size_t)n * P_.cmd_cap);
         desc_.alloc(n);
         rng_.alloc(n);
+        err_.alloc();
         hipLaunchKernelGGL(mortar_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, state_.p);
         MG_HIP(hipDeviceSynchronize());
         rebuild();
@@ -548,14 +555,16 @@ class MortarFamily : public Family {
     void set_option(const std::string& key, const double* v, int n) override {
         const bool endless = P_.variant == V_ENDLESS;
         auto scalar_i = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
-        auto list = [&](OptList& l, int lo, int hi) {
-            if (n < 1 || n > 8) throw OptionError{-3, "option " + key + ": lists of 1..8 values are supported"};
-            l.n = n;
+        // "sample one per episode" lists of any length (np_random.choice, e.g. mortar_mayhem_grid.py:181,253-254,268-269)
+        auto list = [&](OptList& l, OptListStore& st, int lo, int hi) {
+            if (n < 1) throw OptionError{-3, "option " + key + ": an empty list cannot be sampled"};
+            std::vector<int> vals(n);
             for (int i = 0; i < n; ++i) {
-                l.v[i] = to_int_checked(v[i], key.c_str());
-                if (l.v[i] < lo || l.v[i] > hi)
-                    throw OptionError{-3, "option " + key + ": value out of the supported range"};
+                vals[i] = to_int_checked(v[i], key.c_str());
+                if (vals[i] < lo || vals[i] > hi)
+                    throw OptionError{-3, "option " + key + ": value out of the supported range " + std::to_string(lo) + ".." + std::to_string(hi)};
             }
+            st.set(l, vals);
         };
         if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
         else if (key == "allowed_commands") {
@@ -563,10 +572,10 @@ class MortarFamily : public Family {
             if (a < 4 || a > 9) throw OptionError{-4, "assert 4 <= allowed_commands <= 9"};
             P_.allowed = a;
         }
-        else if (!P_.taskb && key == "command_show_duration") list(P_.show_dur, 1, 100);
-        else if (!P_.taskb && key == "command_show_delay") list(P_.show_delay, 0, 100);
-        else if (key == "explosion_duration") list(P_.expl_dur, 1, 200);
-        else if (key == "explosion_delay") list(P_.expl_delay, 1, 200);
+        else if (!P_.taskb && key == "command_show_duration") list(P_.show_dur, st_show_dur_, 1, 100);
+        else if (!P_.taskb && key == "command_show_delay") list(P_.show_delay, st_show_delay_, 0, 100);
+        else if (key == "explosion_duration") list(P_.expl_dur, st_expl_dur_, 1, 200);
+        else if (key == "explosion_delay") list(P_.expl_delay, st_expl_delay_, 1, 200);
         else if (key == "visual_feedback") P_.visual_feedback = v[0] != 0.0;
         else if (key == "reward_command_failure") P_.r_fail = v[0];
         else if (key == "reward_command_success") P_.r_succ = v[0];
@@ -583,7 +592,7 @@ class MortarFamily : public Family {
             P_.N = a;
             dirty_ = true;
         }
-        else if (!endless && key == "command_count") list(P_.command_count, 1, P_.taskb ? VEC_DIM / 9 : P_.cmd_cap);
+        else if (!endless && key == "command_count") list(P_.command_count, st_command_count_, 1, P_.taskb ? VEC_DIM / 9 : P_.cmd_cap);
         else if (!endless && key == "reward_episode_success") P_.r_ep_succ = v[0];
         else if (P_.variant != V_GRID && key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
         else throw OptionError{-2, "unknown reset parameter " + key};
@@ -620,12 +629,13 @@ class MortarFamily : public Family {
     }
 
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+    int poll_errors() override {
+        MG_HIP(hipDeviceSynchronize());
+        return err_.take();
+    }
+    int peek_errors() override { return err_.peek(); }
 
    private:
-    static void set_list(OptList& l, std::initializer_list<int> v) {
-        l.n = 0;
-        for (int x : v) l.v[l.n++] = x;
-    }
     MortarIO io() {
         MortarIO o;
         o.state = state_.p;
@@ -633,6 +643,7 @@ class MortarFamily : public Family {
         o.rng = rng_.view();
         o.desc = desc_.p;
         o.vec = vec_;
+        o.err = err_.dev;
         return o;
     }
 
@@ -706,6 +717,8 @@ class MortarFamily : public Family {
     DevArray<uint8_t> cmds_;
     DevArray<MortarDesc> desc_;
     RngStore rng_;
+    ErrorWord err_;
+    OptListStore st_command_count_, st_show_dur_, st_show_delay_, st_expl_dur_, st_expl_delay_;
 };
 
 Family* make_mortar(int variant, int num_envs) { return new MortarFamily(variant, num_envs); }

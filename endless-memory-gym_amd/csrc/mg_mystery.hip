@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         if (!defer) serve_mp(W, req, g, io.err, len, pm, io.walls, i);
         if (reset_me) {
             mp_post_reset(P, s, req, len, pm, d);  // (deferred: path_mask / path_len are filled in by mp_path_kernel)
-            if (defer) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+            if (defer) queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         }
     }
     if (active) {
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
         path_ws_init(smem);
         const PathWS W{smem};
         const bool me = (threadIdx.x & 63) == 0;
-        const int count = io.qctr[QC_COUNT];
+        const int count = queue_count(&io.qctr[QC_COUNT], n);
         const int waves = PATH_WGS * (blockDim.x >> 6);
         int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
         while (idx < count) {
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
         if (MysteryComposer::skip(d)) continue;
         MysteryComposer::compose(d, R);
         __syncthreads();
-        store_frame<FMT>(smem, obs, env, tid);
+        store_frame<FMT, false>(smem, obs, env, tid);
         __syncthreads();
     }
 }
@@ -1088,14 +1088,14 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryI
     int nx = 0, ny = 0;
     if (emp_step_a(P, i, s, actions, nx, ny)) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         io.core[i] = s;
-        io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i | EMP_Q_SEGMENT;
+        queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
         io.desc[i].valid = DESC_QUEUED;  // (the rest of the descriptor is last step's)
         return;
     }
     MysteryDesc d;
     const bool q = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
     if (q) {
-        io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+        queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         d.valid = DESC_QUEUED;
     }
     io.core[i] = s;
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryI
 __global__ __launch_bounds__(256) void emp_enqueue_kernel(int n, MysteryIO io, const uint8_t* mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (mask[i]) io.queue[atomicAdd(&io.qctr[QC_COUNT], 1)] = i;
+    if (mask[i]) queue_push(io.queue, &io.qctr[QC_COUNT], n, i, io.err);
     else io.desc[i].valid = 0;
 }
 
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
     path_ws_init(smem);
     const PathWS W{smem};
     const bool me = (threadIdx.x & 63) == 0;
-    const int count = all ? P.n : io.qctr[QC_COUNT];
+    const int count = all ? P.n : queue_count(&io.qctr[QC_COUNT], P.n);
     // the first entry of wave w is entry w (no atomic: with thousands of idle waves the same-address atomics of their
     // failing pops were the launch time); later ones are popped from a shared counter that starts after the last wave
     const int waves = gridDim.x * (blockDim.x >> 6);
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
         const PathWS W{ws};
         const int wv = tid >> 6;
         const bool me = (tid & 63) == 0;
-        const int count = io.qctr[QC_COUNT];
+        const int count = queue_count(&io.qctr[QC_COUNT], n);
         const int waves = svc * 4;
         int idx = bcast((int)(blockIdx.x * 4 + wv), 0);
         for (;;) {
@@ -1429,10 +1429,11 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
                 any = true;
                 MysteryComposer::compose(&sdesc[w], R);
                 __syncthreads();
-                store_frame<FMT>(smem, obs, e, tid);
+                store_frame<FMT, false>(smem, obs, e, tid);
                 __syncthreads();
             }
             if (!any) break;
+            __syncthreads();  // served[] / sdesc[] are rewritten by the next round: every wave has finished reading them
         }
         if (tid == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == svc - 1) {  // last service workgroup out
             io.qctr[QC_COUNT] = 0;
@@ -1447,7 +1448,7 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
         if (d->valid != 1) continue;  // masked, or drawn by the workgroup that serves its queue entry
         MysteryComposer::compose(d, R);
         __syncthreads();
-        store_frame<FMT>(smem, obs, env, tid);
+        store_frame<FMT, false>(smem, obs, env, tid);
         __syncthreads();
     }
 }
@@ -1472,8 +1473,7 @@ class MysteryFamily : public Family {
         } else {
             P_.max_steps = P_.grid ? 128 : 512;
             if (P_.grid) P_.r_progress = 0.0;
-            P_.cardinal.n = 4;
-            for (int k = 0; k < 4; ++k) P_.cardinal.v[k] = k;
+            st_cardinal_.set(P_.cardinal, {0, 1, 2, 3});
             P_.r_goal = 1.0;
         }
         core_.alloc(n);
@@ -1521,9 +1521,13 @@ class MysteryFamily : public Family {
         else if (e && key == "stamina_level") { I(P_.stamina_level); must_be(P_.stamina_level > 0); }
         else if (e && key == "reward_path_progress_dense") P_.r_dense = v[0];
         else if (!e && key == "cardinal_origin_choice") {
-            must_be(n >= 1 && n <= 8);
-            P_.cardinal.n = n;
-            for (int k = 0; k < n; ++k) P_.cardinal.v[k] = to_int_checked(v[k], key.c_str());
+            must_be(n >= 1);  // any length; every value other than 0, 1, 2 takes the reference's `else` branch (mystery_path.py:155-166)
+            std::vector<int> vals(n);
+            for (int k = 0; k < n; ++k) {
+                const int c = to_int_checked(v[k], key.c_str());
+                vals[k] = (c >= 0 && c <= 2) ? c : 3;
+            }
+            st_cardinal_.set(P_.cardinal, vals);
         }
         else if (!e && key == "show_goal") B(P_.show_goal);
         else if (!e && key == "reward_goal") P_.r_goal = v[0];
@@ -1747,6 +1751,7 @@ class MysteryFamily : public Family {
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
     RngStore rng_;
+    OptListStore st_cardinal_;
 };
 
 void MysteryFamily::raster_debug(void* frames, hipStream_t s) {

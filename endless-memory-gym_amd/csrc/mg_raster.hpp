@@ -25,6 +25,7 @@
 
 #include "../../include/memgym.h"
 #include "mg_device.hpp"
+#include "mg_stream_out.hpp"
 
 namespace mg {
 
@@ -45,7 +46,6 @@ constexpr int DISC_RMAX = 64;
 constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
-constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
 constexpr int RASTER_GRID = 256 * 7 * 8;      // persistent workgroups; flat between 10,752 and 14,336 at five resident workgroups per CU
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
 constexpr int RASTER_LDS_REQUEST = 28 * 1024;  // uint8 format: see launch_raster
@@ -92,8 +92,6 @@ __device__ __forceinline__ void put_rgb(uint8_t* frame, int x, int y, uint32_t r
     p[1] = (uint8_t)(rgb >> 8);
     p[2] = (uint8_t)(rgb >> 16);
 }
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct (HIP's uint4 class members end up in scratch)
 
 // d - floor(d * a / 255) for the four bytes of a dword (SDL ALPHA_BLEND_RGB towards black), two bytes at a time in
 // 16-bit lanes: t = d*a <= 65025 and t + 1 + (t >> 8) <= 65280 never carry into the neighbouring lane, and
@@ -302,84 +300,14 @@ __device__ __forceinline__ void templ_apply_dark(const RasterCtx& R, const Templ
 // inside compose() could only be consumed after the previous frame's stores had drained).  A software-pipelined loop
 // (frame i+1's prefetch issued before frame i's stores) was built and measured: no gain over this simple loop for the
 // spotlight frames, a loss for the mortar frames (profiles/r01c_raster_generations.md).
-// ---- frame stream-out ---------------------------------------------------------------------------------------
-// MG_OBS_U8_XYC: the reference's observation, pygame.surfarray.array3d order [x][y][c] uint8 (21,168 B = 1,323 x 16 B).
-// MG_OBS_F32_CYX / MG_OBS_F16_CYX: what a trainer builds from it before its CNN: value / 255 as
-// float32 / float16 in image order [c][y][x].  The transpose is done LDS-side (byte gathers, stride 252 B), the
-// global stores stay contiguous 16-B vectors.
-// 16-bit element of the half formats: IEEE half, or bfloat16 = the float32 quotient rounded to nearest even
-template <int FMT>
-__device__ __forceinline__ uint16_t to_half16(float q) {
-    if constexpr (FMT == MG_OBS_BF16_CYX) {
-        const uint32_t b = __float_as_uint(q);
-        return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
-    } else {
-        union { _Float16 h; uint16_t u; } c;
-        c.h = (_Float16)q;
-        return c.u;
-    }
-}
-
-// b / 255 as the correctly rounded float32 quotient, without the ~10 instructions of an IEEE division: the rounded
-// reciprocal, one residual, one correction (Markstein); equal to the division for all 256 bytes (tests/test_unit_division.py)
-__device__ __forceinline__ float byte_to_unit(uint8_t b) {
-    const float v = (float)b, r = 1.0f / 255.0f;
-    const float q0 = v * r;
-    return __fmaf_rn(__fmaf_rn(-q0, 255.0f, v), r, q0);
-}
-
-template <int FMT>
-__device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
-    if constexpr (FMT == MG_OBS_U8_XYC) {
-        const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
-        u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
-        u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
-        u32x4 v5 = (u32x4)(0u);
-        if (tid < TAIL) v5 = lds16[tid + 1280];
-        // non-temporal stores: the observation stream does not displace the logic kernel's state and descriptors
-        // from L2 (spotlight workloads: raster -4 %, logic kernel -9 %; for the mortar frames of generation 1 the
-        // same hint costs 40 %, profiles/r01c_raster_generations.md)
+// Stream-out: mg_stream_out.hpp, with NON-TEMPORAL stores for the uint8 format -- the observation stream then does not
+// displace the logic kernel's state and descriptors from L2 (spotlight workloads: raster -4 %, logic kernel -9 %; for the
+// mortar frames of generation 1 the same hint costs 40 %, profiles/r01c_raster_generations.md).
 #ifdef MG_LAB_PLAIN_STORES  // measurement builds only
-        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
-        if (tid < TAIL) dst[tid + 1280] = v5;
+constexpr bool RASTER_NT = false;
 #else
-        __builtin_nontemporal_store(v0, &dst[tid]); __builtin_nontemporal_store(v1, &dst[tid + 256]);
-        __builtin_nontemporal_store(v2, &dst[tid + 512]); __builtin_nontemporal_store(v3, &dst[tid + 768]);
-        __builtin_nontemporal_store(v4, &dst[tid + 1024]);
-        if (tid < TAIL) __builtin_nontemporal_store(v5, &dst[tid + 1280]);
+constexpr bool RASTER_NT = true;
 #endif
-    } else if constexpr (FMT == MG_OBS_F32_CYX) {
-        float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
-        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame
-        for (int q = tid; q < TOTAL; q += 256) {
-            const int row = q / PER_ROW, x0 = (q - row * PER_ROW) * 4;
-            const int c = row / SCREEN, y = row - c * SCREEN;
-            const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
-            float4 v;
-            v.x = byte_to_unit(src[0]);
-            v.y = byte_to_unit(src[COL_BYTES]);
-            v.z = byte_to_unit(src[2 * COL_BYTES]);
-            v.w = byte_to_unit(src[3 * COL_BYTES]);
-            dst[q] = v;
-        }
-    } else {
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint16_t*>(obs) + (size_t)env * FRAME_BYTES);
-        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
-        for (int q = tid; q < TOTAL; q += 256) {
-            union { uint16_t h[8]; uint4 v; } u;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int qq = 2 * q + g;
-                const int row = qq / PER_ROW, x0 = (qq - row * PER_ROW) * 4;
-                const int c = row / SCREEN, y = row - c * SCREEN;
-                const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = to_half16<FMT>(byte_to_unit(src[k * COL_BYTES]));
-            }
-            dst[q] = u.v;
-        }
-    }
-}
 
 template <class Composer, int FMT>
 __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
@@ -402,7 +330,7 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
         Composer::compose(cdescs + env, P, R);
         __syncthreads();
         Composer::recycle(R);  // overlaps the stream-out, saves a barrier at the start of the next compose()
-        store_frame<FMT>(smem, obs, env, tid);
+        store_frame<FMT, RASTER_NT>(smem, obs, env, tid);
         __syncthreads();  // the LDS frame is reused by the next iteration
     }
 }

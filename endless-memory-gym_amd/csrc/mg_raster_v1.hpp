@@ -31,6 +31,7 @@
 
 #include "../../include/memgym.h"
 #include "mg_device.hpp"
+#include "mg_stream_out.hpp"
 
 namespace mg {
 namespace v1 {
@@ -38,7 +39,6 @@ namespace v1 {
 constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
-constexpr int TAIL = FRAME_VEC16 - 5 * 256;   // 43 lanes carry a sixth 16-byte chunk
 constexpr int RASTER_GRID = 256 * 7 * 8;      // persistent workgroups (bench sweep at seven per CU: best of 2..37 rounds)
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
 
@@ -158,69 +158,6 @@ __device__ __forceinline__ void rect(const RasterCtx& R, int x, int y, int w, in
     }
 }
 
-template <int FMT>
-__device__ __forceinline__ uint16_t to_half16(float q) {
-    if constexpr (FMT == MG_OBS_BF16_CYX) {
-        const uint32_t b = __float_as_uint(q);
-        return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
-    } else {
-        union { _Float16 h; uint16_t u; } c;
-        c.h = (_Float16)q;
-        return c.u;
-    }
-}
-
-// b / 255 as the correctly rounded float32 quotient, without the ~10 instructions of an IEEE division: the rounded
-// reciprocal, one residual, one correction (Markstein); equal to the division for all 256 bytes (tests/test_unit_division.py)
-__device__ __forceinline__ float byte_to_unit(uint8_t b) {
-    const float v = (float)b, r = 1.0f / 255.0f;
-    const float q0 = v * r;
-    return __fmaf_rn(__fmaf_rn(-q0, 255.0f, v), r, q0);
-}
-
-template <int FMT>
-__device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
-    if constexpr (FMT == MG_OBS_U8_XYC) {
-        const uint4* lds16 = reinterpret_cast<const uint4*>(frame);
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
-        uint4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
-        uint4 v5 = make_uint4(0, 0, 0, 0);
-        if (tid < TAIL) v5 = lds16[tid + 1280];
-        dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
-        if (tid < TAIL) dst[tid + 1280] = v5;
-    } else if constexpr (FMT == MG_OBS_F32_CYX) {
-        float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
-        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame
-        for (int q = tid; q < TOTAL; q += 256) {
-            const int row = q / PER_ROW, x0 = (q - row * PER_ROW) * 4;
-            const int c = row / SCREEN, y = row - c * SCREEN;
-            const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
-            float4 v;
-            v.x = byte_to_unit(src[0]);
-            v.y = byte_to_unit(src[COL_BYTES]);
-            v.z = byte_to_unit(src[2 * COL_BYTES]);
-            v.w = byte_to_unit(src[3 * COL_BYTES]);
-            dst[q] = v;
-        }
-    } else {
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint16_t*>(obs) + (size_t)env * FRAME_BYTES);
-        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
-        for (int q = tid; q < TOTAL; q += 256) {
-            union { uint16_t h[8]; uint4 v; } u;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int qq = 2 * q + g;
-                const int row = qq / PER_ROW, x0 = (qq - row * PER_ROW) * 4;
-                const int c = row / SCREEN, y = row - c * SCREEN;
-                const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = to_half16<FMT>(byte_to_unit(src[k * COL_BYTES]));
-            }
-            dst[q] = u.v;
-        }
-    }
-}
-
 #ifdef MG_LAB  // measurement builds only (tools/placement_lab.py): window k of the frame walk is displaced by g_lab_win_off[k] bytes
 static __device__ long long g_lab_win_off[16];
 #endif
@@ -242,9 +179,9 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
         Composer::compose(d, R);
         __syncthreads();
 #ifdef MG_LAB
-        store_frame<FMT>(smem, static_cast<uint8_t*>(obs) + g_lab_win_off[(env / (int)gridDim.x) & 15], env, tid);
+        store_frame<FMT, false>(smem, static_cast<uint8_t*>(obs) + g_lab_win_off[(env / (int)gridDim.x) & 15], env, tid);
 #else
-        store_frame<FMT>(smem, obs, env, tid);
+        store_frame<FMT, false>(smem, obs, env, tid);  // plain stores (mg_stream_out.hpp)
 #endif
         __syncthreads();  // the LDS frame is reused by the next iteration
     }

@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     // frame; state, stream and the descriptor head (its n_holes are the reset frame's stale holes) are stored as after
     // any other step, exactly what a masked mg_reset(seed = None) would find.
     const bool reset_me = done && autoreset;
-    if (defer && reset_me && leader) io.queue[atomicAdd(&io.qctr[SQ_COUNT], 1)] = i;
+    if (defer && reset_me && leader) queue_push(io.queue, &io.qctr[SQ_COUNT], P.n, i, io.err);
     if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
         spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh);
     } else {
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
     const int tid = threadIdx.x;
     const cptr<SpotDesc> cdescs = as_const(descs);
     const bool service = (int)blockIdx.x < SPOT_SVC_WGS;
-    const int count = service ? io.qctr[SQ_COUNT] : 0;
+    const int count = service ? queue_count(&io.qctr[SQ_COUNT], n) : 0;
     if (service && (int)blockIdx.x * SPOT_SVC_BATCH >= count) return;
     Composer::recycle(R);
     __syncthreads();
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
         Composer::compose(cdescs + env, Pq, R);
         __syncthreads();
         Composer::recycle(R);
-        store_frame<MG_OBS_U8_XYC>(smem, obs, env, tid);
+        store_frame<MG_OBS_U8_XYC, RASTER_NT>(smem, obs, env, tid);
         __syncthreads();
     };
     if (service) {
@@ -1097,7 +1097,7 @@ class SpotFamily : public Family {
         } else {
             P_.max_steps = 256; P_.initial_spawns = 4; P_.num_spawns = 30;
             initial_spawn_interval_ = 30; spawn_interval_threshold_ = 10;
-            P_.num_coins.n = 1; P_.num_coins.v[0] = 1; P_.agent_health = 5; P_.r_exit = 1.0;
+            st_num_coins_.set(P_.num_coins, {1}); P_.agent_health = 5; P_.r_exit = 1.0;
         }
         core_.alloc(n);
         for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) a->alloc((size_t)SLOTS * n);
@@ -1190,12 +1190,14 @@ class SpotFamily : public Family {
         else if (!e && key == "spawn_interval_threshold") { spawn_interval_threshold_ = v[0]; dirty_ = true; }
         else if (!e && key == "spawn_interval_decay") { /* only intervals[0] is ever read (pop() takes the last) */ }
         else if (!e && key == "num_coins") {
-            must_be(n >= 1 && n <= 8);
-            P_.num_coins.n = n;
+            // any length (searing_spotlights.py:408); the empty list is refused by mg_set_option: the reference ends every such
+            // episode with a ZeroDivisionError (searing_spotlights.py:553)
+            std::vector<int> vals(n);
             for (int k = 0; k < n; ++k) {
-                P_.num_coins.v[k] = to_int_checked(v[k], key.c_str());
-                must_be(P_.num_coins.v[k] >= 1 && P_.num_coins.v[k] <= MAX_COINS);
+                vals[k] = to_int_checked(v[k], key.c_str());
+                must_be(vals[k] >= 1 && vals[k] <= MAX_COINS);
             }
+            st_num_coins_.set(P_.num_coins, vals);
         }
         else if (!e && key == "use_exit") must_be(v[0] != 0.0);  // use_exit=False crashes the reference itself
         else if (!e && key == "exit_scale") { exit_scale_ = v[0]; dirty_ = true; }
@@ -1369,6 +1371,7 @@ class SpotFamily : public Family {
     DevArray<SpotDesc> desc_;
     ErrorWord err_;
     RngStore rng_;
+    OptListStore st_num_coins_;
 };
 
 void SpotFamily::raster_debug(void* frames, hipStream_t s) {

@@ -1,0 +1,96 @@
+// mg_stream_out.hpp -- the ONE frame stream-out both raster generations use (mg_raster_v1.hpp, mg_raster.hpp).
+//
+// A composed 84x84x3 frame sits in LDS in the reference's observation order ([x][y][c] uint8, what
+// pygame.surfarray.array3d returns, e.g. memory_gym/mortar_mayhem_grid.py:277,372); store_frame writes it to the
+// caller's observation buffer in the format chosen with mg_set_obs_format:
+//   MG_OBS_U8_XYC    1,323 x 16-byte stores, lane-contiguous (1 KiB per wave instruction), the headline format;
+//   MG_OBS_F32_CYX / MG_OBS_F16_CYX / MG_OBS_BF16_CYX   value / 255 in image order [c][y][x]: the
+//                    transpose is done LDS-side (byte gathers, stride 252 B), the global stores stay 16-byte vectors.
+// NT (uint8 format only): non-temporal stores.  The hint is a per-generation measurement, not a taste: the spotlight
+// frames (generation 2) gain 4 % and their logic kernel 9 % because the observation stream stops displacing state and
+// descriptors from L2; the mortar frames (generation 1) LOSE 40 % with it (profiles/r01c_raster_generations.md).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/memgym.h"
+#include "mg_device.hpp"
+
+namespace mg {
+
+constexpr int TAIL = FRAME_VEC16 - 5 * 256;  // 43 lanes of a 256-lane workgroup carry a sixth 16-byte chunk
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct (HIP's uint4 class members end up in scratch)
+
+// 16-bit element of the half formats: IEEE half, or bfloat16 = the float32 quotient rounded to nearest even
+template <int FMT>
+__device__ __forceinline__ uint16_t to_half16(float q) {
+    if constexpr (FMT == MG_OBS_BF16_CYX) {
+        const uint32_t b = __float_as_uint(q);
+        return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+    } else {
+        union { _Float16 h; uint16_t u; } c;
+        c.h = (_Float16)q;
+        return c.u;
+    }
+}
+
+// b / 255 as the correctly rounded float32 quotient, without the ~10 instructions of an IEEE division: the rounded
+// reciprocal, one residual, one correction (Markstein); equal to the division for all 256 bytes (tests/test_unit_division.py)
+__device__ __forceinline__ float byte_to_unit(uint8_t b) {
+    const float v = (float)b, r = 1.0f / 255.0f;
+    const float q0 = v * r;
+    return __fmaf_rn(__fmaf_rn(-q0, 255.0f, v), r, q0);
+}
+
+template <int FMT, bool NT>
+__device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
+    if constexpr (FMT == MG_OBS_U8_XYC) {
+        const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
+        u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
+        u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
+        u32x4 v5 = (u32x4)(0u);
+        if (tid < TAIL) v5 = lds16[tid + 1280];
+        if constexpr (NT) {
+            __builtin_nontemporal_store(v0, &dst[tid]); __builtin_nontemporal_store(v1, &dst[tid + 256]);
+            __builtin_nontemporal_store(v2, &dst[tid + 512]); __builtin_nontemporal_store(v3, &dst[tid + 768]);
+            __builtin_nontemporal_store(v4, &dst[tid + 1024]);
+            if (tid < TAIL) __builtin_nontemporal_store(v5, &dst[tid + 1280]);
+        } else {
+            dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
+            if (tid < TAIL) dst[tid + 1280] = v5;
+        }
+    } else if constexpr (FMT == MG_OBS_F32_CYX) {
+        float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW;  // 21 float4 per (c, y) row, 5,292 per frame
+        for (int q = tid; q < TOTAL; q += 256) {
+            const int row = q / PER_ROW, x0 = (q - row * PER_ROW) * 4;
+            const int c = row / SCREEN, y = row - c * SCREEN;
+            const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+            float4 v;
+            v.x = byte_to_unit(src[0]);
+            v.y = byte_to_unit(src[COL_BYTES]);
+            v.z = byte_to_unit(src[2 * COL_BYTES]);
+            v.w = byte_to_unit(src[3 * COL_BYTES]);
+            dst[q] = v;
+        }
+    } else {
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint16_t*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
+        for (int q = tid; q < TOTAL; q += 256) {
+            union { uint16_t h[8]; uint4 v; } u;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int qq = 2 * q + g;
+                const int row = qq / PER_ROW, x0 = (qq - row * PER_ROW) * 4;
+                const int c = row / SCREEN, y = row - c * SCREEN;
+                const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = to_half16<FMT>(byte_to_unit(src[k * COL_BYTES]));
+            }
+            dst[q] = u.v;
+        }
+    }
+}
+
+}  // namespace mg

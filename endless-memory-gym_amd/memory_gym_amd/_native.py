@@ -17,7 +17,7 @@ MG_INFO_SLOTS = 8
 
 
 class InfoBuffers(C.Structure):
-    _fields_ = [("ep_reward_dev", C.c_void_p), ("ep_length_dev", C.c_void_p), ("aux_dev", C.c_void_p * MG_INFO_SLOTS),
+    _fields_ = [("struct_size", C.c_size_t), ("ep_reward_dev", C.c_void_p), ("ep_length_dev", C.c_void_p), ("aux_dev", C.c_void_p * MG_INFO_SLOTS),
                 ("final_obs_dev", C.c_void_p), ("reward64_dev", C.c_void_p)]
 
 

@@ -171,6 +171,7 @@ class VecMemoryGym:
             self.info_names.append(nm.decode())
         self.aux = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in self.info_names]
         self._info = _native.InfoBuffers()
+        self._info.struct_size = C.sizeof(_native.InfoBuffers)
         self._err = C.c_int(0)
         self._info.ep_reward_dev = self.ep_reward.data_ptr()
         self._info.ep_length_dev = self.ep_length.data_ptr()
@@ -324,7 +325,9 @@ class VecMemoryGym:
     ERROR_BITS = {1: "more than 16 live spotlights in one instance (raise spawn_interval / spot speeds or lower initial_spawns)",
                   2: "path generation found no valid path (pygame_assets.py:723-724 raises here too)",
                   4: "endless path longer than 128 segments", 8: "more than 128 distinct fall-off cells",
-                  16: "past-path window wider than 16 columns"}
+                  16: "past-path window wider than 16 columns",
+                  32: "Endless Mortar Mayhem command list reached its 512-entry capacity (the episode was ended)",
+                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)"}
 
     def check_errors(self):
         """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device).

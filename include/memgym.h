@@ -32,6 +32,10 @@ typedef struct mg_env mg_env;
  * `info` dict returned on the terminal step, e.g. mortar_mayhem_grid.py:356-362).  Device SoA,
  * all arrays [num_envs]; any pointer may be NULL.  `aux[k]` meaning per env id: see mg_info_name(). */
 typedef struct mg_info_buffers {
+    /* Versioning: set to sizeof(mg_info_buffers) of the header the caller was built against.  The library reads that many
+     * bytes (never more than it knows) and treats the fields a shorter, older struct lacks as NULL; 0 or any size that
+     * cannot be a layout of this header is refused (-1) instead of the struct being read past its end. */
+    size_t struct_size;
     double* ep_reward_dev;         /* "reward": Python sum() of the step rewards, in double        */
     int32_t* ep_length_dev;        /* "length"                                                      */
     float* aux_dev[MG_INFO_SLOTS]; /* "success", "commands_completed", "num_fails", ... per env id */
@@ -111,9 +115,10 @@ int mg_render(mg_env* env, void* obs_dev, void* stream);
 /* Env.render() with render_mode "debug_rgb_array" (e.g. mortar_mayhem_grid.py:403-405 -> _build_debug_surface :104-135)
  * for every instance: the ground-truth view (target tile ring / whole path and walls / everything the spotlight layer
  * hides drawn over it), stretched to 336 x 336 like pygame.transform.scale, in IMAGE order:
- * rgb_dev uint8 [num_envs][336 y][336 x][3].  No state changes.  The command glyph of the mortar family follows the
- * reference's clone of the visualisation list under the assumption of one render per reset / step (what a recording
- * loop does).  Synchronous (allocates and frees a scratch buffer); not a hot path. */
+ * rgb_dev uint8 [num_envs][336 y][336 x][3].  Changes nothing the observations, rewards or RNG streams depend on; the
+ * only state it touches is the mortar family's counter of entries popped from the reference's CLONE of the command
+ * visualisation list (mortar_mayhem_grid.py:122: every debug render pops one), so that zero, one or several renders
+ * between steps show what the reference shows.  Synchronous (allocates and frees a scratch buffer); not a hot path. */
 int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream);
 
 /* Env.step(action) (e.g. mortar_mayhem_grid.py:280-375) for all instances.
@@ -127,7 +132,11 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
             float* gt_dev, const mg_info_buffers* info, int autoreset, void* stream);
 
 /* Checkpoint hooks (the reference cannot serialise an env; SoA state makes it free).  Synchronous.
- * mg_state_size: bytes needed.  Layout is private to one library build. */
+ * mg_state_size: bytes needed.  The blob starts with a 64-byte header {magic "MGSTATE1", MG_STATE_VERSION, num_envs,
+ * payload bytes, FNV-1a of the env id}; the layout behind it is private to one MG_STATE_VERSION.  mg_set_state refuses
+ * (-1, message in mg_last_error) a blob whose magic, version, env id, num_envs or payload size differ from the handle's
+ * instead of mis-assigning it. */
+#define MG_STATE_VERSION 3u
 size_t mg_state_size(const mg_env* env);
 int mg_get_state(mg_env* env, void* host_buf, size_t size);
 int mg_set_state(mg_env* env, const void* host_buf, size_t size);
@@ -144,7 +153,11 @@ int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
  * exceptions, e.g. pygame_assets.py:723-724 "No valid path found"); 0 = none.  Synchronous.
  *   1  spotlight slots exhausted (more than 16 live spotlights)      2  path generation found no valid path
  *   4  endless path longer than 128 segments                         8  more than 128 distinct fall-off cells
- *  16  past-path window wider than 16 columns */
+ *  16  past-path window wider than 16 columns
+ *  32  Endless Mortar Mayhem: the command list reached its capacity of 512 entries (the reference's list is unbounded,
+ *      endless_mortar_mayhem.py:316-318); the episode of that instance was ended
+ *  64  a deferred-reset queue was found over-full (an earlier fused launch failed before draining it); the excess
+ *      entries were dropped */
 int mg_poll_errors(mg_env* env, int* flags);
 
 /* The same bits as they stand right now: no synchronisation, nothing cleared.  The error word lives in pinned host

@@ -101,6 +101,14 @@ int mgo_render_debug(mgo_env* e, uint8_t* out) {
     return 0;
 }
 
+/* test hook: see mgo_vtbl.scene */
+int mgo_scene(mgo_env* e, const double* v, int n, uint8_t* obs) {
+    if (!e->vt->scene || !e->seeded) return -1;
+    int rc = e->vt->scene(e, v, n);
+    if (rc == 0 && obs) mgo_array3d(e->screen, obs);
+    return rc;
+}
+
 double mgo_get(mgo_env* e, const char* field, int* ok) {
     int k = 0;
     double v = e->vt->get(e, field, &k);

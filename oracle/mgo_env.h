@@ -192,6 +192,11 @@ typedef struct mgo_vtbl {
     void (*destroy)(struct mgo_env*);
     /* render("debug_rgb_array"): _build_debug_surface before its final transform.scale; dst is screen_dim x screen_dim */
     void (*debug)(struct mgo_env*, mgo_surf* dst);
+    /* Test hook (tests/test_oracle_old_gif_replay.py): put the instance into a given SCENE -- agent position / sprite, tile
+     * states, cross, coins, exit, spotlight discs ... (family-specific vector, see each file) -- and draw the frame with the
+     * family's own _draw_surfaces code.  Used to replay recordings of OTHER revisions of the reference frame by frame:
+     * their dynamics differ, the drawing of a given scene does not.  NULL: not offered.  Requires one reset. */
+    int (*scene)(struct mgo_env*, const double* v, int n);
 } mgo_vtbl;
 
 typedef struct mgo_env {

@@ -17,7 +17,7 @@ enum { MM_GRID = 0, MM_FREE = 1, MM_ENDLESS = 2, MM_B_GRID = 3, MM_B_FREE = 4 };
 #define MM_IS_GRID(v) ((v) == MM_GRID || (v) == MM_B_GRID)
 /* _encode_commands_one_hot (mortar_mayhem_b_grid.py:100-129): slot of each Command.COMMANDS id inside a block of 9 */
 static const int CMD_ONE_HOT[9] = {1, 4, 2, 3, 0, 5, 6, 7, 8};
-#define MM_MAXLIST 8
+#define MM_MAXLIST 256 /* the reference samples from lists of any length; 256 covers every fixture */
 
 static const int CMD_DX[9] = {1, 0, -1, 0, 0, 1, 1, -1, -1}; /* Command.COMMANDS (pygame_assets.py:242-252) */
 static const int CMD_DY[9] = {0, 1, 0, -1, 0, 1, -1, 1, -1};
@@ -54,7 +54,7 @@ typedef struct {
     int num_commands, cmds_cap;
     int* vis; /* _command_visualization, entries 0..8 or 9 for "" */
     int vis_head, vis_len, vis_cap;
-    int dbg_lead; /* render(): _command_visualization_clone runs one entry ahead after an endless regeneration */
+    int clone_pops; /* render(): entries popped so far from _command_visualization_clone (copied at reset and at an endless regeneration) */
     int glyph; /* glyph drawn in the last frame (-1 none) */
     mgo_surf* glyph_surf[10];
     int tx, ty, cur_cmd, cmd_steps, verify_step, total_completed, t;
@@ -165,9 +165,9 @@ static void mm_draw_frame(mgo_env* e, mm_t* m, mgo_surf* agent_surf, const mgo_r
 /* _build_debug_surface (mortar_mayhem_grid.py:104-135, mortar_mayhem.py:105-136, endless_mortar_mayhem.py:114-145): arena,
  * agent, a command glyph and a green ring around the target tile.  The glyph comes from a CLONE of the visualisation list
  * (copied when the list is made: reset :237/:257, endless regeneration :321) of which every debug render pops one entry
- * while the real list is not empty.  With one render() per reset()/step() -- what a recording loop does, and what this
- * restatement assumes -- that is entry (entries popped from the real list - 1 + lead), lead = 1 after a regeneration
- * (the clone is copied in a step that pops nothing), shown only while the real list still holds entries. */
+ * while the real list is not empty: clone_pops counts them, so any number of renders between steps (none, one as in a
+ * recording loop, several) shows what the reference shows.  The reference raises IndexError once the clone is empty while
+ * the real list is not (more renders than steps); here no glyph is drawn then. */
 static void mm_debug(mgo_env* e, mgo_surf* dst) {
     mm_t* m = (mm_t*)e->impl;
     mgo_fill(dst, 0);
@@ -179,7 +179,7 @@ static void mm_debug(mgo_env* e, mgo_surf* dst) {
         mgo_blit(dst, m->agent.sprites[0], m->agent.rect.x, m->agent.rect.y);
     }
     if (m->vis_head < m->vis_len) {
-        int idx = m->vis_head - 1 + m->dbg_lead, g = idx >= 0 && idx < m->vis_len ? m->vis[idx] : 9;
+        int idx = m->clone_pops++, g = idx >= 0 && idx < m->vis_len ? m->vis[idx] : 9;
         if (g >= 0 && g < 9) { /* 9 = "" (delay frames) */
             double rect_dim = 88 * e->scale;
             int p = (int)((e->screen_dim / 2) - floor(rect_dim / 2));
@@ -190,6 +190,20 @@ static void mm_debug(mgo_env* e, mgo_surf* dst) {
     double tr = mgo_rect_cx(&m->arena_rect) - m->local_cx + floor(m->tile_dim / 2);
     int px = (int)(m->tile_dim * m->tx + tr), py = (int)(m->tile_dim * m->ty + tr);
     mgo_draw_circle(dst, MGO_RGB(0, 255, 0), px, py, (int)floor(m->tile_dim / 2), (int)(8 * e->scale));
+}
+
+/* scene hook: v = {ax, ay, sprite (0..7, -1 none), tiles_on, tx, ty, glyph (0..8, 9 blank, -1 none)} */
+static int mm_scene(mgo_env* e, const double* v, int n) {
+    mm_t* m = (mm_t*)e->impl;
+    if (n < 7) return -1;
+    mgo_rect_set_center(&m->agent.rect, v[0], v[1]);
+    const int sprite = (int)v[2], on = (int)v[3], glyph = (int)v[6];
+    mm_toggle_tiles(m, e->scale, 0, 0, 0, 1);
+    m->tx = (int)v[4];
+    m->ty = (int)v[5];
+    if (on) mm_toggle_tiles(m, e->scale, 1, m->tx, m->ty, 1);
+    mm_draw_frame(e, m, sprite >= 0 ? m->agent.sprites[sprite & 7] : NULL, &m->agent.rect, glyph);
+    return 0;
 }
 
 static void mm_set_disp(mm_t* m, int sprite, int rect_is_agent) {
@@ -311,7 +325,7 @@ static void mm_reset(mgo_env* e) {
         m->show_dur = (int)mm_choice(e, m->show_duration, m->n_show_duration);
         m->show_delay_v = (int)mm_choice(e, m->show_delay, m->n_show_delay);
         mm_gen_vis(m, m->cmds, m->num_commands, m->show_dur, m->show_delay_v);
-        m->dbg_lead = 0;
+        m->clone_pops = 0;
         glyph = mm_vis_pop(m);
     }
 
@@ -386,7 +400,7 @@ static void mm_step(mgo_env* e, const int action[2]) {
                     m->cmd_steps = 0;
                     m->verify_step = 0;
                     mm_gen_vis(m, &nc, 1, m->show_dur, m->show_delay_v);
-                    m->dbg_lead = 1;
+                    m->clone_pops = 0;
                 } else {
                     done = 1;
                     success = 1;
@@ -530,11 +544,11 @@ static void mm_destroy(mgo_env* e) {
 }
 
 static const mgo_vtbl MM_VT[5] = {
-    {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
-    {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
-    {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
-    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
-    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug},
+    {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
+    {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
+    {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
+    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
+    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
 };
 
 int mgo_mortar_create(mgo_env* e, int variant) {

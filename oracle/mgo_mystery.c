@@ -12,7 +12,7 @@
 #include "mgo_env.h"
 
 #define G 7 /* grid_dim */
-#define MP_MAXLIST 8
+#define MP_MAXLIST 256
 
 typedef struct {
     int x, y, rvis, svis;
@@ -329,6 +329,24 @@ static void mpf_step(mgo_env* e, const int action[2]) {
     mgo_blit(e->screen, m->cross, m->cross_rect.x, m->cross_rect.y);
     e->reward = reward;
     e->done = done;
+}
+
+/* scene hook (finite variants): v = {ax, ay, sprite, cross_on, cross_cx, cross_cy, sx, sy, ex, ey, show_origin, show_goal} */
+static int mpf_scene(mgo_env* e, const double* v, int n) {
+    mp_t* m = (mp_t*)e->impl;
+    if (n < 12) return -1;
+    const int d = (int)m->tile_dim;
+    mgo_fill(m->path_surf, 0);
+    if ((int)v[11]) mgo_draw_rect(m->path_surf, MGO_RGB(0, 255, 0), (int)((int)v[8] * m->tile_dim), (int)((int)v[9] * m->tile_dim), d, d, 0);
+    if ((int)v[10]) mgo_draw_rect(m->path_surf, MGO_RGB(0, 0, 255), (int)((int)v[6] * m->tile_dim), (int)((int)v[7] * m->tile_dim), d, d, 0);
+    mgo_rect_set_center(&m->agent.rect, v[0], v[1]);
+    m->disp_sprite = (int)v[2] & 7;
+    mgo_set_alpha(m->cross, (int)v[3] ? 255 : 0);
+    mgo_rect_set_center(&m->cross_rect, v[4], v[5]);
+    mgo_blit(e->screen, m->path_surf, 0, 0);
+    mgo_blit(e->screen, m->agent.sprites[m->disp_sprite], m->agent.rect.x, m->agent.rect.y);
+    mgo_blit(e->screen, m->cross, m->cross_rect.x, m->cross_rect.y);
+    return 0;
 }
 
 /* ======================================== Endless-MysteryPath-v0 ======================================== */
@@ -687,9 +705,9 @@ static void mp_destroy(mgo_env* e) {
 }
 
 static const mgo_vtbl MP_VT[3] = {
-    {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug},
-    {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy, emp_debug},
-    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug},
+    {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug, mpf_scene},
+    {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy, emp_debug, NULL},
+    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug, mpf_scene},
 };
 
 int mgo_mystery_create(mgo_env* e, int variant) {

@@ -20,7 +20,7 @@
 
 #define SP_MAX 64
 #define SP_MAXCOINS 16
-#define SP_MAXLIST 8
+#define SP_MAXLIST 256
 
 typedef struct {
     double radius, speed, t;
@@ -305,6 +305,56 @@ static void sp_debug(mgo_env* e, mgo_surf* dst) {
     }
     mgo_blit(dst, p->top_bar, 0, 0);
     mgo_surf_free(coin);
+}
+
+/* scene hook: v = {bg_red, alpha, ax, ay, sprite, exit_x, exit_y, exit_open, n_coins, (x, y) * n_coins, n_spots,
+ * (x, y, radius) * n_spots}.  Coins / exit / spotlight surfaces are painted like reset() / step() paint them; the top bar
+ * is left as the last reset / step drew it. */
+static int sp_scene(mgo_env* e, const double* v, int n) {
+    sp_t* p = (sp_t*)e->impl;
+    if (n < 10) return -1;
+    int k = 0;
+    p->bg_is_red = (int)v[k++];
+    mgo_set_alpha(p->spot_surf, (int)v[k++]);
+    const int ax = (int)v[k++], ay = (int)v[k++];
+    mgo_rect_set_center(&p->agent.rect, ax, ay);
+    p->have_disp = 1;
+    p->disp_sprite = (int)v[k++] & 7;
+    p->disp_x = ax;
+    p->disp_y = ay;
+    if (!p->endless) {
+        p->exit_x = (int)v[k];
+        p->exit_y = (int)v[k + 1];
+        p->exit_open = !(int)v[k + 2]; /* force a repaint */
+        sp_exit_draw(e, p, (int)v[k + 2]);
+    }
+    k += 3;
+    const int nc = (int)v[k++];
+    if (nc < 0 || nc > SP_MAXCOINS || k + 2 * nc + 1 > n) return -1;
+    mgo_fill(p->coin_surf, 255);
+    mgo_set_colorkey(p->coin_surf, 255);
+    p->n_coins = nc;
+    if (!p->endless) p->num_coins = nc > p->num_coins ? nc : p->num_coins;
+    p->has_coin = nc > 0;
+    for (int i = 0; i < nc; i++) {
+        p->coin_x[i] = (int)v[k++];
+        p->coin_y[i] = (int)v[k++];
+        sp_draw_coin(p->coin_surf, p->coin_scale, p->coin_x[i], p->coin_y[i]);
+    }
+    const int ns = (int)v[k++];
+    if (ns < 0 || ns > SP_MAX || k + 3 * ns > n) return -1;
+    mgo_fill(p->spot_surf, 0);
+    p->n_spots = ns;
+    for (int i = 0; i < ns; i++) {
+        spot_t* s = &p->spots[i];
+        memset(s, 0, sizeof(*s));
+        s->cur_x = v[k++];
+        s->cur_y = v[k++];
+        s->radius = v[k++];
+        mgo_draw_circle(p->spot_surf, MGO_RGB(255, 0, 0), (int)s->cur_x, (int)s->cur_y, (int)s->radius, 0);
+    }
+    sp_compose(e, p, p->agent.sprites[p->disp_sprite]);
+    return 0;
 }
 
 static void sp_reset(mgo_env* e) {
@@ -702,8 +752,8 @@ static void sp_destroy(mgo_env* e) {
 }
 
 static const mgo_vtbl SP_VT[2] = {
-    {"SearingSpotlights-v0", 0, 0, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug},
-    {"Endless-SearingSpotlights-v0", 0, 4, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug},
+    {"SearingSpotlights-v0", 0, 0, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug, sp_scene},
+    {"Endless-SearingSpotlights-v0", 0, 4, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug, sp_scene},
 };
 
 int mgo_spot_create(mgo_env* e, int variant) {

@@ -388,6 +388,64 @@ SESSIONS = {
 }
 
 
+# `--long`: "sample one per episode" option lists LONGER than eight entries (the reference samples from any length:
+# mortar_mayhem_grid.py:181,253-254,268-269, mystery_path.py:154, searing_spotlights.py:408) -> tests/golden/long_<env>.npz.
+# 16-entry command_count lists, 40-entry duration lists (longer than the 32 entries the HIP path keeps in kernel arguments),
+# many short episodes so that many list positions are drawn.
+_CC16 = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 2, 3, 1, 4, 12, 5]
+_D40 = [2 + (7 * k) % 5 for k in range(40)]
+_L40 = [4 + (11 * k) % 9 for k in range(40)]
+LONG_SESSIONS = {
+    "MortarMayhem-Grid-v0": [
+        (11, dict(command_count=_CC16, command_show_duration=[1, 2, 3, 1, 2, 3, 1, 2, 3, 2], command_show_delay=[0, 1, 2, 0, 1, 2, 0, 1, 2],
+                  explosion_duration=_D40, explosion_delay=_L40), 0.9, 900),
+        (12, dict(arena_size=6, allowed_commands=9, command_count=list(range(1, 33)), explosion_duration=[2] * 33 + [3],
+                  explosion_delay=[4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]), 0.8, 900),
+    ],
+    "MortarMayhem-v0": [
+        (11, dict(command_count=_CC16, command_show_duration=[1, 2, 3, 4, 1, 2, 3, 4, 1, 2, 3], explosion_duration=[d + 2 for d in _D40],
+                  explosion_delay=[d + 8 for d in _L40]), 0.97, 1200),
+    ],
+    "Endless-MortarMayhem-v0": [
+        (11, dict(command_show_duration=[1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 1], command_show_delay=[0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 2, 2],
+                  explosion_duration=[d + 2 for d in _D40], explosion_delay=[d + 8 for d in _L40]), 0.6, 1500),
+    ],
+    "MortarMayhemB-Grid-v0": [
+        (11, dict(command_count=_CC16 + [20, 18], explosion_duration=_D40, explosion_delay=_L40), 0.9, 900),
+    ],
+    "MortarMayhemB-v0": [
+        (11, dict(command_count=_CC16 + [20, 18], explosion_duration=[d + 2 for d in _D40], explosion_delay=[d + 8 for d in _L40]), 0.95, 1200),
+    ],
+    "MysteryPath-v0": [
+        (11, dict(max_steps=24, cardinal_origin_choice=[0, 1, 2, 3, 3, 2, 1, 0, 2, 2, 1, 3]), 0.9, 700),
+        (12, dict(max_steps=16, cardinal_origin_choice=[(5 * k) % 4 for k in range(37)]), 0.5, 700),
+    ],
+    "MysteryPath-Grid-v0": [
+        (11, dict(max_steps=20, cardinal_origin_choice=[0, 1, 2, 3, 3, 2, 1, 0, 2, 2, 1, 3]), 0.9, 700),
+        (12, dict(max_steps=12, cardinal_origin_choice=[(3 * k) % 4 for k in range(41)]), 0.5, 700),
+    ],
+    "SearingSpotlights-v0": [
+        (11, dict(num_coins=[1, 2, 3, 4, 1, 2, 3, 4, 2, 1, 3], max_steps=24, agent_health=50), 0.9, 700),
+        (12, dict(num_coins=[1 + (3 * k) % 4 for k in range(35)], max_steps=16, agent_health=50), 0.5, 600),
+    ],
+}
+
+
+def main_long():
+    for env_id, sess in LONG_SESSIONS.items():
+        rows_all, meta = [], []
+        for (seed, options, skill, n) in sess:
+            rows = run_session(env_id, seed, options, skill, n)
+            rows_all.append(rows)
+            n_eps = sum(r["done"] for r in rows)
+            meta.append(dict(seed=seed, options=options, skill=skill, n_steps=n, episodes=n_eps))
+            print(env_id, "long seed", seed, "rows", len(rows), "episodes", n_eps)
+        out = pack(rows_all, meta)
+        fn = os.path.join(HERE, "long_" + env_id.replace("-", "_") + ".npz")
+        np.savez_compressed(fn, **out)
+        print("  ->", fn, os.path.getsize(fn) // 1024, "KiB")
+
+
 def run_session(env_id, seed, options, skill, n_steps):
     spec = ENVS[env_id]
     env = make(env_id)
@@ -490,6 +548,8 @@ def main_fuzz():
 def main():
     if "--fuzz" in sys.argv:
         return main_fuzz()
+    if "--long" in sys.argv:
+        return main_long()
     only = sys.argv[1:] or list(SESSIONS)
     for env_id in only:
         rows_all, meta = [], []

@@ -37,6 +37,7 @@ def lib():
         L.mgo_get_gt.argtypes = [C.c_void_p, C.c_void_p]
         L.mgo_rng_words.argtypes = [C.c_void_p, C.c_void_p]
         L.mgo_render_debug.argtypes = [C.c_void_p, C.c_void_p]
+        L.mgo_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mgo_test_rng.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mgo_batch_create.restype = C.c_void_p
         L.mgo_batch_create.argtypes = [C.c_char_p, C.c_int, C.c_double]
@@ -123,6 +124,14 @@ class OracleEnv:
         w = np.zeros(6, np.uint64)
         self.L.mgo_rng_words(self.h, w.ctypes.data)
         return w
+
+    def scene(self, values):
+        """Test hook (oracle/mgo_env.h mgo_vtbl.scene): put the instance into the scene described by the family-specific
+        vector and draw it with the family's own drawing code; returns the observation [x][y][c]."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        obs = np.empty((self.dim, self.dim, 3), np.uint8)
+        assert self.L.mgo_scene(self.h, v.ctypes.data, len(v), obs.ctypes.data) == 0, "scene refused"
+        return obs
 
     def debug_view(self):
         """render() with render_mode "debug_rgb_array": uint8 [336][336][3], image order"""

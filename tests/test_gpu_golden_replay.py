@@ -1,4 +1,4 @@
-"""GPU (-m gpu): replay the REFERENCE's recorded sessions (tests/golden/{logic,fuzz}_*.npz: captured from the unmodified
+"""GPU (-m gpu): replay the REFERENCE's recorded sessions (tests/golden/{logic,fuzz,long}_*.npz: captured from the unmodified
 reference by tests/golden/make_golden.py) straight through the HIP path -- the public single-instance API over the C ABI --
 without the oracle in between: reward (the reference's Python float, bit for bit), done, the numpy PCG64 words after every
 call, info["ground_truth"] and the terminal info dict must equal what the reference produced."""
@@ -20,7 +20,10 @@ def load(env_id, kind):
     return np.load(os.path.join(GOLDEN, kind + "_" + env_id.replace("-", "_") + ".npz"))
 
 
-CASES = [(e, k) for e in ENV_IDS for k in ("logic", "fuzz")]
+# "long": option lists of 9..41 entries (tests/golden/make_golden.py --long), incl. lists beyond the 32 entries the kernels
+# keep in their arguments
+CASES = [(e, k) for e in ENV_IDS for k in ("logic", "fuzz")] + [
+    (e, "long") for e in ENV_IDS if os.path.exists(os.path.join(GOLDEN, "long_" + e.replace("-", "_") + ".npz"))]
 
 
 @pytest.mark.parametrize("env_id,kind", CASES, ids=["%s-%s" % c for c in CASES])

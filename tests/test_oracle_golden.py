@@ -25,11 +25,13 @@ def sessions(env_id, kind="logic"):
     return [(env_id, i, kind) for i in range(len(meta))]
 
 
-# "logic": hand-picked sessions; "fuzz": seeded random option dictionaries (tests/option_fuzz.py, make_golden.py --fuzz)
-ALL = [s for e in ENV_IDS for s in sessions(e)] + [s for e in ENV_IDS for s in sessions(e, "fuzz")]
+# "logic": hand-picked sessions; "fuzz": seeded random option dictionaries (tests/option_fuzz.py, make_golden.py --fuzz);
+# "long": "sample one per episode" option lists of 9..41 entries (make_golden.py --long)
+LONG_IDS = [e for e in ENV_IDS if os.path.exists(os.path.join(GOLDEN, "long_" + e.replace("-", "_") + ".npz"))]
+ALL = [s for e in ENV_IDS for s in sessions(e)] + [s for e in ENV_IDS for s in sessions(e, "fuzz")] + [s for e in LONG_IDS for s in sessions(e, "long")]
 
 
-@pytest.mark.parametrize("env_id,si,kind", ALL, ids=["%s-%s%d" % (a[0], a[2][0], a[1]) for a in ALL])
+@pytest.mark.parametrize("env_id,si,kind", ALL, ids=["%s-%s%d" % (a[0], a[2][:2] if a[2] == "long" else a[2][0], a[1]) for a in ALL])
 def test_replay_matches_reference(env_id, si, kind):
     z = load(env_id, kind)
     meta = json.loads(str(z["meta"]))[si]
