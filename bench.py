@@ -18,10 +18,18 @@ episodes de-synchronise -- right after a reset all instances are in the same pha
 raster launches are 10-20 % slower than the stationary mix.  Then W warm-up steps, then EXACTLY K timed steps between
 barrier + synchronize on both sides (max over ranks).
 
+The timed region is measured with a HIP event pair recorded on the launch stream right behind the opening fence and right
+before the closing one (`timing` says so, the host clock around the same region is kept next to it as
+`wall_ms_per_step`; with a gather on another stream the host clock between the fences is the one that counts).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (raster kernel, HIP events recorded by
 the library on the launch stream: every 8th step of the timed region when K >= 64; for shorter runs the timed region stays
 undisturbed and the 32 steps after it are all bracketed) and `cpu_baseline` (the CPU oracle = a port of the reference's
-algorithm, bounded sample, OpenMP over instances, timed in a subprocess; rank 0, N = 1 only).
+algorithm, bounded sample, OpenMP over instances, timed in a subprocess; rank 0, N = 1 only).  N = 1 also carries
+`c1` (BASELINE config C1, the reference's own bench.py loop: one instance, reset(seed=1), actions from PCG64(12345), 200
+episodes -- the HIP single-instance adapter and the oracle on one thread), the C3 entry's `reset_share` (time of the
+path-generating resets over the step time) and, when rocprofv3 is on PATH, `roofline.traffic` MEASURED by two child passes
+of this very command (--pmc WRITE_SIZE, --pmc FETCH_SIZE; /opt/skills/guides/MI355X_MICROARCH.md, HBM section).
 """
 import argparse
 import json
@@ -147,13 +155,14 @@ def pygame_baseline(env_id, episodes=30):
 
 
 # ---------------------------------------------------------------------------------------------------------------- one workload
-def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8_xyc", gather=None, events=True, event_stride=8):
+def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8_xyc", gather=None, events=True, event_stride=8,
+                 count_done=False):
     """Create the environments, settle, warm up, time K steps; returns a dict (identical on every rank)."""
     import torch
     import torch.distributed as dist
 
     import memory_gym_amd
-    from memory_gym_amd.dist import PeerObsBuffer, shard_seeds
+    from memory_gym_amd.dist import ObsGatherer, PeerObsBuffer, shard_seeds
 
     n_total = n_local * world
     peer = None
@@ -172,16 +181,22 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     n_act_bufs = 64
     shape, hi = ((n_local,), 4) if env.action_dim == 1 else ((n_local, 2), 3)
     acts = [torch.randint(0, hi, shape, device=dev, generator=g, dtype=torch.int32) for _ in range(n_act_bufs)]
-    gather_bufs = [torch.empty_like(env.obs) for _ in range(world)] if (gather == "rccl" and world > 1 and rank == 0) else None
+    # the collective path is taken whenever a process group exists -- also at world size 1 (RCCL on one GPU: the plumbing
+    # test of tests/test_gpu_rccl_world1.py)
+    dist_on = dist.is_available() and dist.is_initialized()
+    gatherer = ObsGatherer(env) if (gather == "rccl" and dist_on) else None  # double-buffered: gather t beside step t + 1
 
     def one_step(k):
-        obs, rew, done, _, _ = env.step(acts[k % n_act_bufs])
+        if gatherer is not None:
+            gatherer.step(acts[k % n_act_bufs])
+            return
+        env.step(acts[k % n_act_bufs])
         if peer is not None:  # the frames are already in rank 0's memory; one 4-byte all-reduce orders the streams
             peer.fence()
-        elif gather and world > 1:  # equal shards: plain gather into preallocated buffers (no per-step allocation)
-            dist.gather(obs, gather_bufs, dst=0)
 
     def fence():
+        if gatherer is not None:
+            gatherer.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -194,12 +209,19 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     in_region = events and K >= 64
     if in_region:
         env.set_profiling(max(1, event_stride))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    done_sum = torch.zeros((), dtype=torch.int64, device=dev) if count_done else None
     fence()
     t0 = time.perf_counter()
+    ev0.record()  # hipEventRecord on the launch stream (torch's current stream is the one mg_step is given)
     for k in range(K):
         one_step(settle + W + k)
+    ev1.record()
     fence()
-    dt = time.perf_counter() - t0
+    dt_wall = time.perf_counter() - t0
+    dt_event = ev0.elapsed_time(ev1) * 1e-3
+    # everything of a step is enqueued on the launch stream unless a collective runs beside it: then the fences decide
+    dt = dt_wall if (gather and dist_on) else dt_event
     raster_ms = raster_n = logic_ms = logic_n = 0
     region = None
     if events:
@@ -217,12 +239,40 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    extra = {}
+    if count_done:  # after the timed region: how many instances finish per step, and what resetting that many costs
+        for k in range(100):
+            env.step(acts[k % n_act_bufs])
+            done_sum += env.done_u8.sum()
+        torch.cuda.synchronize()
+        per_step = float(done_sum.item()) / 100.0
+        mask = torch.ones(n_local, dtype=torch.bool, device=dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        reset_ms, render_ms = [], []
+        for _ in range(5):
+            e0.record()
+            env.reset(mask=mask)   # reset kernel (path generation for every instance) + raster
+            e1.record()
+            env.render()           # the raster alone
+            e2.record()
+            torch.cuda.synchronize()
+            reset_ms.append(e0.elapsed_time(e1))
+            render_ms.append(e1.elapsed_time(e2))
+        per_reset_us = max(0.0, (min(reset_ms) - min(render_ms))) * 1e3 / n_local
+        extra = {"resets_per_step": per_step, "reset_kernel_us_per_instance": per_reset_us,
+                 "full_reset_kernel_ms": max(0.0, min(reset_ms) - min(render_ms))}
     out = {"env_id": env_id, "n_local": n_local, "n_total": n_total, "seconds": dt_max, "value": n_total * K / dt_max,
+           "wall_ms_per_step": dt_wall / K * 1e3, "timing": ("host clock between the fences (a collective runs beside the launch stream)"
+                                                               if (gather and dist_on) else "hipEvent pair on the launch stream around the K steps"),
+           "extra": extra,
            "ms_per_step": dt_max / K * 1e3, "raster_avg_ms": raster_ms / raster_n if raster_n else None, "raster_launches": raster_n,
            "logic_avg_ms": logic_ms / logic_n if logic_n else None, "event_region": region,
-           "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if world > 1 else None, "note": note}
+           "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if dist_on else None, "note": note}
+    if gatherer is not None and rank == 0:  # the frames rank 0 received in the last step equal the ranks' own (rank 0's: checked here)
+        got = gatherer.gathered()
+        out["gather_check"] = bool(torch.equal(got[0], gatherer.bufs[(gatherer.t - 1) & 1]))
     env.close()
-    del env, gather_bufs, peer
+    del env, gatherer, peer
     torch.cuda.empty_cache()
     return out
 
@@ -234,12 +284,111 @@ def secondary_workloads(primary, dev, settle):
     for env_id, label in (("MysteryPath-v0", "C3"), ("Endless-SearingSpotlights-v0", "C4"), ("Endless-MortarMayhem-v0", "C5 per-GPU shard")):
         if env_id == primary:
             continue
-        r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev)
-        out.append({"config": label, "workload": "%s, %d envs" % (env_id, r["n_local"]), "value": r["value"], "unit": "env steps/s",
-                    "ms_per_step": r["ms_per_step"], "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"],
-                    "raster_GBps": (FRAME + 16) * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 if r["raster_avg_ms"] else None,
-                    "obs_placement_zones": (r["obs_placement"] or {}).get("zones")})
+        r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev, count_done=(label == "C3"))
+        entry = {"config": label, "workload": "%s, %d envs" % (env_id, r["n_local"]), "value": r["value"], "unit": "env steps/s",
+                 "ms_per_step": r["ms_per_step"], "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"],
+                 "raster_GBps": (FRAME + 16) * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 if r["raster_avg_ms"] else None,
+                 "obs_placement_zones": (r["obs_placement"] or {}).get("zones")}
+        if label == "C3" and r["extra"]:
+            # "report the reset (A* path-gen) kernel's share of time separately".  The path generation
+            # of an auto-reset runs inside the step's logic kernel (served by the instance's wave), so its share is reported
+            # as (instances that reset per step) x (cost of one reset, from a masked mg_reset of the whole batch: reset kernel
+            # = mg_reset - raster) over the step time, next to the logic kernel's own time.
+            x = r["extra"]
+            entry["reset_share"] = x["resets_per_step"] * x["reset_kernel_us_per_instance"] * 1e-3 / r["ms_per_step"]
+            entry["reset_share_detail"] = dict(x, method="resets per step x (masked full-batch mg_reset - mg_render) / instances, over ms_per_step",
+                                               logic_share=(r["logic_avg_ms"] / r["ms_per_step"]) if r["logic_avg_ms"] else None)
+        out.append(entry)
     return out
+
+
+def c1_leg(episodes=200):
+    """BASELINE config C1 (the reference's own loop, /root/reference/bench.py:12-30, restated in tests/c1_loop.py): one
+    MortarMayhem-Grid-v0 instance, reset(seed=1), actions from Generator(PCG64(12345)), `episodes` episodes with the resets
+    inside the timed region.  The HIP single-instance adapter here, the CPU oracle (one thread) in a subprocess; both walk
+    the same episodes (`steps` must agree)."""
+    import c1_loop
+
+    hip = c1_loop.run("hip", "MortarMayhem-Grid-v0", episodes)
+    out = {"recipe": "MortarMayhem-Grid-v0 x1, reset(seed=1), PCG64(12345) actions, %d episodes, resets inside the timed region" % episodes,
+           "hip_adapter": hip,
+           "note": "one instance is latency-bound on a GPU (two launches and one device->host round trip per step); the batched "
+                   "path is the product, this leg is the plumbing check BASELINE.md asks for"}
+    try:
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "c1_loop.py"), "--backend", "oracle", "--episodes", str(episodes), "--json"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        out["cpu_oracle_1_thread"] = json.loads(line[-1])
+        out["same_episodes"] = out["cpu_oracle_1_thread"]["steps"] == hip["steps"]
+    except Exception as e:
+        out["cpu_oracle_1_thread"] = "unavailable: %s" % e
+    return out
+
+
+def under_rocprof():
+    return any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def measure_traffic(argv_env, n_local):
+    """roofline.traffic measured for THIS workload on THIS box: two child passes of bench.py under rocprofv3 (--pmc WRITE_SIZE
+    and --pmc FETCH_SIZE need separate passes: TCC slots), --kernel-trace only next to them, as MI355X_MICROARCH.md's HBM
+    section prescribes; counters are in KiB, FETCH_SIZE is doubled on gfx950.  Average over the raster launches of the child's
+    timed region.  Returns (bytes per launch or None, description dict)."""
+    import shutil
+    import sqlite3
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, {"source": "rocprofv3 not on PATH"}
+    if under_rocprof():
+        return None, {"source": "this process already runs under rocprofv3: no nested passes"}
+    meta, vals = {}, {}
+    for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+        d = tempfile.mkdtemp(prefix="memgym_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--env", argv_env, "--envs-per-gpu", str(n_local), "--steps", "24", "--warmup", "4", "--settle", "60", "--no-cpu-baseline",
+               "--no-secondary", "--no-events", "--no-traffic", "--no-c1"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            db_path = None
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db_path = os.path.join(root, f)
+            if db_path is None:
+                raise RuntimeError("no results.db (rc %d): %s" % (p.returncode, p.stderr[-200:]))
+            db = sqlite3.connect(db_path)
+
+            def table(prefix):
+                for (n,) in db.execute("select name from sqlite_master where type='table'"):
+                    if n.startswith(prefix + "_0") or n == prefix:
+                        return n
+                raise KeyError(prefix)
+            kd, ks, pe, pi = table("rocpd_kernel_dispatch"), table("rocpd_info_kernel_symbol"), table("rocpd_pmc_event"), table("rocpd_info_pmc")
+            rows = db.execute("select e.value, d.end - d.start from %s e join %s q on e.pmc_id = q.id join %s d on d.event_id = e.event_id "
+                              "join %s s on d.kernel_id = s.id where q.name = ? and s.display_name like '%%raster%%' order by d.start desc limit 20"
+                              % (pe, pi, kd, ks), (counter,)).fetchall()
+            if not rows:
+                raise RuntimeError("no raster dispatches with %s in the trace" % counter)
+            vals[counter] = sum(r[0] for r in rows) / len(rows) * 1024.0
+            meta[counter + "_launches"] = len(rows)
+            meta[counter + "_pass_raster_avg_us"] = sum(r[1] for r in rows) / len(rows) / 1e3
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if line:  # where the child's observation buffer lay (the PMC passes are perturbed: see profiles/r03_pmc_passes.md)
+                meta[counter + "_pass_obs_placement"] = json.loads(line[-1]).get("obs_placement")
+        except Exception as e:
+            meta[counter + "_error"] = str(e)[:300]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "WRITE_SIZE" in vals and "FETCH_SIZE" in vals:
+        meta.update(source="MEASURED in this run: two child passes of this command under rocprofv3 (--pmc WRITE_SIZE / --pmc FETCH_SIZE, "
+                           "--kernel-trace), last 20 raster launches; counters in KiB, FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md)",
+                    write_bytes=vals["WRITE_SIZE"], fetch_bytes_corrected_x2=2 * vals["FETCH_SIZE"])
+        return vals["WRITE_SIZE"] + 2 * vals["FETCH_SIZE"], meta
+    meta.setdefault("source", "rocprofv3 child passes failed")
+    return None, meta
 
 
 # ---------------------------------------------------------------------------------------------------------------- launch
@@ -289,6 +438,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5 measurements")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
+    ap.add_argument("--no-c1", action="store_true", help="skip the single-instance C1 leg")
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every N-th step with HIP events (each bracketed step costs ~15 us)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only for plumbing tests with all ranks on one GPU)")
@@ -317,6 +468,9 @@ def main():
             dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
+        if args.gather == "rccl" and "MASTER_PORT" in os.environ:  # a one-rank RCCL group: the gather path on a single GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", 0)} if args.backend == "nccl" else {}))
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d (the launcher decides)" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -341,17 +495,22 @@ def main():
                        "env_id": env_id, "envs_per_gpu": n_local, "envs_total": r["n_total"],
                        "parallelism": "env-sharded x%d, no data-path collective" % world if not r["gather"] else
                        "env-sharded x%d + %s(obs)->rank0" % (world, "peer-mapped stores" if r["gather"] == "peer" else "gather")},
-            "per_gpu_value": r["value"] / world,
+            "per_gpu_value": r["value"] / world, "timing": r["timing"], "wall_ms_per_step": r["wall_ms_per_step"],
         }
         if r["note"]:
             out["note"] = r["note"]
+        if "gather_check" in r:
+            out["gather_check"] = r["gather_check"]
         if r["raster_launches"]:
             avg_ms = r["raster_avg_ms"]
             rb = (FRAME * obs_elem + 16) * n_local
             achieved = rb / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_source = None, None
+            traffic, traffic_source, traffic_meta = None, None, None
+            if world == 1 and obs_elem == 1 and not args.no_traffic:
+                traffic, traffic_meta = measure_traffic(env_id, n_local)
+                traffic_source = traffic_meta.get("source")
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
+            if traffic is None and os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
                     if j.get("env_id") == env_id and j.get("envs_per_gpu") == n_local and obs_elem == 1:
@@ -362,6 +521,7 @@ def main():
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                               "traffic_passes": traffic_meta,
                                "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],
                                "event_region": r["event_region"], "logic_kernel_avg_ms": r["logic_avg_ms"],
                                "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * r["n_total"] / (r["seconds"] / K) / 1e9}
@@ -389,13 +549,18 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "unavailable: %s" % e}
             out["pygame_baseline"] = pygame_baseline(env_id)
+        if world == 1 and not args.no_c1:
+            try:
+                out["c1"] = c1_leg()
+            except Exception as e:
+                out["c1"] = "failed: %s" % e
         if world == 1 and not args.no_secondary and args.obs_format == "u8_xyc":
             try:
                 out["secondary_workloads"] = secondary_workloads(env_id, dev, args.settle)
             except Exception as e:
                 out["secondary_workloads"] = "failed: %s" % e
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

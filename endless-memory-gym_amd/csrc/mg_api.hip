@@ -11,11 +11,27 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 }  // namespace mg
 
+constexpr int MG_MAX_GROUPS = 8;
+
+// One handle = one device, num_envs instances in `groups` contiguous blocks (include/memgym.h: mg_set_groups), each block a
+// Family object of its own (state, atlases, queues).  groups == 1: everything runs on the caller's stream as it always did.
 struct mg_env {
-    mg::Family* fam = nullptr;
+    std::vector<mg::Family*> fams;
+    std::vector<int> base;  // first instance of block g; base[groups] = num_envs
+    mg::Family* fam = nullptr;  // fams[0]: static properties
     int device = 0;
     int num_envs = 0;
+    int variant = 0, family = 0;  // what make_* was called with
+    bool started = false;         // a reset has happened: the grouping is fixed
     std::string id;
+    std::vector<std::pair<std::string, std::vector<double>>> options;  // every mg_set_option so far (replayed by mg_set_groups)
+    int obs_format = MG_OBS_U8_XYC;
+    float* vec_dev = nullptr;
+    int prof_stride = 0;
+    hipStream_t gs[MG_MAX_GROUPS] = {};
+    hipEvent_t ev_in = nullptr, ev_logic[MG_MAX_GROUPS] = {}, ev_done[MG_MAX_GROUPS] = {};
+    int groups() const { return (int)fams.size(); }
+    int count(int g) const { return base[g + 1] - base[g]; }
 };
 
 namespace {
@@ -79,6 +95,77 @@ int guarded(mg_env* env, F&& f) {
 }
 }  // namespace
 
+namespace {
+mg::Family* make_family(int family, int variant, int n) {
+    if (family == 0) return mg::make_mortar(variant, n);
+    if (family == 1) return mg::make_spot(variant, n);
+    return mg::make_mystery(variant, n);
+}
+void destroy_families(mg_env* e) {
+    for (auto* f : e->fams) delete f;
+    e->fams.clear();
+    e->fam = nullptr;
+    for (int g = 0; g < MG_MAX_GROUPS; ++g) {
+        if (e->gs[g]) (void)hipStreamDestroy(e->gs[g]);
+        if (e->ev_logic[g]) (void)hipEventDestroy(e->ev_logic[g]);
+        if (e->ev_done[g]) (void)hipEventDestroy(e->ev_done[g]);
+        e->gs[g] = nullptr;
+        e->ev_logic[g] = e->ev_done[g] = nullptr;
+    }
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    e->ev_in = nullptr;
+}
+// (re)build the blocks of a handle; options, observation format, vector-observation binding and profiling are carried over
+void build_groups(mg_env* e, int groups) {
+    destroy_families(e);
+    e->base.assign(groups + 1, 0);
+    for (int g = 0; g <= groups; ++g) e->base[g] = (int)((int64_t)e->num_envs * g / groups);
+    for (int g = 0; g < groups; ++g) {
+        mg::Family* f = make_family(e->family, e->variant, e->count(g));
+        e->fams.push_back(f);
+        f->obs_format = e->obs_format;
+        f->prof.stride = e->prof_stride;
+        for (auto& o : e->options) f->set_option(o.first, o.second.data(), (int)o.second.size());
+        if (e->vec_dev && f->vec_dim()) f->bind_vector_obs(e->vec_dev + (size_t)e->base[g] * f->vec_dim());
+    }
+    e->fam = e->fams[0];
+    if (groups > 1) {
+        MG_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+        for (int g = 0; g < groups; ++g) {
+            MG_HIP(hipStreamCreateWithFlags(&e->gs[g], hipStreamNonBlocking));
+            MG_HIP(hipEventCreateWithFlags(&e->ev_logic[g], hipEventDisableTiming));
+            MG_HIP(hipEventCreateWithFlags(&e->ev_done[g], hipEventDisableTiming));
+            e->fams[g]->logic_event = e->ev_logic[g];
+        }
+    }
+}
+size_t obs_bytes_of(int f) {
+    const size_t elem = f == MG_OBS_F32_CYX ? 4 : ((f == MG_OBS_F16_CYX || f == MG_OBS_BF16_CYX) ? 2 : 1);
+    return elem * 84 * 84 * 3;
+}
+// Run `body(g, stream)` for every block: on the caller's stream for one block; otherwise on the blocks' own streams, which
+// first wait for what the caller's stream has enqueued so far, and the caller's stream waits for all of them afterwards.
+// stagger: block g's stream additionally waits for block g - 1's logic kernel (Family::logic_event).
+template <typename F>
+void for_groups(mg_env* e, hipStream_t s, bool stagger, F&& body) {
+    const int G = e->groups();
+    if (G == 1) {
+        body(0, s);
+        return;
+    }
+    MG_HIP(hipEventRecord(e->ev_in, s));
+    for (int g = 0; g < G; ++g) {
+        MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_in, 0));
+        if (stagger && g > 0) MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_logic[g - 1], 0));
+        body(g, e->gs[g]);
+        MG_HIP(hipEventRecord(e->ev_done[g], e->gs[g]));
+    }
+    for (int g = 0; g < G; ++g) MG_HIP(hipStreamWaitEvent(s, e->ev_done[g], 0));
+}
+template <typename T>
+T* off(T* p, size_t n) { return p ? p + n : nullptr; }
+}  // namespace
+
 extern "C" {
 
 const char* mg_last_error(void) { return mg::g_last_error.c_str(); }
@@ -91,26 +178,34 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
         }
         DeviceGuard guard(device);
         std::string id(env_id);
-        mg::Family* fam = nullptr;
-        if (id == "MortarMayhem-Grid-v0") fam = mg::make_mortar(0, num_envs);
-        else if (id == "MortarMayhem-v0") fam = mg::make_mortar(1, num_envs);
-        else if (id == "Endless-MortarMayhem-v0") fam = mg::make_mortar(2, num_envs);
-        else if (id == "MortarMayhemB-Grid-v0") fam = mg::make_mortar(3, num_envs);
-        else if (id == "MortarMayhemB-v0") fam = mg::make_mortar(4, num_envs);
-        else if (id == "Endless-SearingSpotlights-v0") fam = mg::make_spot(1, num_envs);
-        else if (id == "SearingSpotlights-v0") fam = mg::make_spot(0, num_envs);
-        else if (id == "MysteryPath-v0") fam = mg::make_mystery(0, num_envs);
-        else if (id == "Endless-MysteryPath-v0") fam = mg::make_mystery(1, num_envs);
-        else if (id == "MysteryPath-Grid-v0") fam = mg::make_mystery(2, num_envs);
+        int family = -1, variant = 0;
+        if (id == "MortarMayhem-Grid-v0") { family = 0; variant = 0; }
+        else if (id == "MortarMayhem-v0") { family = 0; variant = 1; }
+        else if (id == "Endless-MortarMayhem-v0") { family = 0; variant = 2; }
+        else if (id == "MortarMayhemB-Grid-v0") { family = 0; variant = 3; }
+        else if (id == "MortarMayhemB-v0") { family = 0; variant = 4; }
+        else if (id == "Endless-SearingSpotlights-v0") { family = 1; variant = 1; }
+        else if (id == "SearingSpotlights-v0") { family = 1; variant = 0; }
+        else if (id == "MysteryPath-v0") { family = 2; variant = 0; }
+        else if (id == "Endless-MysteryPath-v0") { family = 2; variant = 1; }
+        else if (id == "MysteryPath-Grid-v0") { family = 2; variant = 2; }
         else {
             mg::set_error("mg_create: environment id not available in this build: " + id);
             return -5;
         }
         mg_env* e = new mg_env();
-        e->fam = fam;
         e->device = device;
         e->num_envs = num_envs;
         e->id = id;
+        e->family = family;
+        e->variant = variant;
+        try {
+            build_groups(e, 1);
+        } catch (...) {
+            destroy_families(e);
+            delete e;
+            throw;
+        }
         *out = e;
         return 0;
     } catch (const std::exception& e) {
@@ -124,10 +219,21 @@ void mg_destroy(mg_env* env) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(env->device);
-    delete env->fam;
+    (void)hipDeviceSynchronize();  // the blocks' streams may still run
+    destroy_families(env);
     delete env;
     if (prev >= 0) (void)hipSetDevice(prev);
 }
+
+int mg_set_groups(mg_env* env, int groups) {
+    return guarded(env, [&] {
+        if (groups != 1 && groups != 2 && groups != 4 && groups != 8) throw std::runtime_error("mg_set_groups: 1, 2, 4 or 8 groups");
+        if (env->num_envs % groups != 0 || env->num_envs / groups < 1) throw std::runtime_error("mg_set_groups: num_envs must be divisible by the number of groups");
+        if (env->started) throw std::runtime_error("mg_set_groups: the grouping is fixed by the first mg_reset");
+        if (groups != env->groups()) build_groups(env, groups);
+    });
+}
+int32_t mg_groups(const mg_env* env) { return env ? env->groups() : 0; }
 
 int32_t mg_num_envs(const mg_env* env) { return env ? env->num_envs : 0; }
 int32_t mg_action_dim(const mg_env* env) { return env ? env->fam->action_dim() : 0; }
@@ -136,7 +242,8 @@ int32_t mg_vec_dim(const mg_env* env) { return env ? env->fam->vec_dim() : 0; }
 int mg_bind_vector_obs(mg_env* env, float* vec_dev) {
     return guarded(env, [&] {
         if (env->fam->vec_dim() == 0 && vec_dev) throw std::runtime_error("mg_bind_vector_obs: this env id has no vector observation");
-        env->fam->bind_vector_obs(vec_dev);
+        env->vec_dev = vec_dev;
+        for (int g = 0; g < env->groups(); ++g) env->fams[g]->bind_vector_obs(off(vec_dev, (size_t)env->base[g] * env->fam->vec_dim()));
     });
 }
 const char* mg_info_name(const mg_env* env, int k) { return env ? env->fam->info_name(k) : nullptr; }
@@ -144,7 +251,8 @@ const char* mg_info_name(const mg_env* env, int k) { return env ? env->fam->info
 int mg_set_option(mg_env* env, const char* key, const double* values, int n) {
     return guarded(env, [&] {
         if (!key || !values || n < 1) throw mg::OptionError{-3, "mg_set_option: bad arguments"};
-        env->fam->set_option(key, values, n);
+        for (auto* f : env->fams) f->set_option(key, values, n);
+        env->options.emplace_back(std::string(key), std::vector<double>(values, values + n));
     });
 }
 
@@ -152,28 +260,36 @@ int mg_set_obs_format(mg_env* env, int format) {
     return guarded(env, [&] {
         if (format != MG_OBS_U8_XYC && format != MG_OBS_F32_CYX && format != MG_OBS_F16_CYX && format != MG_OBS_BF16_CYX)
             throw mg::OptionError{-3, "mg_set_obs_format: unknown format"};
-        env->fam->obs_format = format;
+        env->obs_format = format;
+        for (auto* f : env->fams) f->obs_format = format;
     });
 }
 
 size_t mg_obs_bytes(const mg_env* env) {
     if (!env) return 0;
-    const int f = env->fam->obs_format;
-    const size_t elem = f == MG_OBS_F32_CYX ? 4 : ((f == MG_OBS_F16_CYX || f == MG_OBS_BF16_CYX) ? 2 : 1);
-    return elem * 84 * 84 * 3;
+    return obs_bytes_of(env->obs_format);
 }
 
 int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, void* obs_dev, float* gt_dev, void* stream) {
     return guarded(env, [&] {
         if (!obs_dev) throw std::runtime_error("mg_reset: obs_dev is NULL");
-        env->fam->reset(seeds_dev, mask_dev, obs_dev, gt_dev, (hipStream_t)stream);
+        const size_t ob = obs_bytes_of(env->obs_format);
+        const int gd = env->fam->gt_dim();
+        for_groups(env, (hipStream_t)stream, false, [&](int g, hipStream_t st) {
+            const size_t b = (size_t)env->base[g];
+            env->fams[g]->reset(off(seeds_dev, b), off(mask_dev, b), (char*)obs_dev + b * ob, off(gt_dev, b * gd), st);
+        });
+        env->started = true;
     });
 }
 
 int mg_render(mg_env* env, void* obs_dev, void* stream) {
     return guarded(env, [&] {
         if (!obs_dev) throw std::runtime_error("mg_render: obs_dev is NULL");
-        env->fam->raster_only(obs_dev, nullptr, (hipStream_t)stream);
+        const size_t ob = obs_bytes_of(env->obs_format);
+        for_groups(env, (hipStream_t)stream, false, [&](int g, hipStream_t st) {
+            env->fams[g]->raster_only((char*)obs_dev + (size_t)env->base[g] * ob, nullptr, st);
+        });
     });
 }
 
@@ -201,7 +317,7 @@ int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream) {
         uint8_t* frames = nullptr;
         MG_HIP(hipMalloc((void**)&frames, (size_t)env->num_envs * MG_OBS_BYTES));
         try {
-            env->fam->raster_debug(frames, st);
+            for (int g = 0; g < env->groups(); ++g) env->fams[g]->raster_debug(frames + (size_t)env->base[g] * MG_OBS_BYTES, st);
             const size_t total = (size_t)env->num_envs * 336 * 336;
             const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
             hipLaunchKernelGGL(debug_stretch_kernel, dim3(grid), dim3(256), 0, st, frames, rgb_dev, env->num_envs);
@@ -221,24 +337,37 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
         if (!actions_dev || !obs_dev || !reward_dev || !done_dev) throw std::runtime_error("mg_step: NULL buffer");
         hipStream_t st = (hipStream_t)stream;
         const mg_info_buffers ib = read_info(info);
-        info = &ib;
-        if (autoreset && info->final_obs_dev) {
-            // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
-            // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
-            // consumption and frames as the fused path (tests/test_gpu_vector_api.py)
-            env->fam->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, info, 0, st);
-            env->fam->raster_only(info->final_obs_dev, done_dev, st);
-            env->fam->reset(nullptr, done_dev, obs_dev, gt_dev, st);
-        } else {
-            env->fam->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, info, autoreset, st);
-        }
+        const size_t ob = obs_bytes_of(env->obs_format);
+        const int ad = env->fam->action_dim(), gd = env->fam->gt_dim();
+        for_groups(env, st, true, [&](int g, hipStream_t gst) {
+            const size_t b = (size_t)env->base[g];
+            mg_info_buffers gi = ib;  // this block's rows of every array
+            gi.ep_reward_dev = off(ib.ep_reward_dev, b);
+            gi.ep_length_dev = off(ib.ep_length_dev, b);
+            for (int k = 0; k < MG_INFO_SLOTS; ++k) gi.aux_dev[k] = off(ib.aux_dev[k], b);
+            gi.final_obs_dev = ib.final_obs_dev ? (char*)ib.final_obs_dev + b * ob : nullptr;
+            gi.reward64_dev = off(ib.reward64_dev, b);
+            mg::Family* f = env->fams[g];
+            void* obs_g = (char*)obs_dev + b * ob;
+            if (autoreset && gi.final_obs_dev) {
+                // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
+                // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
+                // consumption and frames as the fused path (tests/test_gpu_vector_api.py)
+                f->step(actions_dev + b * ad, obs_g, reward_dev + b, done_dev + b, off(gt_dev, b * gd), &gi, 0, gst);
+                f->raster_only(gi.final_obs_dev, done_dev + b, gst);
+                f->reset(nullptr, done_dev + b, obs_g, off(gt_dev, b * gd), gst);
+            } else {
+                f->step(actions_dev + b * ad, obs_g, reward_dev + b, done_dev + b, off(gt_dev, b * gd), &gi, autoreset, gst);
+            }
+        });
     });
 }
 
 size_t mg_state_size(const mg_env* env) {
     if (!env) return 0;
     size_t t = sizeof(StateHeader);
-    for (auto& b : env->fam->state_blobs()) t += b.second;
+    for (auto* f : env->fams)
+        for (auto& b : f->state_blobs()) t += b.second;
     return t;
 }
 
@@ -253,12 +382,14 @@ int mg_get_state(mg_env* env, void* host_buf, size_t size) {
         h.num_envs = (uint32_t)env->num_envs;
         h.payload = mg_state_size(env) - sizeof(StateHeader);
         h.id_hash = fnv1a(env->id);
+        h.pad[0] = (uint8_t)env->groups();
         memcpy(host_buf, &h, sizeof(h));
         char* p = (char*)host_buf + sizeof(StateHeader);
-        for (auto& b : env->fam->state_blobs()) {
-            MG_HIP(hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost));
-            p += b.second;
-        }
+        for (auto* f : env->fams)
+            for (auto& b : f->state_blobs()) {
+                MG_HIP(hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost));
+                p += b.second;
+            }
     });
 }
 
@@ -275,29 +406,46 @@ int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
         if (h.num_envs != (uint32_t)env->num_envs)
             throw std::runtime_error("mg_set_state: the blob holds " + std::to_string(h.num_envs) + " instances, the handle " +
                                      std::to_string(env->num_envs));
+        if ((int)h.pad[0] != env->groups())
+            throw std::runtime_error("mg_set_state: the blob was taken with " + std::to_string((int)h.pad[0]) + " instance group(s), the handle has " +
+                                     std::to_string(env->groups()) + " (mg_set_groups before the first reset)");
         if (h.payload != mg_state_size(env) - sizeof(StateHeader) || size < mg_state_size(env))
             throw std::runtime_error("mg_set_state: payload size differs from this handle's state");
         MG_HIP(hipDeviceSynchronize());
         const char* p = (const char*)host_buf + sizeof(StateHeader);
-        for (auto& b : env->fam->state_blobs()) {
-            MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
-            p += b.second;
+        for (auto* f : env->fams) {
+            for (auto& b : f->state_blobs()) {
+                MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
+                p += b.second;
+            }
+            f->on_state_loaded();  // reset(seed=None) / auto-reset are legal on a restored handle
         }
-        env->fam->on_state_loaded();  // reset(seed=None) / auto-reset are legal on a restored handle
+        env->started = true;
     });
 }
 
 int mg_set_profiling(mg_env* env, int on) {
     return guarded(env, [&] {
-        env->fam->prof.stride = on < 0 ? 0 : on;
-        env->fam->prof.count[0] = env->fam->prof.count[1] = 0;
+        env->prof_stride = on < 0 ? 0 : on;
+        for (auto* f : env->fams) {
+            f->prof.stride = env->prof_stride;
+            f->prof.count[0] = f->prof.count[1] = 0;
+        }
     });
 }
 
 int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches) {
     return guarded(env, [&] {
         if (kind < 0 || kind > 1 || !total_ms || !launches) throw std::runtime_error("mg_get_profile: bad arguments");
-        env->fam->prof.collect(kind, total_ms, launches);
+        *total_ms = 0;
+        *launches = 0;
+        for (auto* f : env->fams) {  // with several blocks: the sum over the blocks' (concurrent) launches
+            double ms = 0;
+            int64_t n = 0;
+            f->prof.collect(kind, &ms, &n);
+            *total_ms += ms;
+            *launches += n;
+        }
     });
 }
 
@@ -305,14 +453,16 @@ int mg_poll_errors(mg_env* env, int* flags) {
     return guarded(env, [&] {
         if (!flags) throw std::runtime_error("mg_poll_errors: NULL");
         MG_HIP(hipDeviceSynchronize());
-        *flags = env->fam->poll_errors();
+        *flags = 0;
+        for (auto* f : env->fams) *flags |= f->poll_errors();
     });
 }
 
 int mg_peek_errors(mg_env* env, int* flags) {
     return guarded(env, [&] {
         if (!flags) throw std::runtime_error("mg_peek_errors: NULL");
-        *flags = env->fam->peek_errors();
+        *flags = 0;
+        for (auto* f : env->fams) *flags |= f->peek_errors();
     });
 }
 
@@ -350,7 +500,9 @@ int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
     return guarded(env, [&] {
         if (i < 0 || i >= env->num_envs) throw std::runtime_error("mg_debug_rng: index out of range");
         MG_HIP(hipDeviceSynchronize());
-        env->fam->debug_rng(i, out);
+        int g = 0;
+        while (g + 1 < env->groups() && i >= env->base[g + 1]) ++g;
+        env->fams[g]->debug_rng(i - env->base[g], out);
     });
 }
 

@@ -173,6 +173,13 @@ struct KernelProfile {
 class Family {
    public:
     KernelProfile prof;
+    // Set by the C ABI for handles with several instance groups (mg_set_groups): recorded on the launch stream right behind
+    // the step's logic kernel, so that the NEXT group's logic kernel can start under this group's raster launch.
+    hipEvent_t logic_event = nullptr;
+    void end_logic(hipStream_t s) {
+        prof.end(0, s);
+        if (logic_event) MG_HIP(hipEventRecord(logic_event, s));
+    }
     int obs_format = MG_OBS_U8_XYC;  // stream-out format of the raster kernel (include/memgym.h)
     virtual ~Family() {}
     virtual int action_dim() const = 0;

@@ -616,7 +616,7 @@ class MortarFamily : public Family {
         prof.begin(0, s);
         hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), actions, reward, done,
                            gt_dim() ? gt : nullptr, ib, autoreset);
-        prof.end(0, s);
+        end_logic(s);
         prof.begin(1, s);
         raster(obs, s);
         prof.end(1, s);

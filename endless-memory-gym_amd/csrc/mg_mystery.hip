@@ -177,6 +177,7 @@ struct MysteryIO {
     int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
     uint64_t* walls;  // finite: [N] wall cells of the current path generation (bit x*7+y), read by the debug view only
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
+    const uint4* jump;  // [64][2] PCG64 jump constants {A^(k+1), S_(k+1)} (WaveRng)
 };
 constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_WORDS = 96;  // one 128-byte line each
 // MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
@@ -217,6 +218,7 @@ constexpr int WS_BYTES = WS_STAGE + 4 * 64;
 
 struct PathWS {
     uint8_t* base;
+    const uint4* jump;  // WaveRng's per-lane jump constants
     __device__ __forceinline__ double h(int d2) const { return reinterpret_cast<const double*>(base + WS_SQRT)[d2]; }
     __device__ __forceinline__ uint8_t* stage() const { return base + WS_STAGE + (threadIdx.x >> 6) * 64; }
 };
@@ -240,10 +242,102 @@ __device__ __forceinline__ Pcg bcast(const Pcg& g, int lane) {
     return b;
 }
 
+// ---- the instance's RNG stream, generated 64 outputs at a time by the whole wave ------------------------------------------
+// A path draws ~130 32-bit numbers; drawn one by one from wave-uniform state, every PCG64 step is a 128 x 128-bit multiply on
+// the scalar unit (~45 scalar instructions per 64-bit output) inside a kernel that is bound by scalar issue -- a third of a
+// path's instructions.  An LCG can be jumped: s_k = A^k s_0 + S_k inc with S_k = 1 + A + ... + A^(k-1), so lane k computes
+// step k + 1 directly (two 128-bit multiplies on the vector unit, all 64 lanes at once) and a draw is one v_readlane.  The
+// 32-bit draws are numpy's: low half, then the buffered high half of each 64-bit output (Pcg::next32), a half buffered
+// before the hand-over first.  jump[k] = {A^(k+1), S_(k+1)} is built on the host (MysteryFamily).
+struct WaveRng {
+    u128 M, S;        // per lane: A^(lane + 1), S_(lane + 1)
+    u128 st;          // per lane: the state after lane + 1 steps from `base`
+    uint32_t lo, hi;  // per lane: that step's output
+    u128 base, inc;   // uniform
+    int cursor;       // uniform: 32-bit draws taken from the current batch (0 .. 128)
+    bool pre_has;     // uniform: the stream was handed over with a buffered half, not consumed yet
+    uint32_t pre_buf;
+
+    __device__ __forceinline__ void load_jump(const uint4* jump) {
+        const int lane = threadIdx.x & 63;
+        const uint4 m = jump[2 * lane], q = jump[2 * lane + 1];
+        M = ((u128)m.w << 96) | ((u128)m.z << 64) | ((u128)m.y << 32) | m.x;
+        S = ((u128)q.w << 96) | ((u128)q.z << 64) | ((u128)q.y << 32) | q.x;
+    }
+    __device__ __forceinline__ void refill() {
+        st = M * base + S * inc;
+        const uint64_t h = (uint64_t)(st >> 64), l = (uint64_t)st, x = h ^ l;
+        const unsigned rot = (unsigned)(h >> 58);
+        const uint64_t o = (x >> rot) | (x << ((64 - rot) & 63));
+        lo = (uint32_t)o;
+        hi = (uint32_t)(o >> 32);
+        cursor = 0;
+    }
+    static __device__ __forceinline__ u128 lane128(u128 v, int lane) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 64), lane);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 96), lane);
+        return ((u128)d << 96) | ((u128)c << 64) | ((u128)b << 32) | a;
+    }
+    // g: wave-uniform (a broadcast copy of the requesting lane's stream)
+    __device__ __forceinline__ void take(const Pcg& g) {
+        base = g.state;
+        inc = g.inc;
+        pre_has = g.has;
+        pre_buf = g.buf;
+        refill();
+    }
+    // the stream as it stands after the draws taken (uniform)
+    __device__ __forceinline__ void give(Pcg& g) const {
+        const int m = (cursor + 1) >> 1;  // 64-bit outputs consumed from this batch
+        g.inc = inc;
+        if (m == 0) {
+            g.state = base;
+            g.has = pre_has;
+            g.buf = pre_buf;
+        } else {
+            g.state = lane128(st, m - 1);
+            g.has = (cursor & 1) != 0;
+            g.buf = (uint32_t)__builtin_amdgcn_readlane((int)hi, m - 1);  // numpy keeps the last buffered half also once it is used
+        }
+    }
+    __device__ __forceinline__ uint32_t next32() {
+        if (pre_has) {
+            pre_has = false;
+            return pre_buf;
+        }
+        if (cursor == 128) {
+            base = lane128(st, 63);
+            refill();
+        }
+        const int idx = cursor >> 1;
+        const uint32_t v = (cursor & 1) ? (uint32_t)__builtin_amdgcn_readlane((int)hi, idx) : (uint32_t)__builtin_amdgcn_readlane((int)lo, idx);
+        ++cursor;
+        return v;
+    }
+    // Generator.integers(lo, hi): Lemire bounded draw on the 32-bit path; span 1 consumes nothing (Pcg::integers)
+    __device__ __forceinline__ int integers(int lo_, int hi_) {
+        const uint32_t rng = (uint32_t)(hi_ - 1 - lo_);
+        if (rng == 0) return lo_;
+        const uint32_t n = rng + 1u;
+        uint64_t m = (uint64_t)next32() * n;
+        uint32_t left = (uint32_t)m;
+        if (left < n) {
+            const uint32_t thr = (0xFFFFFFFFu - rng) % n;
+            while (left < thr) {
+                m = (uint64_t)next32() * n;
+                left = (uint32_t)m;
+            }
+        }
+        return lo_ + (int)(m >> 32);
+    }
+};
+
 // MysteryPath.__init__ (pygame_assets.py:606-724) + Node (:438-493), every argument wave-uniform, called by all 64
 // lanes.  Returns the path length (-1 = "No valid path found"); lane k < len receives the k-th path node (flat index
 // x*7+y, END FIRST like the reference's list) in out_node, path_mask has one bit per path node.
-__device__ int coop_path(Pcg& g, const PathWS& W, int sx, int sy, int ex, int ey, int& out_node, uint64_t& path_mask, uint64_t& wall_out) {
+__device__ int coop_path(WaveRng& g, const PathWS& W, int sx, int sy, int ex, int ey, int& out_node, uint64_t& path_mask, uint64_t& wall_out) {
     const int lane = threadIdx.x & 63;
     uint64_t wall = 0, closed = 0, in_open = 0;
     for (int i = 0; i < G; ++i)
@@ -421,6 +515,8 @@ __device__ __forceinline__ void mp_post_reset(const MysteryParams& P, MysteryCor
 __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, int& len_out, uint64_t& pm_out, uint64_t* walls, int inst) {
     const int lane = threadIdx.x & 63;
     uint64_t todo = __ballot(req.need != 0);
+    WaveRng wr;
+    if (todo) wr.load_jump(W.jump);
     while (todo) {
         const int L = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
@@ -428,7 +524,9 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
         int node = 0;
         uint64_t pm = 0;
         uint64_t wl = 0;
-        int len = coop_path(bg, W, bcast(req.sx, L), bcast(req.sy, L), bcast(req.ex, L), bcast(req.ey, L), node, pm, wl);
+        wr.take(bg);
+        int len = coop_path(wr, W, bcast(req.sx, L), bcast(req.sy, L), bcast(req.ex, L), bcast(req.ey, L), node, pm, wl);
+        wr.give(bg);
         if (len < 0) {
             if (lane == 0) raise_error(err, 2);
             len = 0;
@@ -562,18 +660,22 @@ struct SegRec {
 __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want, MysteryCore& s, Pcg& g) {
     const int lane = threadIdx.x & 63;
     int todo_n = want;
+    WaveRng wr;
+    if (__ballot(todo_n > 0)) wr.load_jump(W.jump);
     for (;;) {
         const uint64_t todo = __ballot(todo_n > 0);
         if (!todo) break;
         const int L = __ffsll((unsigned long long)todo) - 1;
         Pcg bg = bcast(g, L);
+        wr.take(bg);
         const int have = bcast((int)s.have_start, L), endy = bcast((int)s.end_y, L);
-        const int sy = have ? endy : bg.integers(0, G);
-        const int ey = bg.integers(0, G);
+        const int sy = have ? endy : wr.integers(0, G);
+        const int ey = wr.integers(0, G);
         int node = 0;
         uint64_t pm = 0;
         uint64_t walls_unused = 0;
-        int len = coop_path(bg, W, 0, sy, G - 1, ey, node, pm, walls_unused);
+        int len = coop_path(wr, W, 0, sy, G - 1, ey, node, pm, walls_unused);
+        wr.give(bg);
         if (len < 0) {
             if (lane == 0) raise_error(io.err, 2);
             len = 0;
@@ -928,7 +1030,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
                                                             const uint8_t* mask, float* gt, int lpw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem};
+    const PathWS W{smem, io.jump};
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool in_range = worker && i < P.n;
@@ -970,7 +1072,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
                                                            mg_info_buffers info, int autoreset, int lpw, int defer) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem};
+    const PathWS W{smem, io.jump};
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool active = worker && i < P.n;
@@ -1017,7 +1119,7 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if (blockIdx.x < PATH_WGS) {
         path_ws_init(smem);
-        const PathWS W{smem};
+        const PathWS W{smem, io.jump};
         const bool me = (threadIdx.x & 63) == 0;
         const int count = queue_count(&io.qctr[QC_COUNT], n);
         const int waves = PATH_WGS * (blockDim.x >> 6);
@@ -1356,7 +1458,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem};
+    const PathWS W{smem, io.jump};
     const bool me = (threadIdx.x & 63) == 0;
     const int count = all ? P.n : queue_count(&io.qctr[QC_COUNT], P.n);
     // the first entry of wave w is entry w (no atomic: with thousands of idle waves the same-address atomics of their
@@ -1405,7 +1507,7 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
     if (blockIdx.x < svc) {
         uint8_t* ws = smem + FRAME_BYTES;  // the path workspace lives in the (unused) mask words behind the frame
         path_ws_init(ws);
-        const PathWS W{ws};
+        const PathWS W{ws, io.jump};
         const int wv = tid >> 6;
         const bool me = (tid & 63) == 0;
         const int count = queue_count(&io.qctr[QC_COUNT], n);
@@ -1482,6 +1584,18 @@ class MysteryFamily : public Family {
         rng_.alloc(n);
         err_.alloc();
         queue_.alloc((size_t)n + 32 + QC_WORDS);
+        {   // WaveRng: s_k = A^k s_0 + S_k inc for k = 1 .. 64 (PCG64's 128-bit LCG, multiplier as in mg_device.hpp Pcg::advance)
+            const u128 A = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
+            std::vector<uint4> jt(128);
+            u128 m = 1, q = 0;
+            for (int k = 0; k < 64; ++k) {
+                q = q * A + 1;  // S_(k+1) = S_k A + 1
+                m = m * A;      // A^(k+1)
+                jt[2 * k] = make_uint4((uint32_t)m, (uint32_t)(m >> 32), (uint32_t)(m >> 64), (uint32_t)(m >> 96));
+                jt[2 * k + 1] = make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(q >> 64), (uint32_t)(q >> 96));
+            }
+            jump_.upload(jt);
+        }
         if (endless) {
             segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
             falloff_.alloc((size_t)n * MAX_FALL);
@@ -1567,7 +1681,7 @@ class MysteryFamily : public Family {
         if (P_.endless) {
             hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
             if (fuse_serve() && obs_format == MG_OBS_U8_XYC) {  // the queue is served inside the raster launch
-                prof.end(0, s);
+                end_logic(s);
                 prof.begin(1, s);
                 const int svc = EMP_SVC_WGS;
                 const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + svc;
@@ -1584,14 +1698,14 @@ class MysteryFamily : public Family {
             hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
                                (float*)nullptr, ib, autoreset, lpw(), defer);
             if (defer) {  // the paths of this step's resets are generated by the first workgroups of the raster launch
-                prof.end(0, s);
+                end_logic(s);
                 prof.begin(1, s);
                 raster_with_paths(obs, s);
                 prof.end(1, s);
                 return;
             }
         }
-        prof.end(0, s);
+        end_logic(s);
         prof.begin(1, s);
         raster(obs, s);
         prof.end(1, s);
@@ -1681,6 +1795,7 @@ class MysteryFamily : public Family {
         o.queue = queue_.p;
         o.walls = P_.endless ? nullptr : walls_.p;
         o.qctr = queue_.p + ((n_ + 31) & ~31);
+        o.jump = jump_.p;
         return o;
     }
 
@@ -1748,6 +1863,7 @@ class MysteryFamily : public Family {
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
+    DevArray<uint4> jump_;  // WaveRng jump constants
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
     RngStore rng_;

@@ -1238,7 +1238,7 @@ class SpotFamily : public Family {
         const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets()) ? 1 : 0;
         if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
         else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
-        prof.end(0, s);
+        end_logic(s);
         prof.begin(1, s);
         if (defer) {
             const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + SPOT_SVC_WGS;

@@ -42,6 +42,9 @@ def _load():
     for f in ("mg_num_envs", "mg_action_dim", "mg_gt_dim"):
         getattr(L, f).argtypes = [C.c_void_p]
         getattr(L, f).restype = C.c_int32
+    L.mg_set_groups.argtypes = [C.c_void_p, C.c_int]
+    L.mg_groups.argtypes = [C.c_void_p]
+    L.mg_groups.restype = C.c_int32
     L.mg_info_name.argtypes = [C.c_void_p, C.c_int]
     L.mg_info_name.restype = C.c_char_p
     L.mg_set_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]

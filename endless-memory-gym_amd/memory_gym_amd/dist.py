@@ -8,6 +8,7 @@ The only (optional) exchange is BASELINE config 5's gather of observations/rewar
 single-learner rollout.  Two forms with the same result on rank 0:
 
     gather_to_rank0   a torch.distributed gather (RCCL send/recv): every rank writes its frames locally, then ships them;
+    ObsGatherer       the same collective, double-buffered: the gather of step t runs beside step t + 1;
     PeerObsBuffer     rank 0's [N_total, ...] observation tensor is mapped into every rank (HIP IPC, peer access over
                       xGMI) and handed to VecMemoryGym as `obs_buffer`: the raster kernels store their frames straight
                       into rank 0's HBM -- no second copy, no collective on the data path (only a barrier per step).
@@ -46,6 +47,59 @@ def gather_to_rank0(tensor, dst=0, group=None):
     if rank != dst:
         return None
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+class ObsGatherer:
+    """BASELINE config 5's optional exchange, double-buffered: the gather of step t's observations to rank `dst` runs BESIDE
+    step t + 1 (hard part 6).
+
+    The environment alternates between two observation buffers (VecMemoryGym.use_obs_buffer); after step t has been
+    enqueued, the gather of its buffer is issued as an asynchronous collective (RCCL runs it on its own stream, ordered
+    behind the step's kernels), and only the step that is about to OVERWRITE that buffer -- step t + 2 -- waits for it.
+    Rank dst keeps two sets of receive buffers as well; `gathered(t)` joins the gather of step t and returns its W per-rank
+    tensors (rank dst; None elsewhere).  Shards must be equal-sized (N_total % W == 0, what the bench uses).
+
+        g = ObsGatherer(env)                 # env: VecMemoryGym, after reset()
+        for t in range(T):
+            obs, rew, done, _, info = g.step(actions[t])      # gather of step t starts, step t - 1's may still run
+            frames = g.gathered()            # rank dst: list of W tensors of the LATEST step (joins it); else None
+    """
+
+    def __init__(self, env, dst=0, group=None):
+        self.env, self.dst, self.group = env, dst, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.bufs = [env.obs, env.new_obs_buffer() if hasattr(env, "new_obs_buffer") else torch.empty_like(env.obs)]
+        self.recv = [[torch.empty_like(env.obs) for _ in range(self.world)] for _ in range(2)] if self.rank == dst else [None, None]
+        self.work = [None, None]
+        self.t = 0
+
+    def step(self, actions):
+        k = self.t & 1
+        if self.work[k] is not None:  # the gather that still reads this buffer (step t - 2): the launch stream waits for it
+            self.work[k].wait()
+            self.work[k] = None
+        self.env.use_obs_buffer(self.bufs[k])
+        out = self.env.step(actions)
+        self.work[k] = dist.gather(self.bufs[k], self.recv[k], dst=self.dst, group=self.group, async_op=True)
+        self.t += 1
+        return out
+
+    def gathered(self):
+        """Join the gather of the latest step; rank dst gets its W per-rank observation tensors (valid until the step
+        after next), the other ranks None."""
+        k = (self.t - 1) & 1
+        if self.t == 0:
+            return None
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        return self.recv[k]
+
+    def drain(self):
+        for k in range(2):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
 
 
 class PeerObsBuffer:

@@ -99,7 +99,7 @@ class VecMemoryGym:
                    "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
     def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False,
-                 obs_buffer=None, obs_placement=None):
+                 obs_buffer=None, obs_placement=None, groups=1):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -114,6 +114,12 @@ class VecMemoryGym:
         h = C.c_void_p()
         _native.check(_native.LIB.mg_create(env_id.encode(), self.num_envs, self.device.index, C.byref(h)), "mg_create")
         self._h = h
+        # groups > 1 (1, 2, 4, 8; num_envs divisible): the instances are stepped in that many blocks on streams of their own,
+        # one block's logic kernel under the previous block's raster launch (include/memgym.h: mg_set_groups).  Same results.
+        self.groups = int(groups)
+        if self.groups != 1:
+            with torch.cuda.device(self.device):
+                _native.check(_native.LIB.mg_set_groups(h, self.groups), "mg_set_groups")
         self.action_dim = _native.LIB.mg_action_dim(h)
         self.gt_dim = _native.LIB.mg_gt_dim(h)
         self.vec_dim = _native.LIB.mg_vec_dim(h)
@@ -269,6 +275,25 @@ class VecMemoryGym:
         if self.final_obs is not None and self.autoreset:  # rows valid where done_mask is set
             info["final_observation"] = self.final_obs
         return self._obs(), self.reward, done, self._truncated, info
+
+    def new_obs_buffer(self):
+        """A second observation buffer like `obs` (same shape, dtype, device and -- if `obs` came from mg_obs_alloc -- the same
+        zone-balanced placement), for consumers that double-buffer (use_obs_buffer)."""
+        if self.obs_placement_info is not None:
+            try:
+                t, _ = alloc_obs_buffer(tuple(self.obs.shape), self.obs.dtype, self.device)
+                return t
+            except RuntimeError:
+                pass
+        return torch.empty_like(self.obs)
+
+    def use_obs_buffer(self, tensor):
+        """Make `tensor` (same shape / dtype / device as `obs`) the buffer the NEXT reset / step writes its observations to
+        (mg_step takes the buffer per call).  A consumer that still reads the previous buffer -- e.g. a gather to another
+        rank running beside the next step (memory_gym_amd.dist.ObsGatherer) -- alternates between two buffers this way."""
+        if tuple(tensor.shape) != tuple(self.obs.shape) or tensor.dtype != self.obs.dtype or tensor.device != self.obs.device or not tensor.is_contiguous():
+            raise ValueError("use_obs_buffer: need a contiguous tensor like env.obs")
+        self.obs = tensor
 
     def _obs(self):
         if self.vector_obs is None:

@@ -56,6 +56,17 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out);
 void mg_destroy(mg_env* env);
 const char* mg_last_error(void);
 
+/* Instance groups (optional; the reference has no counterpart: it steps one instance at a time).  A handle's instances can
+ * be split into `groups` contiguous, equally treated blocks (1, 2, 4 or 8; num_envs must be divisible).  mg_reset / mg_step
+ * then launch each block's kernels on a stream of its own, staggered: block g's logic kernel waits for block g - 1's, so it
+ * runs UNDER block g - 1's raster launch (the logic kernels are latency-bound, the raster kernels HBM-bound; measured
+ * x1.08-1.35 per step: profiles/r03_groups.md), and the caller's stream waits for all blocks at the end of the call
+ * (stream-ordered: no host synchronisation).  Results are bit-identical to groups = 1: instance i is the same instance with
+ * the same RNG stream whatever the grouping (tests/test_gpu_groups.py).  All buffers keep their [num_envs] layout.  Must be
+ * called before the first mg_reset; option calls made earlier are replayed.  Checkpoints record the grouping. */
+int mg_set_groups(mg_env* env, int groups);
+int32_t mg_groups(const mg_env* env);
+
 /* Static properties (action_space / observation_space / ground_truth_space of the reference classes):
  * mg_action_dim: 1 = Discrete(4) (mortar_mayhem_grid.py:82, endless_mystery_path.py:83),
  *                2 = MultiDiscrete([3,3]) (e.g. mortar_mayhem.py:83).
@@ -133,7 +144,7 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
 
 /* Checkpoint hooks (the reference cannot serialise an env; SoA state makes it free).  Synchronous.
  * mg_state_size: bytes needed.  The blob starts with a 64-byte header {magic "MGSTATE1", MG_STATE_VERSION, num_envs,
- * payload bytes, FNV-1a of the env id}; the layout behind it is private to one MG_STATE_VERSION.  mg_set_state refuses
+ * payload bytes, FNV-1a of the env id, groups}; the layout behind it is private to one MG_STATE_VERSION.  mg_set_state refuses
  * (-1, message in mg_last_error) a blob whose magic, version, env id, num_envs or payload size differ from the handle's
  * instead of mis-assigning it. */
 #define MG_STATE_VERSION 3u

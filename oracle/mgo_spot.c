@@ -7,8 +7,11 @@
  *                                 helpers :137-330
  * plus GridPositionSampler :7-59, Spotlight :61-131, Coin :133-167, Exit :169-220 and
  * get_tiled_background_surface :222-239 of memory_gym/pygame_assets.py.
- * Pinned by tests/golden/logic_{Endless_,}SearingSpotlights_v0.npz (logic) and docs/assets/ess_0.gif (pixels,
- * SCALE 1.0).  Exit's rounded rectangle (finite variant only) has NO reference fixture: parity unpinned for that stamp.
+ * Pinned by tests/golden/logic_{Endless_,}SearingSpotlights_v0.npz (logic), docs/assets/ess_0.gif (pixels of the endless
+ * variant, SCALE 1.0, all 692 frames) and, for the finite variant, docs/assets/searing_spotlights_0.gif + _gt.gif (an older
+ * revision's recording, every one of its 118 frames in both views: chessboards, dim ramp, filled discs, coin, the Exit's
+ * rounded rectangle CLOSED (frames 0-52) and OPEN (frames 53-117, (48,141,70)): tests/test_oracle_old_gif_replay.py,
+ * tests/test_oracle_old_gifs.py).
  * hide_chessboard / black_background repaint the two background surfaces an environment object keeps for its lifetime
  * (searing_spotlights.py:349-351, 234-235, 420-421; endless :313-315, 223-224, 376-377), so they stick to the INSTANCE
  * across episodes and option changes; black_background also gives every spotlight spawned under it a white 1-px border
@@ -169,7 +172,8 @@ static void sp_spawn_coin_endless(mgo_env* e, sp_t* p) {
 
 /* Exit.draw (pygame_assets.py:191-205): rounded top corners.  pygame's draw_round_rect restated from its
  * published algorithm (filled: octagon + filled circle quadrants; outline: four thick lines + quadrant arcs).
- * NOT covered by any reference fixture -> parity unpinned for this stamp. */
+ * Pinned pixel for pixel, closed and open, by the reference's searing_spotlights_0(_gt).gif
+ * (tests/test_oracle_old_gif_replay.py). */
 static void sp_quadrant(mgo_surf* s, int x0, int y0, int radius, int thickness, uint32_t c, int tr, int tl, int bl, int br) {
     /* pygame draw_circle_quadrant */
     int f = 1 - radius, ddx = 0, ddy = -2 * radius, x = 0, y = radius;

@@ -45,17 +45,14 @@ def make(backend, env_id):
     return gym.make(env_id)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--backend", default="oracle", choices=["oracle", "hip", "reference"])
-    ap.add_argument("--env", default="MortarMayhem-Grid-v0")
-    ap.add_argument("--episodes", type=int, default=1000)
-    args = ap.parse_args()
-    env = make(args.backend, args.env)
+def run(backend, env_id="MortarMayhem-Grid-v0", episodes=1000):
+    """The C1 recipe; returns {"steps_per_s_mean", "steps_per_s_std", "episodes", "steps", "mean_success", "checksum"} --
+    `checksum` = the total number of steps, which every backend must agree on (same seed, same action stream)."""
+    env = make(backend, env_id)
     g = np.random.Generator(np.random.PCG64(12345))
     fps, succ, total = [], [], 0
     seed = 1
-    for ep in range(args.episodes):
+    for ep in range(episodes):
         t0 = time.perf_counter()
         env.reset(seed=seed)
         seed = None  # later resets continue the env's RNG stream
@@ -66,8 +63,26 @@ def main():
         fps.append(steps / (time.perf_counter() - t0))
         succ.append(float(info.get("success", 0)))
         total += steps
+    if hasattr(env, "close"):
+        env.close()
+    return {"backend": backend, "steps_per_s_mean": float(np.mean(fps)), "steps_per_s_std": float(np.std(fps)), "episodes": episodes,
+            "steps": total, "mean_success": float(np.mean(succ))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="oracle", choices=["oracle", "hip", "reference"])
+    ap.add_argument("--env", default="MortarMayhem-Grid-v0")
+    ap.add_argument("--episodes", type=int, default=1000)
+    ap.add_argument("--json", action="store_true")
+    args = ap.parse_args()
+    r = run(args.backend, args.env, args.episodes)
+    if args.json:
+        import json
+        print(json.dumps(r))
+        return
     print("backend %s  %s  episodes %d  steps %d  mean steps/s %.1f  std %.1f  mean success %.3f" % (
-        args.backend, args.env, args.episodes, total, np.mean(fps), np.std(fps), np.mean(succ)))
+        args.backend, args.env, args.episodes, r["steps"], r["steps_per_s_mean"], r["steps_per_s_std"], r["mean_success"]))
 
 
 if __name__ == "__main__":

@@ -76,6 +76,58 @@ def test_gather_world2_even_and_ragged(tmp_path):
         assert (d / "ok").exists()
 
 
+class _FakeEnv:
+    """What ObsGatherer needs of a VecMemoryGym: `obs`, use_obs_buffer(), step() writing the frames of step t of this rank's
+    instances into the buffer in use."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi, self.t = lo, hi, 0
+        self.obs = torch.zeros((hi - lo, 84, 84, 3), dtype=torch.uint8)
+
+    def use_obs_buffer(self, t):
+        self.obs = t
+
+    def step(self, actions):
+        self.obs.copy_((_frames_for(self.lo, self.hi).to(torch.int64) + 3 * self.t + int(actions)).remainder(256).to(torch.uint8))
+        self.t += 1
+        return self.obs, None, None, None, {}
+
+
+def _gatherer_worker(rank, world, port, n_total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _load_dist_module()
+    lo, hi = m.shard_range(n_total, rank, world)
+    env = _FakeEnv(lo, hi)
+    g = m.ObsGatherer(env)
+    assert g.bufs[0] is not g.bufs[1]
+    for t in range(7):
+        obs, *_ = g.step(t % 3)
+        assert obs is g.bufs[t & 1]  # the environment alternates between the two buffers
+        if t >= 1:  # step t - 1's frames are still intact in the other buffer while their gather may be running
+            want_prev = (_frames_for(lo, hi).to(torch.int64) + 3 * (t - 1) + (t - 1) % 3).remainder(256).to(torch.uint8)
+            assert torch.equal(g.bufs[(t - 1) & 1], want_prev)
+        if t % 2 == 0 or t == 6:  # join only some steps: the others are overtaken by the wait inside step t + 2
+            got = g.gathered()
+            if rank == 0:
+                full = torch.cat(got, 0)
+                want = (_frames_for(0, n_total).to(torch.int64) + 3 * t + t % 3).remainder(256).to(torch.uint8)
+                assert torch.equal(full, want), "gathered frames of step %d differ" % t
+            else:
+                assert got is None
+    g.drain()
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_double_buffered_gatherer_world2(tmp_path):
+    mp.spawn(_gatherer_worker, args=(2, _free_port(), 8, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 def test_bench_self_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):
     """`python bench.py --gpus N` without a launcher spawns N ranks with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and
     lets only rank 0 write to stdout (the driver's SCALE runs call bench.py exactly like that)."""
