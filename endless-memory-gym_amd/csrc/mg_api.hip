@@ -153,14 +153,21 @@ void for_groups(mg_env* e, hipStream_t s, bool stagger, F&& body) {
         body(0, s);
         return;
     }
-    MG_HIP(hipEventRecord(e->ev_in, s));
+    // measurement switches (tools/groups_probe.py): MEMGYM_GROUPS_LAB bit 0 = no fork from / join into the caller's stream
+    // (results are then NOT ordered with it), bit 1 = no stagger
+    static const int lab = [] {
+        const char* v = getenv("MEMGYM_GROUPS_LAB");
+        return v ? atoi(v) : 0;
+    }();
+    if (!(lab & 1)) MG_HIP(hipEventRecord(e->ev_in, s));
     for (int g = 0; g < G; ++g) {
-        MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_in, 0));
-        if (stagger && g > 0) MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_logic[g - 1], 0));
+        if (!(lab & 1)) MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_in, 0));
+        if (stagger && g > 0 && !(lab & 2)) MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_logic[g - 1], 0));
         body(g, e->gs[g]);
-        MG_HIP(hipEventRecord(e->ev_done[g], e->gs[g]));
+        if (!(lab & 1)) MG_HIP(hipEventRecord(e->ev_done[g], e->gs[g]));
     }
-    for (int g = 0; g < G; ++g) MG_HIP(hipStreamWaitEvent(s, e->ev_done[g], 0));
+    if (!(lab & 1))
+        for (int g = 0; g < G; ++g) MG_HIP(hipStreamWaitEvent(s, e->ev_done[g], 0));
 }
 template <typename T>
 T* off(T* p, size_t n) { return p ? p + n : nullptr; }

@@ -31,8 +31,14 @@ constexpr size_t PIECE = 304 * MiB;         // = one window of the probe: 14,336
                                             // same, 16 MiB +6 %, 2 MiB +12 %: profiles/r02_zones.md)
 constexpr int FILL_STEP = 32;               // filler handles per step of the walk
 constexpr int PROBE_GRID = 14336;
-static const double CROSS_ZONE_TBPS = getenv("MEMGYM_OBS_CROSS_TBPS") ? atof(getenv("MEMGYM_OBS_CROSS_TBPS")) : 5.85;  // different zones 6.1-6.5 ...
-constexpr double SAME_ZONE_TBPS = 5.35;     // ... same zone 4.9-5.3 (profiles/r02_zones.md); in between: a piece that straddles
+// Classification of a probed pair by the RATIO to this process' own one-zone speed S (round 2 used absolute thresholds,
+// 5.35 / 5.85 TB/s, tuned on the boxes of that round).  S starts as the probe of a piece paired with ITSELF -- two windows in
+// one piece are in one zone by construction -- and follows the slowest pair seen since (a same-zone pair of distinct pieces
+// is a few per cent slower than a piece with itself: no cache hits between the windows).  Pairs in one zone measured
+// 4.9-5.3 TB/s, pairs across zones 6.1-6.5 (profiles/r02_zones.md): ratios <= 1.05 and >= 1.15; in between = a piece that
+// straddles a boundary.  MEMGYM_OBS_SAME_RATIO / MEMGYM_OBS_CROSS_RATIO override.
+static const double SAME_RATIO = getenv("MEMGYM_OBS_SAME_RATIO") ? atof(getenv("MEMGYM_OBS_SAME_RATIO")) : 1.06;
+static const double CROSS_RATIO = getenv("MEMGYM_OBS_CROSS_RATIO") ? atof(getenv("MEMGYM_OBS_CROSS_RATIO")) : 1.12;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -104,7 +110,16 @@ hipMemAllocationProp prop_for(int device) {
 
 // `exportable`: handle type POSIX file descriptor.  Such pieces come out of a different place of the driver's VRAM manager
 // than ordinary ones (often the other end of the memory, i.e. another zone, without any walking); same speed otherwise.
+size_t g_va_reserved = 0;  // bytes of virtual address space reserved so far (never handed back: see va_free)
+hipError_t va_reserve(void** va, size_t bytes) {
+    const hipError_t e = hipMemAddressReserve(va, bytes, 2 * MiB, nullptr, 0);
+    if (e == hipSuccess) g_va_reserved += bytes;
+    return e;
+}
+
 bool create_piece(int device, size_t bytes, Piece* out, bool exportable = false) {
+    static const bool no_vmm = getenv("MEMGYM_OBS_NO_VMM") && atoi(getenv("MEMGYM_OBS_NO_VMM")) != 0;  // tests: a runtime without hipMemCreate
+    if (no_vmm) return false;
     hipMemAllocationProp p = prop_for(device);
     if (exportable) p.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
     hipMemGenericAllocationHandle_t h;
@@ -122,13 +137,33 @@ void release_piece(Piece& p) {
     p.h = nullptr;
 }
 
+// Access for the owning device and -- so that the buffer can be read by (or gathered to) the other GPUs of the node, like an
+// ordinary allocation after hipDeviceEnablePeerAccess -- for every device that reports peer access to it.  Peers that refuse
+// are skipped: the owner's access is what the library itself needs.
 void map_at(void* va, const Piece& p, int device) {
     MG_HIP(hipMemMap(va, p.bytes, 0, p.h, 0));
+    static const std::vector<int> all = [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 1;
+        std::vector<int> v(n);
+        for (int i = 0; i < n; ++i) v[i] = i;
+        return v;
+    }();
     hipMemAccessDesc acc = {};
     acc.location.type = hipMemLocationTypeDevice;
     acc.location.id = device;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     MG_HIP(hipMemSetAccess(va, p.bytes, &acc, 1));
+    for (int d : all) {
+        if (d == device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, d, device) != hipSuccess || !can) {
+            (void)hipGetLastError();
+            continue;
+        }
+        acc.location.id = d;
+        if (hipMemSetAccess(va, p.bytes, &acc, 1) != hipSuccess) (void)hipGetLastError();
+    }
 }
 
 // a candidate piece, mapped on its own for the probe
@@ -138,7 +173,7 @@ struct Cand {
     double tbps = 0;  // two-window probe against the reference piece
     bool make(int device, bool exportable = false) {
         if (!create_piece(device, PIECE, &piece, exportable)) return false;
-        if (hipMemAddressReserve(&va, PIECE, 2 * MiB, nullptr, 0) != hipSuccess) {
+        if (va_reserve(&va, PIECE) != hipSuccess) {
             release_piece(piece);
             return false;
         }
@@ -241,7 +276,11 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         *out = nullptr;
         size_t free_b = 0, total_b = 0;
         MG_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 20 * 11, 160 * GiB);
+        // Default budget of the transient walk: an eighth of the free memory, at most 32 GiB (round 2: 55 % / 160 GiB --
+        // other processes on the GPU could run out of memory while a search held that much).  Exportable pieces usually
+        // come from another zone without any walk (typically 0-3 GiB are touched); a pristine VRAM that needs the long walk
+        // gets the plain allocation instead, or the caller raises the budget (MEMGYM_OBS_SEARCH_GB).
+        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 8, 32 * GiB);
         const size_t k = (bytes + PIECE - 1) / PIECE;
         auto plain = [&](int zones) {  // (called without the lock)
             void* p = nullptr;
@@ -289,7 +328,7 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         auto ref_va = [&](Group& g) {  // the group's reference, mapped on its own
             Cand& r = g.pcs[0];
             if (!r.va) {
-                if (hipMemAddressReserve(&r.va, PIECE, 2 * MiB, nullptr, 0) != hipSuccess) throw std::runtime_error("mg_obs_alloc: hipMemAddressReserve failed");
+                if (va_reserve(&r.va, PIECE) != hipSuccess) throw std::runtime_error("mg_obs_alloc: hipMemAddressReserve failed");
                 map_at(r.va, r.piece, device);
             }
             return r.va;
@@ -297,6 +336,7 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         std::vector<Cand> unclear;
         std::vector<Piece> spacers;
         size_t walked = 0;
+        double one_zone = 0;  // S: this process' one-zone speed of the probe (see SAME_RATIO)
         int tries_after_good = 0;
         bool exportable = false;
         auto give_back = [&] {  // everything that is not part of the buffer
@@ -324,12 +364,17 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
                 if (!c.make(device, exportable)) break;
                 int home = -1;
                 bool odd = false;
+                if (one_zone == 0) {
+                    one_zone = probe_tbps(c.va, c.va);
+                    if (debug) fprintf(stderr, "mg_obs_alloc: one-zone calibration (a piece with itself) %.2f TB/s\n", one_zone);
+                }
                 for (size_t j = 0; j < groups.size() && home < 0; ++j) {
                     c.tbps = probe_tbps(ref_va(groups[j]), c.va);
-                    if (c.tbps < SAME_ZONE_TBPS) {
+                    if (c.tbps < one_zone) one_zone = std::max(c.tbps, 0.9 * one_zone);  // follow slower pairs, not outliers
+                    if (c.tbps <= one_zone * SAME_RATIO) {
                         home = (int)j;
                         I.probe_same_tbps = std::max(I.probe_same_tbps, c.tbps);
-                    } else if (c.tbps <= CROSS_ZONE_TBPS) {
+                    } else if (c.tbps < one_zone * CROSS_RATIO) {
                         odd = true;
                         break;
                     } else {
@@ -409,7 +454,7 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         give_back();
         // one contiguous virtual range
         void* va = nullptr;
-        if (hipMemAddressReserve(&va, k * PIECE, 2 * MiB, nullptr, 0) != hipSuccess) {
+        if (va_reserve(&va, k * PIECE) != hipSuccess) {
             for (auto& o : order) pool_put(Z, o.second, o.first);
             throw std::runtime_error("mg_obs_alloc: hipMemAddressReserve failed");
         }
@@ -452,6 +497,18 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         mg::set_error(e.what());
         return -1;
     }
+}
+
+// Test hook (tests/test_gpu_obs_alloc.py): what the allocator holds right now -- live buffers, pooled spare pieces (all devices),
+// bytes of virtual address space reserved since the process started (never handed back, see va_free).
+int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* reserved_va_bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (live_buffers) *live_buffers = g_live.size();
+    size_t pooled = 0;
+    for (auto& z : g_zones) pooled += z.second.pooled;
+    if (pooled_pieces) *pooled_pieces = pooled;
+    if (reserved_va_bytes) *reserved_va_bytes = g_va_reserved;
+    return 0;
 }
 
 int mg_obs_free(void* p) {

@@ -69,6 +69,7 @@ def _load():
     L.mg_peek_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mg_obs_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(ObsAllocInfo)]
     L.mg_obs_free.argtypes = [C.c_void_p]
+    L.mg_obs_debug_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.mg_enable_peer_access.argtypes = [C.c_int, C.c_int]
     L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     return L

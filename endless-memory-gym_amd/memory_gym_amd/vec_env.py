@@ -74,8 +74,9 @@ class _ObsMemory:
 def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
     """A tensor of `shape` / `dtype` on `device` whose memory comes from mg_obs_alloc (pieces from two HBM zones, see
     include/memgym.h); returns (tensor, info dict).  The memory is released when the last tensor viewing it goes away.
-    MEMGYM_OBS_SEARCH_GB bounds the transient spacer allocations of the search (default: a quarter of the free memory,
-    at most 80 GiB; 0 = do not search)."""
+    MEMGYM_OBS_SEARCH_GB bounds the transient filler allocations of the search (default: an eighth of the free memory, at
+    most 32 GiB -- VRAM that other processes on the GPU cannot have for the few milliseconds the search lasts; 0 = do not
+    search).  The buffer is accessible from this device and from every device with peer access to it."""
     device = torch.device(device)
     elem = torch.empty((), dtype=dtype).element_size()
     nbytes = int(np.prod(shape)) * elem
@@ -139,7 +140,7 @@ class VecMemoryGym:
             raise ValueError("obs_placement must be 'balanced' or 'plain'")
         if obs_buffer is None:
             # "balanced": physical pages from two HBM zones (include/memgym.h: mg_obs_alloc; 12-15 % on the raster kernel);
-            # buffers below 128 MiB and "plain" are ordinary allocations
+            # buffers of 304 MiB or less and "plain" are ordinary allocations
             nbytes = N * 84 * 84 * 3 * torch.empty((), dtype=dt).element_size()
             self.obs = None
             if obs_placement == "balanced" and nbytes > (304 << 20):

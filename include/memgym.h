@@ -187,10 +187,15 @@ int mg_peek_errors(mg_env* env, int* flags);
  * probe, half of them from the first piece's zone and half from elsewhere, mapped alternately into one contiguous
  * virtual range (rounded up to whole pieces).  Pieces it does not need and spacer allocations of 8 GiB that are never
  * mapped or written keep the driver's allocator moving during the search and are released before the call returns (at
- * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = 55 % of the free memory, at most 160 GiB -- a pristine
- * VRAM hands out 100-130 GiB of ONE zone in a row, so the first spacer is 96 GiB long; 0 = no
- * search).  Buffers of 304 MiB or less are plain hipMalloc.  Synchronous; 2 ms when the first pieces already differ,
- * 1-2 s for the longest search.  mg_obs_free releases a buffer obtained here (after synchronising the device). */
+ * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = an eighth of the free memory, at most 32 GiB: that much
+ * VRAM is transiently unavailable to other processes on the GPU; 0 = no search.  A pristine VRAM can hand out 100-130 GiB
+ * of ONE zone in a row: with the default budget such a process gets the plain allocation, info.zones == 1).  Pieces are
+ * classified by the RATIO of the probe to the process' own one-zone speed, not by absolute TB/s.  Buffers of 304 MiB or
+ * less, and runtimes without hipMemCreate, get a plain hipMalloc.  The range is accessible from the owning device and from
+ * every device that reports peer access to it.  Virtual address ranges are never returned to the runtime (a reused range can
+ * keep stale translations on ROCm 7.2): a process that allocates and frees buffers for ever uses address space, not memory.
+ * Synchronous; 2-10 ms typically, bounded by MEMGYM_OBS_SEARCH_MS (3 s).  mg_obs_free releases a buffer obtained here
+ * (after synchronising the device); the pieces go to a pool of at most ten for the next buffer. */
 typedef struct mg_obs_alloc_info {
     int zones;               /* 2, 3 = pieces from that many zones; 1 = no second zone within the budget (plain
                               * allocation); 0 = plain allocation without a search (small buffer, no room)          */
@@ -204,6 +209,8 @@ typedef struct mg_obs_alloc_info {
 #define MG_OBS_SEARCH_DEFAULT ((size_t)-1)
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out_dev, mg_obs_alloc_info* info);
 int mg_obs_free(void* obs_dev);
+/* Test hook: live buffers, pooled spare pieces, bytes of virtual address space reserved so far. */
+int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* reserved_va_bytes);
 
 /* Multi-GPU helper for caller-owned observation memory on ANOTHER GPU of the node (BASELINE config 5: rank r's raster
  * kernels store their frames straight into rank 0's buffer over xGMI; memory_gym_amd/dist.py PeerObsBuffer): checks

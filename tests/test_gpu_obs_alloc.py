@@ -1,0 +1,108 @@
+"""GPU (-m gpu): mg_obs_alloc (zone-balanced observation buffers, include/memgym.h) under conditions a trainer creates:
+most of the VRAM held by somebody else, buffers created and destroyed over and over, a runtime without the virtual-memory
+API.  In every case the environment must work (frames equal the plain-allocation run), the call must return in bounded
+time, and what could not be had must be reported (info.zones), not guessed."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stats():
+    from memory_gym_amd import _native
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert _native.LIB.mg_obs_debug_stats(C.byref(a), C.byref(b), C.byref(c)) == 0
+    return a.value, b.value, c.value
+
+
+def _frames(env, steps=5):
+    n = env.num_envs
+    env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda"))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(steps):
+        obs, *_ = env.step(torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32))
+    return obs
+
+
+def test_most_of_the_vram_held_by_a_model():
+    """A 200-GiB tensor is allocated first (a model, a replay buffer): the search has little room, must stay within its
+    budget and time bound, and the environment produces the same frames as with a plain buffer."""
+    import memory_gym_amd
+
+    free, total = torch.cuda.mem_get_info()
+    hold_gib = min(200, int(free / (1 << 30)) - 24)
+    if hold_gib < 32:
+        pytest.skip("not enough free VRAM on this box")
+    hold = torch.empty(hold_gib << 30, dtype=torch.uint8, device="cuda")
+    n = 32768  # 694 MB of observations: three pieces
+    t0 = time.perf_counter()
+    env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=n, device=0)
+    dt = time.perf_counter() - t0
+    info = env.obs_placement_info
+    assert dt < 8.0, "make() took %.1f s next to a %d-GiB tensor" % (dt, hold_gib)
+    assert info is None or (info["zones"] in (0, 1, 2, 3) and info["searched_bytes"] <= 33 << 30)
+    ref = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=n, device=0, obs_placement="plain")
+    assert torch.equal(_frames(env), _frames(ref))
+    env.close()
+    ref.close()
+    del hold, env, ref
+    torch.cuda.empty_cache()
+
+
+def test_hundred_create_destroy_cycles_do_not_leak():
+    import gc
+
+    import memory_gym_amd
+
+    n = 32768
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    live0, _, va0 = _stats()
+    worst = 0.0
+    for k in range(100):
+        t0 = time.perf_counter()
+        env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=n, device=0)
+        worst = max(worst, time.perf_counter() - t0)
+        if k % 25 == 0:
+            _frames(env, 2)
+        env.close()
+        del env
+        gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    live1, pooled, va1 = _stats()
+    assert live1 == live0, "observation buffers still alive: %d" % (live1 - live0)
+    assert pooled <= 10
+    # the pool keeps at most ten 304-MiB pieces; everything else went back to the driver
+    assert free0 - free1 <= (11 * 304 << 20) + (64 << 20), "VRAM not returned: %.2f GiB" % ((free0 - free1) / 2 ** 30)
+    # address space is never handed back (stale translations on ROCm 7.2): bounded use, far from the 128-TiB space
+    assert va1 - va0 < 1 << 40, "%.1f GiB of address space for 100 buffers" % ((va1 - va0) / 2 ** 30)
+    assert worst < 5.0
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "endless-memory-gym_amd"))
+import torch, memory_gym_amd
+n = 32768
+env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=n, device=0)
+info = env.obs_placement_info
+assert info is None or info["zones"] <= 1, info   # no virtual-memory API: the plain path, and it says so
+env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda"))
+obs, *_ = env.step(torch.zeros(n, dtype=torch.int32, device="cuda"))
+torch.cuda.synchronize()
+assert int(obs.sum()) > 0
+print("NO_VMM_OK")
+'''
+
+
+def test_runtime_without_the_virtual_memory_api_gets_a_plain_buffer():
+    out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=dict(os.environ, MEMGYM_OBS_NO_VMM="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "NO_VMM_OK" in out.stdout, out.stderr[-2000:]

@@ -25,15 +25,19 @@ def rate(env_id, n, groups, steps=300, settle=200):
         env.step(acts[k % 32])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
     e0.record()
     for k in range(steps):
         env.step(acts[k % 32])
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / steps
+    ms = (time.perf_counter() - t0) * 1e3 / steps  # host clock: with MEMGYM_GROUPS_LAB=1 the blocks' streams are not joined into torch's
     zones = (env.obs_placement_info or {}).get("zones")
     env.close()
     return n / ms / 1e3, ms * 1e3, zones
+
+
+GROUPS = tuple(int(x) for x in os.environ.get("PROBE_GROUPS", "1,2,4,8").split(","))
 
 
 def main():
@@ -45,9 +49,9 @@ def main():
             continue
         res = {}
         for rep in range(2):
-            for groups in (1, 2, 4, 8):
+            for groups in GROUPS:
                 res.setdefault(groups, []).append(rate(env_id, n, groups))
-        for groups in (1, 2, 4, 8):
+        for groups in GROUPS:
             r = res[groups]
             print("| %s | %d | %d | %s | %s | %s |" % (env_id, n, groups, " / ".join("%.1f" % x[0] for x in r), " / ".join("%.1f" % x[1] for x in r),
                                                      "/".join(str(x[2]) for x in r)), flush=True)
