@@ -1067,6 +1067,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
 // start, the frame descriptor -- a reset frame shows nothing of the path) and is queued; the queue is served by the first
 // workgroups of the raster launch that follows (mystery_raster_paths_kernel).  The launch no longer lasts as long as one noisy A* (23 us) whenever any of
 // its instances resets (MysteryPath-Grid: 0.5 % of them per step).
+constexpr int HYBRID_INLINE = 2;
 __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions,
                                                            float* reward_out, uint8_t* done_out, float* gt,
                                                            mg_info_buffers info, int autoreset, int lpw, int defer) {
@@ -1094,10 +1095,14 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         if (reset_me) req = mp_pre_reset(P, s, g);
         int len = 0;
         uint64_t pm = 0;
-        if (!defer) serve_mp(W, req, g, io.err, len, pm, io.walls, i);
+        // defer 2 (hybrid): a wave serves up to HYBRID_INLINE requests itself and queues them all once it has more -- the
+        // steps in which nearly every instance is truncated at once (t == max_steps for everybody who survived: all 16
+        // instances of every wave, 16 x 25 us in a row) go to the raster launch, where every resident workgroup helps
+        const bool queue_mine = defer == 1 || (defer == 2 && __popcll(__ballot(req.need != 0)) > HYBRID_INLINE);
+        if (!queue_mine) serve_mp(W, req, g, io.err, len, pm, io.walls, i);
         if (reset_me) {
-            mp_post_reset(P, s, req, len, pm, d);  // (deferred: path_mask / path_len are filled in by mp_path_kernel)
-            if (defer) queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
+            mp_post_reset(P, s, req, len, pm, d);  // (queued: path_mask / path_len are filled in by the raster launch's path service)
+            if (queue_mine) queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         }
     }
     if (active) {
@@ -1113,47 +1118,63 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
 // instance: its stream stands right behind the draws of mp_pre_reset, the path's ends are in its record; the path, the walls
 // and the stream come back.  No second stream, no events: a fork/join around a side-stream kernel cost 10 us per step.
 constexpr int PATH_WGS = 128;
+// Long queues (a step in which nearly every instance is truncated at once: t == max_steps for all survivors of a batch that
+// was reset together -- every 128 steps for MysteryPath-Grid's defaults, every 512 for MysteryPath-v0): the first
+// PATH_HELP_MAX FRAME workgroups serve entries as well before they start on their frames (a reset frame shows nothing of
+// the path, so no frame waits for one).  128 + 1,664 = 1,792 = the workgroups resident at once (7 per CU): every wave of
+// the chip's first round takes entries w, w + SW, w + 2 SW, ... (static striding: thousands of pops from one counter are
+// 22 ns each, in series).  32,768 paths then take what the cooperative generator's scalar-issue bound allows (~80 paths
+// per us chip-wide, profiles/r03_mass_resets.md) instead of 64 paths in a row on 512 waves (1.3 ms).
+constexpr int PATH_HELP_MAX = 1664;
+constexpr int PATH_MASS = 2 * 4 * PATH_WGS;  // more than two entries per dedicated wave: call for help
 template <int FMT>
 __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs,
                                                                       int n, MysteryParams P, MysteryIO io) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (blockIdx.x < PATH_WGS) {
-        path_ws_init(smem);
-        const PathWS W{smem, io.jump};
-        const bool me = (threadIdx.x & 63) == 0;
+    if (blockIdx.x < PATH_WGS + PATH_HELP_MAX) {
+        // (every one of these workgroups reads the count BEFORE the last participant can clear it: in the long-queue case the
+        // clearing waits for all of them, in the short-queue case whatever a late frame workgroup reads -- the count or 0 -- tells
+        // it not to take part)
         const int count = queue_count(&io.qctr[QC_COUNT], n);
-        const int waves = PATH_WGS * (blockDim.x >> 6);
-        int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
-        while (idx < count) {
-            const int i = bcast(io.queue[idx], 0);
-            Pcg g;
-            PathReq req;
-            req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
-            if (me) {
-                g.load(io.rng, i);
-                const MysteryCore c = io.core[i];
-                req.need = 1; req.sx = c.sx; req.sy = c.sy; req.ex = c.ex; req.ey = c.ey;
-            } else {
-                g.state = g.inc = 0; g.buf = 0; g.has = false;
+        const int helpers = count > PATH_MASS ? min(PATH_HELP_MAX, (count + 3) / 4 - PATH_WGS) : 0;
+        const int busy = PATH_WGS + helpers;
+        if ((int)blockIdx.x < busy) {
+            if (count > 0) {
+                path_ws_init(smem);
+                const PathWS W{smem, io.jump};
+                const bool me = (threadIdx.x & 63) == 0;
+                const int waves = busy * 4;
+                for (int idx = bcast((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), 0); idx < count; idx += waves) {
+                    const int i = bcast(io.queue[idx], 0);
+                    Pcg g;
+                    PathReq req;
+                    req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
+                    if (me) {
+                        g.load(io.rng, i);
+                        const MysteryCore c = io.core[i];
+                        req.need = 1; req.sx = c.sx; req.sy = c.sy; req.ex = c.ex; req.ey = c.ey;
+                    } else {
+                        g.state = g.inc = 0; g.buf = 0; g.has = false;
+                    }
+                    int len = 0;
+                    uint64_t pm = 0;
+                    serve_mp(W, req, g, io.err, len, pm, io.walls, i);
+                    if (me) {
+                        io.core[i].path_mask = pm;
+                        io.core[i].path_len = (uint8_t)len;
+                        g.store(io.rng, i);
+                    }
+                }
             }
-            int len = 0;
-            uint64_t pm = 0;
-            serve_mp(W, req, g, io.err, len, pm, io.walls, i);
-            if (me) {
-                io.core[i].path_mask = pm;
-                io.core[i].path_len = (uint8_t)len;
-                g.store(io.rng, i);
-                idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
+            __syncthreads();
+            if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == busy - 1) {  // last participant out
+                io.qctr[QC_COUNT] = 0;
+                io.qctr[QC_HEAD] = 0;
+                io.qctr[QC_LEFT] = 0;
             }
-            idx = bcast(idx, 0);
+            if (blockIdx.x < PATH_WGS) return;
+            __syncthreads();  // a helper goes on to its frames: the path workspace in LDS is the frame from here on
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == PATH_WGS - 1) {  // last service workgroup out
-            io.qctr[QC_COUNT] = 0;
-            io.qctr[QC_HEAD] = 0;
-            io.qctr[QC_LEFT] = 0;
-        }
-        return;
     }
     RasterCtx R;
     R.frame = smem;
@@ -1694,7 +1715,7 @@ class MysteryFamily : public Family {
             hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
                                reward, done, gt, ib, autoreset);
         } else {
-            const int defer = (autoreset && defer_paths()) ? 1 : 0;
+            const int defer = autoreset ? defer_mode() : 0;
             hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
                                (float*)nullptr, ib, autoreset, lpw(), defer);
             if (defer) {  // the paths of this step's resets are generated by the first workgroups of the raster launch
@@ -1765,12 +1786,16 @@ class MysteryFamily : public Family {
         }();
         return on;
     }
-    bool defer_paths() const {
+    // 0: paths of auto-resets in the step kernel; 1: all of them queued for the raster launch (MysteryPath-Grid: 0.5 % of the
+    // instances reset per step, logic 32.7 -> 12.1 us); 2: hybrid, a wave queues its requests only when it has more than
+    // HYBRID_INLINE of them (MysteryPath-v0: its 512-step episodes reset too rarely to pay for always queueing, but the step
+    // in which all survivors are truncated at once was a 450-us launch).  MEMGYM_MYSTERY_DEFER=0 / 1 / 2 forces a mode.
+    int defer_mode() const {
         static const int forced = [] {
             const char* e = getenv("MEMGYM_MYSTERY_DEFER");
-            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+            return e ? atoi(e) : -1;
         }();
-        return forced >= 0 ? forced == 1 : P_.grid != 0;
+        return forced >= 0 && forced <= 2 ? forced : (P_.grid != 0 ? 1 : 2);
     }
     void raster_with_paths(void* obs, hipStream_t s) {
         const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + PATH_WGS;

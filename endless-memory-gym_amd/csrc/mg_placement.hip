@@ -18,6 +18,7 @@
 // neighbours.  If no second zone turns up within the budget the buffer still works, from one zone (info.zones == 1).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -31,14 +32,30 @@ constexpr size_t PIECE = 304 * MiB;         // = one window of the probe: 14,336
                                             // same, 16 MiB +6 %, 2 MiB +12 %: profiles/r02_zones.md)
 constexpr int FILL_STEP = 32;               // filler handles per step of the walk
 constexpr int PROBE_GRID = 14336;
-// Classification of a probed pair by the RATIO to this process' own one-zone speed S (round 2 used absolute thresholds,
-// 5.35 / 5.85 TB/s, tuned on the boxes of that round).  S starts as the probe of a piece paired with ITSELF -- two windows in
-// one piece are in one zone by construction -- and follows the slowest pair seen since (a same-zone pair of distinct pieces
-// is a few per cent slower than a piece with itself: no cache hits between the windows).  Pairs in one zone measured
-// 4.9-5.3 TB/s, pairs across zones 6.1-6.5 (profiles/r02_zones.md): ratios <= 1.05 and >= 1.15; in between = a piece that
-// straddles a boundary.  MEMGYM_OBS_SAME_RATIO / MEMGYM_OBS_CROSS_RATIO override.
-static const double SAME_RATIO = getenv("MEMGYM_OBS_SAME_RATIO") ? atof(getenv("MEMGYM_OBS_SAME_RATIO")) : 1.06;
-static const double CROSS_RATIO = getenv("MEMGYM_OBS_CROSS_RATIO") ? atof(getenv("MEMGYM_OBS_CROSS_RATIO")) : 1.12;
+// Classification of a probed pair of pieces.  Pairs in one zone measured 4.9-5.5 TB/s, pairs across zones 6.1-6.5
+// (profiles/r02_zones.md) -- on THESE boxes.  Those absolute figures are only the PRIOR (round 2 classified by them alone):
+// every probe of two distinct pieces feeds the per-device extremes (Calib), and as soon as they are 12 % apart -- both kinds
+// of pair have been seen in this process -- the thresholds become relative: the geometric mean of the extremes -/+ 3 %.  A
+// search whose earlier decisions the calibrated thresholds would change starts over once.  (A piece paired with ITSELF is no
+// calibration: both windows then hit the same cache lines, 11.6 TB/s.)  MEMGYM_OBS_SAME_TBPS / MEMGYM_OBS_CROSS_TBPS set the prior.
+static const double PRIOR_SAME_TBPS = getenv("MEMGYM_OBS_SAME_TBPS") ? atof(getenv("MEMGYM_OBS_SAME_TBPS")) : 5.35;
+static const double PRIOR_CROSS_TBPS = getenv("MEMGYM_OBS_CROSS_TBPS") ? atof(getenv("MEMGYM_OBS_CROSS_TBPS")) : 5.85;
+struct Calib {
+    double lo = 1e30, hi = 0;
+    bool relative = false;
+    double same_t = PRIOR_SAME_TBPS, cross_t = PRIOR_CROSS_TBPS;
+    void observe(double t) {
+        lo = std::min(lo, t);
+        hi = std::max(hi, t);
+        if (hi >= 1.12 * lo) {
+            const double mid = std::sqrt(lo * hi);
+            relative = true;
+            same_t = 0.97 * mid;
+            cross_t = 1.03 * mid;
+        }
+    }
+    int classify(double t) const { return t < same_t ? 0 : (t <= cross_t ? 1 : 2); }  // 0 same zone, 1 unclear, 2 other zone
+};
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -237,6 +254,7 @@ struct ZoneCache {
     std::map<int, std::vector<Piece>> pool;  // group id -> spare pieces
     size_t pooled = 0;
     int next_id = 0;
+    Calib calib;  // what the probes of this process have shown so far
 };
 constexpr size_t POOL_CAP = 10;  // pieces (3 GiB) kept at most
 std::map<int, ZoneCache> g_zones;
@@ -336,7 +354,8 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         std::vector<Cand> unclear;
         std::vector<Piece> spacers;
         size_t walked = 0;
-        double one_zone = 0;  // S: this process' one-zone speed of the probe (see SAME_RATIO)
+        std::vector<std::pair<double, int>> decided;  // (probe, class) of this search: rechecked when the calibration turns relative
+        bool restarted = false;
         int tries_after_good = 0;
         bool exportable = false;
         auto give_back = [&] {  // everything that is not part of the buffer
@@ -352,11 +371,11 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             spacers.clear();
         };
         try {
-            // also bounded in time (MEMGYM_OBS_SEARCH_MS, default 3,000): on memory a previous process dirtied the driver
+            // also bounded in time (MEMGYM_OBS_SEARCH_MS, default 1,500): on memory a previous process dirtied the driver
             // wipes what it hands out (~27 ms per GiB)
             static const double max_ms = [] {
                 const char* e = getenv("MEMGYM_OBS_SEARCH_MS");
-                return e ? atof(e) : 3000.0;
+                return e ? atof(e) : 1500.0;
             }();
             auto elapsed_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
             while ((usable(half) < k || groups.size() < 2) && walked <= search_budget_bytes && elapsed_ms() < max_ms) {
@@ -364,21 +383,36 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
                 if (!c.make(device, exportable)) break;
                 int home = -1;
                 bool odd = false;
-                if (one_zone == 0) {
-                    one_zone = probe_tbps(c.va, c.va);
-                    if (debug) fprintf(stderr, "mg_obs_alloc: one-zone calibration (a piece with itself) %.2f TB/s\n", one_zone);
-                }
                 for (size_t j = 0; j < groups.size() && home < 0; ++j) {
                     c.tbps = probe_tbps(ref_va(groups[j]), c.va);
-                    if (c.tbps < one_zone) one_zone = std::max(c.tbps, 0.9 * one_zone);  // follow slower pairs, not outliers
-                    if (c.tbps <= one_zone * SAME_RATIO) {
+                    Z.calib.observe(c.tbps);
+                    const int cls = Z.calib.classify(c.tbps);
+                    decided.push_back({c.tbps, cls});
+                    if (cls == 0) {
                         home = (int)j;
                         I.probe_same_tbps = std::max(I.probe_same_tbps, c.tbps);
-                    } else if (c.tbps < one_zone * CROSS_RATIO) {
+                    } else if (cls == 1) {
                         odd = true;
                         break;
                     } else {
                         I.probe_cross_tbps = I.probe_cross_tbps == 0 ? c.tbps : std::min(I.probe_cross_tbps, c.tbps);
+                    }
+                }
+                if (!restarted && Z.calib.relative) {  // would the thresholds as they stand now have decided differently before?
+                    bool differs = false;
+                    for (auto& d : decided) differs = differs || Z.calib.classify(d.first) != d.second;
+                    if (differs) {
+                        if (debug) fprintf(stderr, "mg_obs_alloc: thresholds now %.2f / %.2f TB/s (relative): starting over\n", Z.calib.same_t, Z.calib.cross_t);
+                        restarted = true;
+                        c.drop();
+                        for (auto& g : groups)
+                            for (auto& q : g.pcs) q.drop();
+                        groups.clear();
+                        for (auto& q : unclear) q.drop();
+                        unclear.clear();
+                        decided.clear();
+                        I.probe_same_tbps = I.probe_cross_tbps = 0;
+                        continue;
                     }
                 }
                 if (debug)

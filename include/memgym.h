@@ -190,11 +190,12 @@ int mg_peek_errors(mg_env* env, int* flags);
  * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = an eighth of the free memory, at most 32 GiB: that much
  * VRAM is transiently unavailable to other processes on the GPU; 0 = no search.  A pristine VRAM can hand out 100-130 GiB
  * of ONE zone in a row: with the default budget such a process gets the plain allocation, info.zones == 1).  Pieces are
- * classified by the RATIO of the probe to the process' own one-zone speed, not by absolute TB/s.  Buffers of 304 MiB or
+ * classified by thresholds that start from the figures measured on the development boxes and turn RELATIVE (geometric
+ * mean of the slowest and the fastest pair seen, -/+ 3 %) once both kinds of pair have been observed.  Buffers of 304 MiB or
  * less, and runtimes without hipMemCreate, get a plain hipMalloc.  The range is accessible from the owning device and from
  * every device that reports peer access to it.  Virtual address ranges are never returned to the runtime (a reused range can
  * keep stale translations on ROCm 7.2): a process that allocates and frees buffers for ever uses address space, not memory.
- * Synchronous; 2-10 ms typically, bounded by MEMGYM_OBS_SEARCH_MS (3 s).  mg_obs_free releases a buffer obtained here
+ * Synchronous; 2-10 ms typically, bounded by MEMGYM_OBS_SEARCH_MS (1.5 s).  mg_obs_free releases a buffer obtained here
  * (after synchronising the device); the pieces go to a pool of at most ten for the next buffer. */
 typedef struct mg_obs_alloc_info {
     int zones;               /* 2, 3 = pieces from that many zones; 1 = no second zone within the budget (plain

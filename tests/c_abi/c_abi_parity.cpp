@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
     mg_env* env = nullptr;
     MG_OK(mg_create(env_id, n, 0, &env));
     const int adim = mg_action_dim(env), n_act = adim == 1 ? 4 : 3;
+    // optional 5th argument: the number of instance groups (include/memgym.h mg_set_groups; results must not depend on it)
+    if (argc > 4) MG_OK(mg_set_groups(env, atoi(argv[4])));
 
     uint8_t *obs_d, *done_d;
     float* rew_d;
@@ -84,6 +86,18 @@ int main(int argc, char** argv) {
         printf("MISMATCH in the reset frames\n");
         return 1;
     }
+    // the versioned info struct: the step reward as the reference's Python float (a double) next to its float32 rounding
+    double* rew64_d;
+    HIP_OK(hipMalloc((void**)&rew64_d, sizeof(double) * n));
+    std::vector<double> rew64(n);
+    mg_info_buffers info;
+    memset(&info, 0, sizeof(info));
+    info.reward64_dev = rew64_d;
+    if (mg_step(env, act_d, obs_d, rew_d, done_d, nullptr, &info, 1, stream) == 0) {  // struct_size still 0: must be refused
+        printf("a mg_info_buffers without struct_size was accepted\n");
+        return 1;
+    }
+    info.struct_size = sizeof(info);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     long episodes = 0;
     for (int t = 0; t < steps; ++t) {
@@ -92,14 +106,15 @@ int main(int argc, char** argv) {
             act[k] = (int32_t)((lcg >> 33) % (uint64_t)n_act);
         }
         HIP_OK(hipMemcpyAsync(act_d, act.data(), sizeof(int32_t) * act.size(), hipMemcpyHostToDevice, stream));
-        MG_OK(mg_step(env, act_d, obs_d, rew_d, done_d, nullptr, nullptr, 1, stream));
+        MG_OK(mg_step(env, act_d, obs_d, rew_d, done_d, nullptr, &info, 1, stream));
+        HIP_OK(hipMemcpyAsync(rew64.data(), rew64_d, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipMemcpyAsync(obs.data(), obs_d, frame * n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipMemcpyAsync(rew.data(), rew_d, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipMemcpyAsync(done.data(), done_d, n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         mgo_batch_step(ref, act.data(), 1, want.data(), want_rew.data(), want_done.data());
         for (int i = 0; i < n; ++i) {
-            if (done[i] != want_done[i] || rew[i] != (float)want_rew[i] || memcmp(&obs[frame * i], &want[frame * i], frame) != 0) {
+            if (done[i] != want_done[i] || rew[i] != (float)want_rew[i] || rew64[i] != want_rew[i] || memcmp(&obs[frame * i], &want[frame * i], frame) != 0) {
                 printf("MISMATCH at step %d, instance %d: done %d/%d reward %g/%g\n", t, i, done[i], want_done[i], rew[i], want_rew[i]);
                 return 1;
             }
@@ -112,7 +127,25 @@ int main(int argc, char** argv) {
         printf("device error flags 0x%x\n", flags);
         return 1;
     }
-    printf("OK %s: %d instances x %d steps, %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, episodes);
+    {   // checkpoint blob: header checked, a blob of another handle shape refused
+        std::vector<char> blob(mg_state_size(env));
+        MG_OK(mg_get_state(env, blob.data(), blob.size()));
+        MG_OK(mg_set_state(env, blob.data(), blob.size()));
+        mg_env* other = nullptr;
+        MG_OK(mg_create(env_id, n + 1, 0, &other));
+        if (mg_set_state(other, blob.data(), blob.size()) == 0) {
+            printf("a state blob of %d instances was accepted by a handle of %d\n", n, n + 1);
+            return 1;
+        }
+        mg_destroy(other);
+        blob[0] ^= 1;
+        if (mg_set_state(env, blob.data(), blob.size()) == 0) {
+            printf("a state blob with a broken magic was accepted\n");
+            return 1;
+        }
+    }
+    printf("OK %s: %d instances x %d steps in %d group(s), %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, (int)mg_groups(env), episodes);
+    (void)hipFree(rew64_d);
     mg_destroy(env);
     mgo_batch_destroy(ref);
     (void)hipFree(obs_d); (void)hipFree(done_d); (void)hipFree(rew_d); (void)hipFree(act_d); (void)hipFree(seeds_d);

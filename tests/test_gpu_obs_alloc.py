@@ -84,7 +84,7 @@ def test_hundred_create_destroy_cycles_do_not_leak():
     assert free0 - free1 <= (11 * 304 << 20) + (64 << 20), "VRAM not returned: %.2f GiB" % ((free0 - free1) / 2 ** 30)
     # address space is never handed back (stale translations on ROCm 7.2): bounded use, far from the 128-TiB space
     assert va1 - va0 < 1 << 40, "%.1f GiB of address space for 100 buffers" % ((va1 - va0) / 2 ** 30)
-    assert worst < 5.0
+    assert worst < 8.0  # MEMGYM_OBS_SEARCH_MS (1.5 s by default) bounds the search itself; the rest is creating / releasing fillers
 
 
 WORKER = r'''
