@@ -38,6 +38,8 @@ struct MysteryParams {
     int max_steps, show_origin, show_goal, visual_feedback, show_past_path, show_background, show_stamina, stamina_level, depth;
     int agent_radius, sprite_dim, v_axis_i, v_diag_i, tile, cross_dim;
     int camera_offset;  // integral at the supported camera_offset_scale values
+    int svc_prio;       // wave priority of the path-service waves inside the fused raster launches (s_setprio)
+    int path_help;      // frame workgroups help with long path queues (MEMGYM_PATH_HELP=0: the 128 dedicated workgroups alone, round 2)
     OptList cardinal;
     double r_goal, r_fall, r_progress, r_dense, r_step;
 };
@@ -1136,10 +1138,11 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
         // clearing waits for all of them, in the short-queue case whatever a late frame workgroup reads -- the count or 0 -- tells
         // it not to take part)
         const int count = queue_count(&io.qctr[QC_COUNT], n);
-        const int helpers = count > PATH_MASS ? min(PATH_HELP_MAX, (count + 3) / 4 - PATH_WGS) : 0;
+        const int helpers = (P.path_help && count > PATH_MASS) ? min(PATH_HELP_MAX, (count + 3) / 4 - PATH_WGS) : 0;
         const int busy = PATH_WGS + helpers;
         if ((int)blockIdx.x < busy) {
             if (count > 0) {
+                if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
                 path_ws_init(smem);
                 const PathWS W{smem, io.jump};
                 const bool me = (threadIdx.x & 63) == 0;
@@ -1166,6 +1169,7 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == busy - 1) {  // last participant out
                 io.qctr[QC_COUNT] = 0;
@@ -1526,6 +1530,8 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
     R.tid = threadIdx.x;
     const int tid = threadIdx.x;
     if (blockIdx.x < svc) {
+        // the service waves run a long dependent instruction chain next to memory-bound raster waves: let them issue first
+        if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
         uint8_t* ws = smem + FRAME_BYTES;  // the path workspace lives in the (unused) mask words behind the frame
         path_ws_init(ws);
         const PathWS W{ws, io.jump};
@@ -1590,6 +1596,8 @@ class MysteryFamily : public Family {
         agent_scale_ = 1.0 * SCALE;
         agent_speed_ = 12.0 * SCALE;
         P_.visual_feedback = 1;
+        P_.svc_prio = [] { const char* e = getenv("MEMGYM_SVC_PRIO"); return e ? atoi(e) : 0; }();
+        P_.path_help = [] { const char* e = getenv("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
         P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
         if (endless) {
             P_.max_steps = -1; P_.show_past_path = 1; camera_offset_scale_ = 5.0; P_.stamina_level = 20;

@@ -34,8 +34,9 @@ constexpr int FILL_STEP = 32;               // filler handles per step of the wa
 constexpr int PROBE_GRID = 14336;
 // Classification of a probed pair of pieces.  Pairs in one zone measured 4.9-5.5 TB/s, pairs across zones 6.1-6.5
 // (profiles/r02_zones.md) -- on THESE boxes.  Those absolute figures are only the PRIOR (round 2 classified by them alone):
-// every probe of two distinct pieces feeds the per-device extremes (Calib), and as soon as they are 12 % apart -- both kinds
-// of pair have been seen in this process -- the thresholds become relative: the geometric mean of the extremes -/+ 3 %.  A
+// every probe of two distinct pieces feeds the per-device extremes (Calib), and as soon as they are 15 % apart -- more than
+// pairs of one kind differ among themselves (4.9-5.5: 12 %), so both kinds have been seen in this process -- the thresholds
+// become relative: the geometric mean of the extremes -/+ 3 %.  A
 // search whose earlier decisions the calibrated thresholds would change starts over once.  (A piece paired with ITSELF is no
 // calibration: both windows then hit the same cache lines, 11.6 TB/s.)  MEMGYM_OBS_SAME_TBPS / MEMGYM_OBS_CROSS_TBPS set the prior.
 static const double PRIOR_SAME_TBPS = getenv("MEMGYM_OBS_SAME_TBPS") ? atof(getenv("MEMGYM_OBS_SAME_TBPS")) : 5.35;
@@ -47,7 +48,7 @@ struct Calib {
     void observe(double t) {
         lo = std::min(lo, t);
         hi = std::max(hi, t);
-        if (hi >= 1.12 * lo) {
+        if (hi >= 1.15 * lo) {
             const double mid = std::sqrt(lo * hi);
             relative = true;
             same_t = 0.97 * mid;
@@ -294,11 +295,12 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         *out = nullptr;
         size_t free_b = 0, total_b = 0;
         MG_HIP(hipMemGetInfo(&free_b, &total_b));
-        // Default budget of the transient walk: an eighth of the free memory, at most 32 GiB (round 2: 55 % / 160 GiB --
-        // other processes on the GPU could run out of memory while a search held that much).  Exportable pieces usually
-        // come from another zone without any walk (typically 0-3 GiB are touched); a pristine VRAM that needs the long walk
-        // gets the plain allocation instead, or the caller raises the budget (MEMGYM_OBS_SEARCH_GB).
-        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 8, 32 * GiB);
+        // Default budget of the transient walk: a quarter of the free memory, at most 64 GiB (round 2: 55 % / 160 GiB --
+        // other processes on the GPU could run out of memory while a search held that much; 32 GiB left one in three
+        // processes of a busy box with a one-zone buffer).  Usually nothing is walked at all (the first few pieces already
+        // differ); a pristine VRAM that needs the long walk gets the plain allocation instead, or the caller raises the
+        // budget (MEMGYM_OBS_SEARCH_GB).
+        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 4, 64 * GiB);
         const size_t k = (bytes + PIECE - 1) / PIECE;
         auto plain = [&](int zones) {  // (called without the lock)
             void* p = nullptr;
