@@ -524,6 +524,10 @@ class MortarFamily : public Family {
         P_.max_steps = -1;
         P_.initial_count = 1;
         P_.cmd_cap = variant == V_ENDLESS ? 512 : 32;
+        if (variant == V_ENDLESS) {  // tests only (tests/test_gpu_error_bits.py): a small capacity makes the overflow reachable
+            const char* e = getenv("MEMGYM_EMM_CMD_CAP");
+            if (e && atoi(e) >= 4 && atoi(e) <= 512) P_.cmd_cap = atoi(e);
+        }
         st_command_count_.set(P_.command_count, {10});
         st_show_dur_.set(P_.show_dur, {3});
         st_show_delay_.set(P_.show_delay, {1});

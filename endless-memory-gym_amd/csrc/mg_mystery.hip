@@ -648,6 +648,17 @@ struct SegRec {
         for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = p[j];
         seg = sg;
     }
+    // the record of segment sg: from `other` if that holds it (prefetched), else from memory
+    __device__ __forceinline__ void load_or_take(const MysteryIO& io, int i, int sg, const SegRec& other) {
+        if (sg == seg) return;
+        if (other.seg == sg) {
+#pragma unroll
+            for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = other.w[j];
+            seg = sg;
+            return;
+        }
+        load(io, i, sg);
+    }
     __device__ __forceinline__ uint8_t byte(int p) const {  // p = 0: node count, 1..: nodes
         uint32_t v = w[0];
 #pragma unroll
@@ -711,7 +722,8 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
     }
 }
 
-__device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float* gt, SegRec& R) {
+// nxt_seg / nxt_w0: dword 0 (node count + first three nodes) of segment nxt_seg if the caller has requested it early, else -1
+__device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float* gt, SegRec& R, int nxt_seg = -1, uint32_t nxt_w0 = 0) {
     R.load(io, i, s.cur_node_seg);
     const uint8_t cb = R.byte(1 + s.cur_node_idx);
     int cx = node_x(s.cur_node_seg, cb), cy = node_y(cb);
@@ -724,6 +736,8 @@ __device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float*
         uint8_t nb;
         if (nseg == R.seg) {
             nb = R.byte(1 + nidx);
+        } else if (nseg == nxt_seg && nidx == 0) {
+            nb = (uint8_t)(nxt_w0 >> 8);
         } else {  // first node of the following segment (keeps R on the current one for the past-path walk)
             nb = seg_ptr(io, i, nseg)[1 + nidx];
         }
@@ -739,7 +753,8 @@ __device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float*
     }
 }
 
-__device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx, SegRec& R) {
+__device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx, SegRec& R,
+                              const SegRec& Rprev) {
     memset(&d, 0, sizeof(d));
     d.valid = 1;
     d.sprite = s.rot8;
@@ -765,10 +780,10 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
                 if (idx < 0) {
                     seg--;
                     if (seg < 0) break;
-                    R.load(io, i, seg);
+                    R.load_or_take(io, i, seg, Rprev);
                     idx = R.byte(0) - 1;
                 }
-                R.load(io, i, seg);
+                R.load_or_take(io, i, seg, Rprev);
                 uint8_t b = R.byte(1 + idx);
                 x = node_x(seg, b);
                 int y = node_y(b);
@@ -820,7 +835,9 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
     s.stamina = P.stamina_level;
     s.max_x = 0;
     s.tiles_visited = 0;
-    emp_fill_desc(P, io, i, s, d, s.ax / P.tile, R);
+    SegRec none;
+    none.seg = -1;
+    emp_fill_desc(P, io, i, s, d, s.ax / P.tile, R, none);
     d.cross_on = 0;
     if (P.show_stamina) d.stamina_red = 0;
 }
@@ -857,8 +874,19 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     double reward = 0.0;
     bool done = false;
     const int seg = s.cur_seg;
-    SegRec R;
+    SegRec R, Rprev;
     R.seg = -1;
+    Rprev.seg = -1;
+    // The segment store is cold (6.6 KB per instance, evicted by the observation stream): every dependent access is a ~2 us
+    // round trip.  The records this step can touch -- the agent's segment, the one before it (past-path tiles), the head of
+    // the one after it (the direction to the next node) -- are requested together, before the first of them is used.
+    int nxt_seg = -1;
+    uint32_t nxt_w0 = 0;
+    if (seg + 1 < s.num_seg) {
+        nxt_seg = seg + 1;
+        nxt_w0 = *reinterpret_cast<const uint32_t*>(seg_ptr(io, i, nxt_seg));
+    }
+    if (seg >= 1 && seg - 1 < s.num_seg) Rprev.load(io, i, seg - 1);
     bool on_path = false;
     if (seg < s.num_seg) {
         uint8_t* sp = seg_ptr(io, i, seg);
@@ -946,7 +974,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     if (s.stamina == 0) done = true;
     s.t++;
     if (s.t == P.max_steps) done = true;
-    emp_direction(io, i, s, gt, R);
+    emp_direction(io, i, s, gt, R, nxt_seg, nxt_w0);
     if (nx > s.max_x && on_path) s.max_x = nx;
     s.ep_sum += reward;
     s.ep_len++;
@@ -961,7 +989,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
     if (done && autoreset) return true;
-    emp_fill_desc(P, io, i, s, d, nx, R);
+    emp_fill_desc(P, io, i, s, d, nx, R, Rprev);
     return false;
 }
 
@@ -1111,89 +1139,6 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
         g.store(io.rng, i);  // unchanged streams are rewritten with the same words
         io.core[i] = s;
         io.desc[i] = d;
-    }
-}
-
-// The queued resets of a deferred step are served INSIDE the raster launch: its first PATH_WGS workgroups do not draw frames
-// but drain the queue, one wave per entry (entry w is wave w's first job, later ones come from a shared counter, the
-// last of them out clears the counters: see emp_serve_kernel), then leave their slots to frame workgroups.  Lane 0 plays the
-// instance: its stream stands right behind the draws of mp_pre_reset, the path's ends are in its record; the path, the walls
-// and the stream come back.  No second stream, no events: a fork/join around a side-stream kernel cost 10 us per step.
-constexpr int PATH_WGS = 128;
-// Long queues (a step in which nearly every instance is truncated at once: t == max_steps for all survivors of a batch that
-// was reset together -- every 128 steps for MysteryPath-Grid's defaults, every 512 for MysteryPath-v0): the first
-// PATH_HELP_MAX FRAME workgroups serve entries as well before they start on their frames (a reset frame shows nothing of
-// the path, so no frame waits for one).  128 + 1,664 = 1,792 = the workgroups resident at once (7 per CU): every wave of
-// the chip's first round takes entries w, w + SW, w + 2 SW, ... (static striding: thousands of pops from one counter are
-// 22 ns each, in series).  32,768 paths then take what the cooperative generator's scalar-issue bound allows (~80 paths
-// per us chip-wide, profiles/r03_mass_resets.md) instead of 64 paths in a row on 512 waves (1.3 ms).
-constexpr int PATH_HELP_MAX = 1664;
-constexpr int PATH_MASS = 2 * 4 * PATH_WGS;  // more than two entries per dedicated wave: call for help
-template <int FMT>
-__global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs,
-                                                                      int n, MysteryParams P, MysteryIO io) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (blockIdx.x < PATH_WGS + PATH_HELP_MAX) {
-        // (every one of these workgroups reads the count BEFORE the last participant can clear it: in the long-queue case the
-        // clearing waits for all of them, in the short-queue case whatever a late frame workgroup reads -- the count or 0 -- tells
-        // it not to take part)
-        const int count = queue_count(&io.qctr[QC_COUNT], n);
-        const int helpers = (P.path_help && count > PATH_MASS) ? min(PATH_HELP_MAX, (count + 3) / 4 - PATH_WGS) : 0;
-        const int busy = PATH_WGS + helpers;
-        if ((int)blockIdx.x < busy) {
-            if (count > 0) {
-                if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
-                path_ws_init(smem);
-                const PathWS W{smem, io.jump};
-                const bool me = (threadIdx.x & 63) == 0;
-                const int waves = busy * 4;
-                for (int idx = bcast((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), 0); idx < count; idx += waves) {
-                    const int i = bcast(io.queue[idx], 0);
-                    Pcg g;
-                    PathReq req;
-                    req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
-                    if (me) {
-                        g.load(io.rng, i);
-                        const MysteryCore c = io.core[i];
-                        req.need = 1; req.sx = c.sx; req.sy = c.sy; req.ex = c.ex; req.ey = c.ey;
-                    } else {
-                        g.state = g.inc = 0; g.buf = 0; g.has = false;
-                    }
-                    int len = 0;
-                    uint64_t pm = 0;
-                    serve_mp(W, req, g, io.err, len, pm, io.walls, i);
-                    if (me) {
-                        io.core[i].path_mask = pm;
-                        io.core[i].path_len = (uint8_t)len;
-                        g.store(io.rng, i);
-                    }
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
-            if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == busy - 1) {  // last participant out
-                io.qctr[QC_COUNT] = 0;
-                io.qctr[QC_HEAD] = 0;
-                io.qctr[QC_LEFT] = 0;
-            }
-            if (blockIdx.x < PATH_WGS) return;
-            __syncthreads();  // a helper goes on to its frames: the path workspace in LDS is the frame from here on
-        }
-    }
-    RasterCtx R;
-    R.frame = smem;
-    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
-    R.A = A;
-    R.T = A.tables;
-    R.tid = threadIdx.x;
-    const int tid = threadIdx.x, stride = (int)gridDim.x - PATH_WGS;
-    for (int env = (int)blockIdx.x - PATH_WGS; env < n; env += stride) {
-        const MysteryDesc* d = descs + env;
-        if (MysteryComposer::skip(d)) continue;
-        MysteryComposer::compose(d, R);
-        __syncthreads();
-        store_frame<FMT, false>(smem, obs, env, tid);
-        __syncthreads();
     }
 }
 
@@ -1450,6 +1395,118 @@ __device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, Myster
     s.end_y = (int8_t)ey;
 }
 
+// The queued resets of a deferred step are served INSIDE the raster launch: its first PATH_WGS workgroups do not draw frames
+// but drain the queue, one wave per entry (entry w is wave w's first job, later ones come from a shared counter, the
+// last of them out clears the counters: see emp_serve_kernel), then leave their slots to frame workgroups.  Lane 0 plays the
+// instance: its stream stands right behind the draws of mp_pre_reset, the path's ends are in its record; the path, the walls
+// and the stream come back.  No second stream, no events: a fork/join around a side-stream kernel cost 10 us per step.
+constexpr int PATH_WGS = 128;
+// Long queues (a step in which nearly every instance is truncated at once: t == max_steps for all survivors of a batch that
+// was reset together -- every 128 steps for MysteryPath-Grid's defaults, every 512 for MysteryPath-v0): the first
+// PATH_HELP_MAX FRAME workgroups serve entries as well before they start on their frames (a reset frame shows nothing of
+// the path, so no frame waits for one).  128 + 1,664 = 1,792 = the workgroups resident at once (7 per CU): every wave of
+// the chip's first round takes entries w, w + SW, w + 2 SW, ... (static striding: thousands of pops from one counter are
+// 22 ns each, in series).  32,768 paths then take what the cooperative generator's scalar-issue bound allows (~80 paths
+// per us chip-wide, profiles/r03_mass_resets.md) instead of 64 paths in a row on 512 waves (1.3 ms).
+constexpr int PATH_HELP_MAX = 1664;
+constexpr int PATH_MASS = 2 * 4 * PATH_WGS;  // more than two entries per dedicated wave: call for help
+// ... and with the LANE-per-path generator (lane_path: 64 paths per wave, twice the cooperative generator's throughput when
+// there are enough paths to fill the lanes -- 107 vs 215 us per 32,768 paths, profiles/r03_mass_resets.md): wave 0 of every
+// participating workgroup takes 64 entries, one per lane, its workspace (LW_BYTES = 19,904 B) is the workgroup's frame.
+static_assert(LW_BYTES <= RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
+template <int FMT>
+__global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs,
+                                                                      int n, MysteryParams P, MysteryIO io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (blockIdx.x < PATH_WGS + PATH_HELP_MAX) {
+        // (every one of these workgroups reads the count BEFORE the last participant can clear it: in the long-queue case the
+        // clearing waits for all of them, in the short-queue case whatever a late frame workgroup reads -- the count or 0 -- tells
+        // it not to take part)
+        const int count = queue_count(&io.qctr[QC_COUNT], n);
+        const bool mass = P.path_help && count > PATH_MASS;
+        const bool by_lanes = mass && P.path_help == 1;  // MEMGYM_PATH_HELP=2: helpers with the cooperative generator
+        const int want = by_lanes ? (count + 63) / 64 : (count + 3) / 4;  // workgroups for one entry per lane / per wave
+        const int helpers = mass ? max(0, min(PATH_HELP_MAX, want - PATH_WGS)) : 0;
+        const int busy = PATH_WGS + helpers;
+        if ((int)blockIdx.x < busy) {
+            if (by_lanes) {
+                lane_ws_init(smem);
+                if (threadIdx.x < 64) {
+                    const LaneWS LW{smem, (int)threadIdx.x};
+                    for (int idx = blockIdx.x * 64 + threadIdx.x; idx < count; idx += busy * 64) {
+                        const int i = io.queue[idx];
+                        Pcg g;
+                        g.load(io.rng, i);
+                        const MysteryCore c = io.core[i];
+                        uint64_t pm = 0, wl = 0;
+                        int len = lane_path(g, LW, c.sx, c.sy, c.ex, c.ey, pm, wl);
+                        if (len < 0) {
+                            raise_error(io.err, 2);
+                            len = 0;
+                            pm = 0;
+                        }
+                        io.core[i].path_mask = pm;
+                        io.core[i].path_len = (uint8_t)len;
+                        if (io.walls) io.walls[i] = wl;
+                        g.store(io.rng, i);
+                    }
+                }
+            } else if (count > 0) {
+                if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
+                path_ws_init(smem);
+                const PathWS W{smem, io.jump};
+                const bool me = (threadIdx.x & 63) == 0;
+                const int waves = busy * 4;
+                for (int idx = bcast((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), 0); idx < count; idx += waves) {
+                    const int i = bcast(io.queue[idx], 0);
+                    Pcg g;
+                    PathReq req;
+                    req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
+                    if (me) {
+                        g.load(io.rng, i);
+                        const MysteryCore c = io.core[i];
+                        req.need = 1; req.sx = c.sx; req.sy = c.sy; req.ex = c.ex; req.ey = c.ey;
+                    } else {
+                        g.state = g.inc = 0; g.buf = 0; g.has = false;
+                    }
+                    int len = 0;
+                    uint64_t pm = 0;
+                    serve_mp(W, req, g, io.err, len, pm, io.walls, i);
+                    if (me) {
+                        io.core[i].path_mask = pm;
+                        io.core[i].path_len = (uint8_t)len;
+                        g.store(io.rng, i);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            if (threadIdx.x == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == busy - 1) {  // last participant out
+                io.qctr[QC_COUNT] = 0;
+                io.qctr[QC_HEAD] = 0;
+                io.qctr[QC_LEFT] = 0;
+            }
+            if (blockIdx.x < PATH_WGS) return;
+            __syncthreads();  // a helper goes on to its frames: the path workspace in LDS is the frame from here on
+        }
+    }
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = A.tables;
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x, stride = (int)gridDim.x - PATH_WGS;
+    for (int env = (int)blockIdx.x - PATH_WGS; env < n; env += stride) {
+        const MysteryDesc* d = descs + env;
+        if (MysteryComposer::skip(d)) continue;
+        MysteryComposer::compose(d, R);
+        __syncthreads();
+        store_frame<FMT, false>(smem, obs, env, tid);
+        __syncthreads();
+    }
+}
+
 // mg_reset of every Endless-MysteryPath instance: one LANE per instance (emp_serve_kernel: one wave per instance)
 __global__ __launch_bounds__(64) void emp_reset_lanes_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds, float* gt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1596,7 +1653,8 @@ class MysteryFamily : public Family {
         agent_scale_ = 1.0 * SCALE;
         agent_speed_ = 12.0 * SCALE;
         P_.visual_feedback = 1;
-        P_.svc_prio = [] { const char* e = getenv("MEMGYM_SVC_PRIO"); return e ? atoi(e) : 0; }();
+        // Endless-MysteryPath: 187-189 -> 175-182 us per fused launch (profiles/r03_emp.md); no effect on MysteryPath-Grid's
+        P_.svc_prio = [endless] { const char* e = getenv("MEMGYM_SVC_PRIO"); return e ? atoi(e) : (endless ? 1 : 0); }();
         P_.path_help = [] { const char* e = getenv("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
         P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
         if (endless) {

@@ -12,7 +12,7 @@ P2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CON
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace -d gpurun_out/${TAG}_p$i -o p -- python bench.py --env $E --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-events > gpurun_out/${TAG}_p$i.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace -d gpurun_out/${TAG}_p$i -o p -- python bench.py --env $E --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-events --no-traffic --no-c1 > gpurun_out/${TAG}_p$i.log 2>&1
 done
 python tools/rocpd_summary.py gpurun_out/${TAG}_p1/p_results.db gpurun_out/${TAG}_p2/p_results.db | grep -v "at::native\|__amd_rocclr\|elementwise_kernel" > gpurun_out/${TAG}.md
 rm -rf gpurun_out/${TAG}_p1 gpurun_out/${TAG}_p2
