@@ -324,7 +324,10 @@ int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream) {
         uint8_t* frames = nullptr;
         MG_HIP(hipMalloc((void**)&frames, (size_t)env->num_envs * MG_OBS_BYTES));
         try {
-            for (int g = 0; g < env->groups(); ++g) env->fams[g]->raster_debug(frames + (size_t)env->base[g] * MG_OBS_BYTES, st);
+            for (int g = 0; g < env->groups(); ++g) {
+                env->fams[g]->sync_state();
+                env->fams[g]->raster_debug(frames + (size_t)env->base[g] * MG_OBS_BYTES, st);
+            }
             const size_t total = (size_t)env->num_envs * 336 * 336;
             const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
             hipLaunchKernelGGL(debug_stretch_kernel, dim3(grid), dim3(256), 0, st, frames, rgb_dev, env->num_envs);
@@ -382,6 +385,7 @@ int mg_get_state(mg_env* env, void* host_buf, size_t size) {
     return guarded(env, [&] {
         if (!host_buf || size < mg_state_size(env)) throw std::runtime_error("mg_get_state: buffer too small");
         MG_HIP(hipDeviceSynchronize());
+        for (auto* f : env->fams) f->sync_state();
         StateHeader h;
         memset(&h, 0, sizeof(h));
         memcpy(h.magic, "MGSTATE1", 8);
@@ -509,6 +513,7 @@ int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
         MG_HIP(hipDeviceSynchronize());
         int g = 0;
         while (g + 1 < env->groups() && i >= env->base[g + 1]) ++g;
+        env->fams[g]->sync_state();
         env->fams[g]->debug_rng(i - env->base[g], out);
     });
 }

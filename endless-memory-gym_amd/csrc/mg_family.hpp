@@ -200,6 +200,9 @@ class Family {
     virtual std::vector<std::pair<void*, size_t>> state_blobs() = 0;
     // called by mg_set_state after the blobs were restored: the instances now carry seeded RNG streams
     virtual void on_state_loaded() {}
+    // called before anything looks at the state from outside (mg_get_state, mg_debug_rng, mg_render_debug): work a family has
+    // put off without changing any result (Endless Mystery Path: owed path segments) is done now.  Synchronous.
+    virtual void sync_state() {}
     virtual void debug_rng(int i, uint64_t out[6]) = 0;
     // device-side error bits accumulated since the last call (0 = none); synchronises
     virtual int poll_errors() { return 0; }

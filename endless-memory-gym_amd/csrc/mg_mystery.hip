@@ -39,6 +39,7 @@ struct MysteryParams {
     int agent_radius, sprite_dim, v_axis_i, v_diag_i, tile, cross_dim;
     int camera_offset;  // integral at the supported camera_offset_scale values
     int svc_prio;       // wave priority of the path-service waves inside the fused raster launches (s_setprio)
+    int lazy;           // Endless: a reset generates ONE of its three initial segments, the other two are owed (see EMP_OWED)
     int path_help;      // frame workgroups help with long path queues (MEMGYM_PATH_HELP=0: the 128 dedicated workgroups alone, round 2)
     OptList cardinal;
     double r_goal, r_fall, r_progress, r_dense, r_step;
@@ -46,7 +47,7 @@ struct MysteryParams {
 
 struct __attribute__((aligned(16))) MysteryCore {
     int16_t ax, ay;
-    uint8_t rot8, off, cross_on, path_len;
+    uint8_t rot8, off, cross_on, path_len;  // path_len: finite variants; endless: segments OWED to the instance (EMP_OWED below)
     uint8_t sx, sy, ex, ey;
     int16_t cross_x, cross_y;           // fall_off_rect centre
     int32_t fails, t, ep_len, stamina;
@@ -179,9 +180,10 @@ struct MysteryIO {
     int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
     uint64_t* walls;  // finite: [N] wall cells of the current path generation (bit x*7+y), read by the debug view only
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
+    int* bgq;    // endless: instances that are owed a segment nobody waits for yet (QC_BG_COUNT entries; lane-per-path service)
     const uint4* jump;  // [64][2] PCG64 jump constants {A^(k+1), S_(k+1)} (WaveRng)
 };
-constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_WORDS = 96;  // one 128-byte line each
+constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_BG_COUNT = 96, QC_BG_LEFT = 128, QC_WORDS = 160;  // one 128-byte line each
 // MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
 // the fused launch, drawn by the workgroup that served it).  Only emp_raster_serve_kernel's frame workgroups tell 1 from 2 / 3.
 constexpr uint8_t DESC_QUEUED = 2, DESC_SERVED = 3;
@@ -801,6 +803,19 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
     }
 }
 
+// ---- lazy initial segments --------------------------------------------------------------------------------------------
+// The reference's reset generates three path segments (endless_mystery_path.py:222-224 -> pygame_assets.py:523-527), ~30 us
+// of dependent work each for a wave: the critical path of the step's fused raster / service launch.  Only the FIRST one is
+// needed for the reset frame, its ground truth and the next steps (the agent starts eight tiles before the second): with
+// P.lazy a reset generates one segment and records two as OWED (MysteryCore::path_len); each of the instance's next steps
+// queues ONE owed segment as a background job nobody waits for -- served by the lane-per-path generator beside the frames
+// (emp_raster_serve_kernel) -- and everything that could observe the difference generates what is owed first: a step that
+// gets near the end of what exists (emp_step_a), the next reset (RNG order: the old episode's owed segments are generated,
+// and discarded, before the new episode's first), and every look at the state (Family::sync_state: checkpoints, RNG words,
+// the debug view).  The instance's random numbers are consumed in exactly the reference's order; nothing else draws from
+// the stream of an Endless Mystery Path instance.
+#define EMP_OWED(s) ((s).path_len)
+
 // EndlessMysteryPathEnv.reset (endless_mystery_path.py:195-280) around the three initial segments (serve_emp)
 __device__ __forceinline__ void emp_pre_reset(MysteryCore& s) {
     s.t = 0;
@@ -866,7 +881,12 @@ __device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, const i
     nx = floordiv_pos(s.ax, P.tile);
     ny = floordiv_pos(s.ay, P.tile);
     s.cur_seg = nx / (G + 1);
-    return s.cur_seg > s.num_seg - 2 ? 1 : 0;
+    // `current_segment > num_segments - 2` counts the owed segments as the reference has them; and whatever this step could
+    // read of a segment that is still owed (the next node's direction at the end of the last generated segment) makes the
+    // owed ones due now -- conservative: within two columns of the end of what exists
+    const int owed = EMP_OWED(s);
+    if (s.cur_seg > s.num_seg + owed - 2) return 1;
+    return (owed > 0 && nx >= (G + 1) * s.num_seg - 2) ? 1 : 0;
 }
 // second part; returns true if the instance finished and is to be reset in this call
 __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
@@ -1169,6 +1189,8 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryI
     if (q) {
         queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         d.valid = DESC_QUEUED;
+    } else if (P.lazy && EMP_OWED(s) > 0) {  // one owed segment per step, as a job nobody waits for
+        queue_push(io.bgq, &io.qctr[QC_BG_COUNT], P.n, i, io.err);
     }
     io.core[i] = s;
     io.desc[i] = d;
@@ -1201,16 +1223,29 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
     }
     int reset_me = 1;
     if (entry & EMP_Q_SEGMENT) {
-        serve_emp(io, W, i, me ? 1 : 0, s, g);
+        // the new segment is due: whatever is still owed comes first (stream order), or -- emp_step_a's conservative test --
+        // only what is owed is due and `current_segment > num_segments - 2` does not hold yet
+        int want = 0;
+        if (me) {
+            want = EMP_OWED(s) + ((s.cur_seg > s.num_seg + EMP_OWED(s) - 2) ? 1 : 0);
+            EMP_OWED(s) = 0;
+        }
+        serve_emp(io, W, i, want, s, g);
         if (me)
             reset_me = emp_step_b(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
                                   gti, info, autoreset, d) ? 1 : 0;
         reset_me = bcast(reset_me, 0);
     }
     if (reset_me) {
+        // segments the finished episode is still owed are generated first (and discarded): they come first in the stream
+        const int owed_old = bcast((me && !seeds) ? (int)EMP_OWED(s) : 0, 0);  // (a re-seeded instance starts a new stream)
+        if (owed_old) serve_emp(io, W, i, me ? owed_old : 0, s, g);
         if (me) emp_pre_reset(s);
-        serve_emp(io, W, i, me ? 3 : 0, s, g);
-        if (me) emp_post_reset(P, io, i, s, d, gti);
+        serve_emp(io, W, i, me ? (P.lazy ? 1 : 3) : 0, s, g);
+        if (me) {
+            EMP_OWED(s) = P.lazy ? 2 : 0;
+            emp_post_reset(P, io, i, s, d, gti);
+        }
     }
     if (me) {
         d.valid = DESC_SERVED;
@@ -1507,6 +1542,29 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
     }
 }
 
+// One background job by one lane: the instance's next owed segment (lazy initial segments, EMP_OWED)
+__device__ __forceinline__ void lane_owed_segment(const MysteryIO& io, const LaneWS& W, int i, int how_many) {
+    MysteryCore s = io.core[i];
+    int owed = EMP_OWED(s);
+    if (owed <= 0) return;
+    Pcg g;
+    g.load(io.rng, i);
+    for (int k = 0; k < how_many && owed > 0; ++k, --owed) lane_segment(io, W, i, s, g);
+    // only the fields a segment changes: the instance's record belongs to nobody else between its step and its next step
+    EMP_OWED(s) = (uint8_t)owed;
+    io.core[i] = s;
+    g.store(io.rng, i);
+}
+
+// Everything still owed, for every instance (Family::sync_state: before the state is looked at)
+__global__ __launch_bounds__(64) void emp_flush_owed_kernel(MysteryParams P, MysteryIO io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    lane_ws_init(smem);
+    const LaneWS W{smem, (int)threadIdx.x};
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < P.n) lane_owed_segment(io, W, i, 2);
+}
+
 // mg_reset of every Endless-MysteryPath instance: one LANE per instance (emp_serve_kernel: one wave per instance)
 __global__ __launch_bounds__(64) void emp_reset_lanes_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds, float* gt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1518,11 +1576,20 @@ __global__ __launch_bounds__(64) void emp_reset_lanes_kernel(MysteryParams P, My
     MysteryCore s;
     g.state = g.inc = 0; g.buf = 0; g.has = false;
     memset(&s, 0, sizeof(s));
+    int owed_old = 0;
     if (active) {
         s = io.core[i];
         if (seeds) g.seed((uint64_t)seeds[i]);
-        else g.load(io.rng, i);
+        else {
+            g.load(io.rng, i);
+            owed_old = EMP_OWED(s);  // reset(seed=None): what the old episode is owed comes first in the stream
+        }
+    }
+    for (int k = 0; k < 2; ++k)
+        if (k < owed_old) lane_segment(io, W, i, s, g);
+    if (active) {
         emp_pre_reset(s);
+        EMP_OWED(s) = 0;
     }
     for (int k = 0; k < 3; ++k)
         if (active) lane_segment(io, W, i, s, g);
@@ -1571,9 +1638,17 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 // Measured (32,768 instances, us per step incl. the 26 us of emp_step_kernel; separate launches: 240): 384 / 512 / 768 /
 // 1,024 / 1,536 service workgroups at 7 workgroups per CU (72 VGPRs, the path generator spills) 218 / 217 / 216 / 224 / 234;
 // at 5 per CU (96 VGPRs) 212 / 211 / 215 / 224 / 227; at 4 per CU 210 / 212 / 213 / 219 / 223.
-constexpr int EMP_SVC_WGS = 512;
+#ifndef MG_LAB_EMP_SVC  // measurement builds: -DMG_LAB_EMP_SVC=<workgroups> -DMG_LAB_EMP_LB=<workgroups per CU>
+#define MG_LAB_EMP_SVC 512
+#endif
+#ifndef MG_LAB_EMP_LB
+#define MG_LAB_EMP_LB 5
+#endif
+constexpr int EMP_SVC_WGS = MG_LAB_EMP_SVC;
+constexpr int EMP_BG_WGS = 512;  // frame workgroups that may carry background jobs (64 each: all 32,768 instances at once)
+static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
 template <int FMT>
-__global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
+__global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
                                                                   MysteryParams P, MysteryIO io, float* reward_out, uint8_t* done_out,
                                                                   float* gt, mg_info_buffers info, int autoreset, int svc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1628,6 +1703,28 @@ __global__ __launch_bounds__(256, 5) void emp_raster_serve_kernel(const MysteryD
         }
         return;
     }
+    // Background jobs (owed segments, lazy initial segments): wave 0 of the first ceil(count / 64) FRAME workgroups takes 64
+    // of them, one per lane, with the lane-per-path generator in the workgroup's frame buffer, then the workgroup starts on
+    // its frames; ~105 us that run beside the other workgroups' frames, and nothing of this launch depends on them.  The
+    // last participant clears the counter (participants read it before that can happen, see mystery_raster_paths_kernel).
+    if ((int)blockIdx.x - svc < EMP_BG_WGS) {
+        const int bg = queue_count(&io.qctr[QC_BG_COUNT], n);
+        const int busy = min(EMP_BG_WGS, (bg + 63) / 64);
+        const int b = (int)blockIdx.x - svc;
+        if (b < busy) {
+            lane_ws_init(smem);
+            if (tid < 64) {
+                const LaneWS LW{smem, tid};
+                for (int idx = b * 64 + tid; idx < bg; idx += busy * 64) lane_owed_segment(io, LW, io.bgq[idx], 1);
+            }
+            __syncthreads();
+            if (tid == 0 && atomicAdd(&io.qctr[QC_BG_LEFT], 1) == busy - 1) {
+                io.qctr[QC_BG_COUNT] = 0;
+                io.qctr[QC_BG_LEFT] = 0;
+            }
+            __syncthreads();
+        }
+    }
     const int stride = (int)gridDim.x - svc;
     for (int env = (int)blockIdx.x - svc; env < n; env += stride) {
         const MysteryDesc* d = descs + env;
@@ -1656,6 +1753,7 @@ class MysteryFamily : public Family {
         // Endless-MysteryPath: 187-189 -> 175-182 us per fused launch (profiles/r03_emp.md); no effect on MysteryPath-Grid's
         P_.svc_prio = [endless] { const char* e = getenv("MEMGYM_SVC_PRIO"); return e ? atoi(e) : (endless ? 1 : 0); }();
         P_.path_help = [] { const char* e = getenv("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
+        lazy_wanted_ = endless && [] { const char* e = getenv("MEMGYM_EMP_LAZY"); return e ? atoi(e) != 0 : true; }();
         P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
         if (endless) {
             P_.max_steps = -1; P_.show_past_path = 1; camera_offset_scale_ = 5.0; P_.stamina_level = 20;
@@ -1671,6 +1769,7 @@ class MysteryFamily : public Family {
         rng_.alloc(n);
         err_.alloc();
         queue_.alloc((size_t)n + 32 + QC_WORDS);
+        bgq_.alloc(endless ? (size_t)n : 1);
         {   // WaveRng: s_k = A^k s_0 + S_k inc for k = 1 .. 64 (PCG64's 128-bit LCG, multiplier as in mg_device.hpp Pcg::advance)
             const u128 A = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
             std::vector<uint4> jt(128);
@@ -1742,6 +1841,7 @@ class MysteryFamily : public Family {
         if (P_.endless) {
             mg_info_buffers none;
             memset(&none, 0, sizeof(none));
+            P_.lazy = 0;  // an explicit reset generates all three segments (whatever an old episode is owed comes first)
             if (mask) {
                 hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
                 hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,
@@ -1766,8 +1866,14 @@ class MysteryFamily : public Family {
         if (info) ib = *info;
         prof.begin(0, s);
         if (P_.endless) {
+            // lazy initial segments need the fused launch (its frame workgroups carry the background jobs); any other path
+            // first generates what earlier fused steps left owed
+            const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC;
+            P_.lazy = (fused && lazy_wanted_) ? 1 : 0;
+            if (!P_.lazy && owed_possible_) flush_owed(s);
+            if (P_.lazy) owed_possible_ = true;
             hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
-            if (fuse_serve() && obs_format == MG_OBS_U8_XYC) {  // the queue is served inside the raster launch
+            if (fused) {  // the queue is served inside the raster launch
                 end_logic(s);
                 prof.begin(1, s);
                 const int svc = EMP_SVC_WGS;
@@ -1886,6 +1992,7 @@ class MysteryFamily : public Family {
         o.queue = queue_.p;
         o.walls = P_.endless ? nullptr : walls_.p;
         o.qctr = queue_.p + ((n_ + 31) & ~31);
+        o.bgq = bgq_.p;
         o.jump = jump_.p;
         return o;
     }
@@ -1944,7 +2051,22 @@ class MysteryFamily : public Family {
     bool dirty_ = true, seeded_ = false;
 
    public:
-    void on_state_loaded() override { seeded_ = true; }
+    void on_state_loaded() override {
+        seeded_ = true;
+        owed_possible_ = P_.endless != 0;  // the blob may carry owed segments
+    }
+    void sync_state() override {
+        if (P_.endless && owed_possible_) {
+            MG_HIP(hipDeviceSynchronize());  // steps in flight on the caller's streams come first
+            flush_owed(0);
+            MG_HIP(hipDeviceSynchronize());
+        }
+    }
+    void flush_owed(hipStream_t s) {
+        hipLaunchKernelGGL(emp_flush_owed_kernel, dim3((n_ + 63) / 64), dim3(64), LW_BYTES, s, P_, io());
+        MG_HIP(hipGetLastError());
+        owed_possible_ = false;
+    }
     void raster_debug(void* frames, hipStream_t s) override;
 
    private:
@@ -1954,6 +2076,8 @@ class MysteryFamily : public Family {
     DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
+    DevArray<int> bgq_;    // endless: background jobs (owed segments)
+    bool lazy_wanted_ = false, owed_possible_ = false;
     DevArray<uint4> jump_;  // WaveRng jump constants
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
