@@ -1639,7 +1639,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 // 1,024 / 1,536 service workgroups at 7 workgroups per CU (72 VGPRs, the path generator spills) 218 / 217 / 216 / 224 / 234;
 // at 5 per CU (96 VGPRs) 212 / 211 / 215 / 224 / 227; at 4 per CU 210 / 212 / 213 / 219 / 223.
 #ifndef MG_LAB_EMP_SVC  // measurement builds: -DMG_LAB_EMP_SVC=<workgroups> -DMG_LAB_EMP_LB=<workgroups per CU>
-#define MG_LAB_EMP_SVC 512
+#define MG_LAB_EMP_SVC 384  // round 3, with lazy initial segments (an entry is one path, not three): profiles/r03_emp.md
 #endif
 #ifndef MG_LAB_EMP_LB
 #define MG_LAB_EMP_LB 5
