@@ -214,6 +214,17 @@ Family* make_mortar(int variant, int num_envs);
 Family* make_spot(int endless, int num_envs);
 Family* make_mystery(int variant, int num_envs);
 
+// Workgroup size of the one-lane-per-instance logic kernels (all are written for any multiple of 64 up to 256).
+// MEMGYM_STEP_BLOCK overrides `shipped` per process (measurements: profiles/r03_step_blocks.md).
+inline int step_block(int shipped) {
+    static const int forced = [] {
+        const char* e = getenv("MEMGYM_STEP_BLOCK");
+        const int v = e ? atoi(e) : 0;
+        return (v == 64 || v == 128 || v == 256) ? v : 0;
+    }();
+    return forced ? forced : shipped;
+}
+
 inline int to_int_checked(double v, const char* key) {
     int i = (int)v;
     if ((double)i != v) throw OptionError{-3, std::string("option ") + key + " must be integral"};

@@ -618,7 +618,8 @@ class MortarFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
-        hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), actions, reward, done,
+        const int sb = step_block(256);
+        hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, n_, io(), actions, reward, done,
                            gt_dim() ? gt : nullptr, ib, autoreset);
         end_logic(s);
         prof.begin(1, s);

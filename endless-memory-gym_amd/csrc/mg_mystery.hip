@@ -1872,12 +1872,13 @@ class MysteryFamily : public Family {
             P_.lazy = (fused && lazy_wanted_) ? 1 : 0;
             if (!P_.lazy && owed_possible_) flush_owed(s);
             if (P_.lazy) owed_possible_ = true;
-            hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+            const int sb = step_block(256);
+            hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
             if (fused) {  // the queue is served inside the raster launch
                 end_logic(s);
                 prof.begin(1, s);
                 const int svc = EMP_SVC_WGS;
-                const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + svc;
+                const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + svc;
                 hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
                                    P_, io(), reward, done, gt, ib, autoreset, svc);
                 MG_HIP(hipGetLastError());
@@ -1970,7 +1971,7 @@ class MysteryFamily : public Family {
         return forced >= 0 && forced <= 2 ? forced : (P_.grid != 0 ? 1 : 2);
     }
     void raster_with_paths(void* obs, hipStream_t s) {
-        const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + PATH_WGS;
+        const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + PATH_WGS;
         if (obs_format == MG_OBS_F32_CYX)
             hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
         else if (obs_format == MG_OBS_BF16_CYX)

@@ -46,9 +46,11 @@ constexpr int DISC_RMAX = 64;
 constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
-constexpr int RASTER_GRID = 256 * 7 * 8;      // persistent workgroups; flat between 10,752 and 14,336 at five resident workgroups per CU
+constexpr int RASTER_GRID = 256 * 7 * 8;      // workgroups of a launch over many frames (65,536 and more)
+constexpr int RASTER_GRID_SMALL = 256 * 38;   // ... over 32,768 frames or fewer: see raster_grid()
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
-constexpr int RASTER_LDS_REQUEST = 28 * 1024;  // uint8 format: see launch_raster
+constexpr int RASTER_LDS_REQUEST = 25 * 1024;  // uint8 format: six workgroups per CU, see launch_raster
+constexpr int RASTER_LDS_FUSED = 28 * 1024;    // spot_raster_serve_kernel: five per CU (its reset code needs the 96 VGPRs)
 
 struct StampInfo {
     uint32_t off;  // pixel offset into the stamp data, pixels stored [x][y] (column-major like the frame)
@@ -335,18 +337,29 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     }
 }
 
+// Workgroups of a raster launch over n frames (MEMGYM_RASTER_GRID overrides: tuning experiments).  A workgroup that draws
+// several frames has each next frame's loads queued behind its own stores (gfx9 counts both in vmcnt), a launch of one
+// workgroup per frame pays ~14,000 wave launches: the optimum lies in between and moves with the launch size.  Round 3,
+// Endless-SearingSpotlights at 16,384 frames, same call (profiles/r03_spot_grid.md): 3,584 / 5,120 / 7,168 / 8,960 / 9,728 /
+// 10,752 / 14,336 / 16,384 workgroups at six per CU -> 78.0 / 73.8 / 69.0 / 65.7 / 65.5 / 67.0 / 72.5 / 77.4 us.
+inline int raster_grid(int n) {
+    static const int forced = [] {
+        const char* e = getenv("MEMGYM_RASTER_GRID");
+        return e ? atoi(e) : 0;
+    }();
+    return forced > 0 ? forced : (n <= 32768 ? RASTER_GRID_SMALL : RASTER_GRID);
+}
+
 template <class Composer>
 inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s,
                           const uint8_t* only = nullptr) {
-    static const int tuned = [] {  // MEMGYM_RASTER_GRID overrides the persistent grid size (tuning experiments)
-        const char* e = getenv("MEMGYM_RASTER_GRID");
-        return e ? atoi(e) : RASTER_GRID;
-    }();
+    const int tuned = raster_grid(n);
     // The kernel needs RASTER_LDS (22,176 B: 7 workgroups per CU); for the uint8 format, whose stores are non-temporal,
-    // it asks for 28 KiB = FIVE per CU: that stream is faster with fewer concurrent writers (Endless-SearingSpotlights
-    // raster, same call: 7 per CU 78-82 us, 6: 72-77, 5: 72-73, 4: 81, 3: 138; with plain stores -- the float formats, or
-    // this format without the hint -- it is the other way round, 7: 85, 5: 98: profiles/r01j_ess_raster_ablation.md).
-    // MEMGYM_RASTER_LDS overrides the request (tuning only).
+    // it asks for 25 KiB = SIX per CU: that stream is faster with fewer concurrent writers than fit.  Round 1 (grid 14,336:
+    // 7 per CU 78-82 us, 6: 72-77, 5: 72-73, 4: 81) shipped five; re-swept in round 3 TOGETHER with the grid size
+    // (profiles/r03_spot_grid.md, Endless-SearingSpotlights 16,384 frames): six per CU x 8,960-10,240 workgroups 65.4-66.1 us,
+    // five per CU x 14,336 (round 2) 71.4 us, seven x 8,960 68.4, four 80-84.  With plain stores -- the float formats -- it is
+    // the other way round (7: 85, 5: 98: profiles/r01j_ess_raster_ablation.md).  MEMGYM_RASTER_LDS overrides (tuning only).
     static const int forced_lds = [] {
         const char* e = getenv("MEMGYM_RASTER_LDS");
         return e && atoi(e) >= RASTER_LDS ? atoi(e) : 0;

@@ -187,13 +187,20 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     }
 }
 
+// Workgroups of a raster launch over n frames (MEMGYM_RASTER_GRID overrides: tuning experiments)
+inline int raster_grid(int n) {
+    static const int forced = [] {
+        const char* e = getenv("MEMGYM_RASTER_GRID");
+        return e ? atoi(e) : 0;
+    }();
+    (void)n;
+    return forced > 0 ? forced : RASTER_GRID;
+}
+
 template <class Composer>
 inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s,
                           const uint8_t* only = nullptr) {
-    static const int tuned = [] {  // MEMGYM_RASTER_GRID overrides the persistent grid size (tuning experiments)
-        const char* e = getenv("MEMGYM_RASTER_GRID");
-        return e ? atoi(e) : RASTER_GRID;
-    }();
+    const int tuned = raster_grid(n);
     const int grid = n < tuned ? n : tuned;
     // MEMGYM_RASTER_LDS inflates the LDS request = fewer resident workgroups per CU (tuning only).  Seven per CU (what
     // fits) is the optimum once the observation buffer sits in a fast allocation (profiles/r01l_placement.md):

@@ -1236,13 +1236,14 @@ class SpotFamily : public Family {
         if (info) ib = *info;
         prof.begin(0, s);
         const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets()) ? 1 : 0;
-        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
-        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
+        const int sb = step_block(256);
+        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
+        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
         end_logic(s);
         prof.begin(1, s);
         if (defer) {
-            const int grid = (n_ < RASTER_GRID ? n_ : RASTER_GRID) + SPOT_SVC_WGS;
-#define SPOT_FUSED(EN, BO) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO>), dim3(grid), dim3(256), RASTER_LDS_REQUEST, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), gt)
+            const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + SPOT_SVC_WGS;
+#define SPOT_FUSED(EN, BO) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO>), dim3(grid), dim3(256), RASTER_LDS_FUSED, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), gt)
             if (P_.endless) { if (P_.ordered_holes) SPOT_FUSED(true, true); else SPOT_FUSED(true, false); }
             else { if (P_.ordered_holes) SPOT_FUSED(false, true); else SPOT_FUSED(false, false); }
 #undef SPOT_FUSED
