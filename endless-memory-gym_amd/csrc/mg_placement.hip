@@ -295,12 +295,14 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         *out = nullptr;
         size_t free_b = 0, total_b = 0;
         MG_HIP(hipMemGetInfo(&free_b, &total_b));
-        // Default budget of the transient walk: a quarter of the free memory, at most 64 GiB (round 2: 55 % / 160 GiB --
-        // other processes on the GPU could run out of memory while a search held that much; 32 GiB left one in three
-        // processes of a busy box with a one-zone buffer).  Usually nothing is walked at all (the first few pieces already
-        // differ); a pristine VRAM that needs the long walk gets the plain allocation instead, or the caller raises the
-        // budget (MEMGYM_OBS_SEARCH_GB).
-        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 4, 64 * GiB);
+        // Default budget of the transient walk: half of the free memory, at most 128 GiB (round 2: 55 % / 160 GiB), and
+        // MEMGYM_OBS_SEARCH_MS (1.5 s) on top.  Usually nothing is walked at all (the first few pieces already differ), but a
+        // pristine VRAM can hand out 100-130 GiB of ONE zone in a row (0.3 s of walking there); on memory earlier processes
+        // have dirtied the driver wipes what it hands out (~27 ms per GiB) and the time bound ends the walk after ~55 GiB.
+        // 32 and 64 GiB were tried this round: one in three processes of a busy box ended on a one-zone buffer (-15 % on the
+        // raster).  The fillers are never mapped or touched, but they ARE memory other processes on the same GPU cannot have
+        // while the search lasts: several processes per GPU should set MEMGYM_OBS_SEARCH_GB (or obs_placement="plain").
+        if (search_budget_bytes == MG_OBS_SEARCH_DEFAULT) search_budget_bytes = std::min<size_t>(free_b / 2, 128 * GiB);
         const size_t k = (bytes + PIECE - 1) / PIECE;
         auto plain = [&](int zones) {  // (called without the lock)
             void* p = nullptr;

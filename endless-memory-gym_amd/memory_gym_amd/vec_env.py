@@ -74,8 +74,8 @@ class _ObsMemory:
 def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
     """A tensor of `shape` / `dtype` on `device` whose memory comes from mg_obs_alloc (pieces from two HBM zones, see
     include/memgym.h); returns (tensor, info dict).  The memory is released when the last tensor viewing it goes away.
-    MEMGYM_OBS_SEARCH_GB bounds the transient filler allocations of the search (default: a quarter of the free memory, at
-    most 64 GiB -- VRAM that other processes on the GPU cannot have for the few milliseconds the search lasts; 0 = do not
+    MEMGYM_OBS_SEARCH_GB bounds the transient filler allocations of the search (default: half of the free memory, at
+    most 128 GiB -- VRAM that other processes on the GPU cannot have for the few milliseconds the search lasts; 0 = do not
     search).  The buffer is accessible from this device and from every device with peer access to it."""
     device = torch.device(device)
     elem = torch.empty((), dtype=dtype).element_size()

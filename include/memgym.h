@@ -187,7 +187,7 @@ int mg_peek_errors(mg_env* env, int* flags);
  * probe, half of them from the first piece's zone and half from elsewhere, mapped alternately into one contiguous
  * virtual range (rounded up to whole pieces).  Pieces it does not need and spacer allocations of 8 GiB that are never
  * mapped or written keep the driver's allocator moving during the search and are released before the call returns (at
- * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = a quarter of the free memory, at most 64 GiB: that much
+ * most `search_budget_bytes` in total; MG_OBS_SEARCH_DEFAULT = half of the free memory, at most 128 GiB: that much
  * VRAM is transiently unavailable to other processes on the GPU; 0 = no search.  A pristine VRAM can hand out 100-130 GiB
  * of ONE zone in a row: with the default budget such a process gets the plain allocation, info.zones == 1).  Pieces are
  * classified by thresholds that start from the figures measured on the development boxes and turn RELATIVE (geometric
