@@ -237,7 +237,19 @@ int mg_set_groups(mg_env* env, int groups) {
         if (groups != 1 && groups != 2 && groups != 4 && groups != 8) throw std::runtime_error("mg_set_groups: 1, 2, 4 or 8 groups");
         if (env->num_envs % groups != 0 || env->num_envs / groups < 1) throw std::runtime_error("mg_set_groups: num_envs must be divisible by the number of groups");
         if (env->started) throw std::runtime_error("mg_set_groups: the grouping is fixed by the first mg_reset");
-        if (groups != env->groups()) build_groups(env, groups);
+        if (groups != env->groups()) {
+            const int before = env->groups();
+            try {
+                build_groups(env, groups);
+            } catch (...) {  // e.g. out of memory for the second set of state arrays: the handle keeps working as it was
+                try {
+                    build_groups(env, before);
+                } catch (...) {
+                    destroy_families(env);
+                }
+                throw;
+            }
+        }
     });
 }
 int32_t mg_groups(const mg_env* env) { return env ? env->groups() : 0; }
