@@ -1645,6 +1645,12 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 #define MG_LAB_EMP_LB 5
 #endif
 constexpr int EMP_SVC_WGS = MG_LAB_EMP_SVC;
+#ifdef MG_LAB_EMP_CLOCK  // measurement builds only: per-workgroup start / end of service / end, constant-rate clock (10 ns)
+static __device__ unsigned long long g_lab_emp_clock[3 * 16384];
+#define LAB_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_emp_clock[3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define LAB_CLOCK(slot) do { } while (0)
+#endif
 constexpr int EMP_BG_WGS = 512;  // frame workgroups that may carry background jobs (64 each: all 32,768 instances at once)
 static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
 template <int FMT>
@@ -1661,6 +1667,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
     R.T = A.tables;
     R.tid = threadIdx.x;
     const int tid = threadIdx.x;
+    LAB_CLOCK(0);
     if (blockIdx.x < svc) {
         // the service waves run a long dependent instruction chain next to memory-bound raster waves: let them issue first
         if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
@@ -1683,6 +1690,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
             }
             if (me) served[wv] = inst;
             __syncthreads();
+            LAB_CLOCK(1);
             bool any = false;
             for (int w = 0; w < 4; ++w) {
                 const int e = served[w];
@@ -1701,6 +1709,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
             io.qctr[QC_HEAD] = 0;
             io.qctr[QC_LEFT] = 0;
         }
+        LAB_CLOCK(2);
         return;
     }
     // Background jobs (owed segments, lazy initial segments): wave 0 of the first ceil(count / 64) FRAME workgroups takes 64
@@ -1723,6 +1732,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
                 io.qctr[QC_BG_LEFT] = 0;
             }
             __syncthreads();
+            LAB_CLOCK(1);
         }
     }
     const int stride = (int)gridDim.x - svc;
@@ -1734,6 +1744,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
         store_frame<FMT, false>(smem, obs, env, tid);
         __syncthreads();
     }
+    LAB_CLOCK(2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2099,3 +2110,9 @@ void MysteryFamily::raster_debug(void* frames, hipStream_t s) {
 Family* make_mystery(int variant, int num_envs) { return new MysteryFamily(variant, num_envs); }
 
 }  // namespace mg
+
+#ifdef MG_LAB_EMP_CLOCK
+extern "C" int mg_lab_emp_clock(unsigned long long* host, int n_wgs) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_emp_clock), sizeof(unsigned long long) * 3 * (size_t)n_wgs) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -10,7 +10,8 @@
 //   3. compose(): builds the 84x84x3 observation in 21,168 B of LDS in the reference's blit order
 //      (endless_searing_spotlights.py:464-479, searing_spotlights.py:524-545) touching LDS only; the spotlight layer
 //      is not a pass of its own: the hole mask is built first and every layer below it is darkened while written,
-//   4. streams the frame to HBM as 1,323 x 16-byte non-temporal stores, lane-contiguous (1 KiB per wave instruction).
+//   4. streams the frame to HBM as 1,323 x 16-byte stores, lane-contiguous (1 KiB per wave instruction); plain or non-temporal
+//      by launch size (raster_nt()).
 // Roofline: HBM write bandwidth; algorithmic traffic per instance-step = 21,168 B written + sizeof(Desc) read.
 //
 // Helpers (all lanes of the workgroup call them together; callers place __syncthreads() between overlapping layers):
@@ -47,9 +48,10 @@ constexpr int MAX_STAMPS = 48;
 constexpr int PALETTE_SIZE = 32;
 constexpr int MASK_WORDS = 3;                 // 84 bits per column
 constexpr int RASTER_GRID = 256 * 7 * 8;      // workgroups of a launch over many frames (65,536 and more)
-constexpr int RASTER_GRID_SMALL = 256 * 38;   // ... over 32,768 frames or fewer: see raster_grid()
+constexpr int RASTER_GRID_SMALL = 256 * 38;   // ... over 24,576 frames or fewer: see raster_grid()
+constexpr int RASTER_PLAIN_MAX = 16384;       // launches up to this many frames use plain stores, larger ones non-temporal: raster_nt()
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
-constexpr int RASTER_LDS_REQUEST = 25 * 1024;  // uint8 format: six workgroups per CU, see launch_raster
+constexpr int RASTER_LDS_REQUEST = 25 * 1024;  // non-temporal uint8 stream: six workgroups per CU, see launch_raster
 constexpr int RASTER_LDS_FUSED = 28 * 1024;    // spot_raster_serve_kernel: five per CU (its reset code needs the 96 VGPRs)
 
 struct StampInfo {
@@ -197,38 +199,47 @@ __device__ __forceinline__ void hole_mask(const RasterCtx& R, cptr<uint32_t> hol
 // ---- fused form of the spotlight layer (<= 16 holes of radius <= 16, the reference's 7..13) --------------------
 // 8 holes x 32 columns per round, two rounds; a column's lit span is at most 32 rows -> at most two mask words.
 struct HoleRegs8 {
-    uint32_t v[2];  // x | y0 << 8 | y1 << 16 | valid << 24
+    uint32_t hole[2];  // the packed hole of this lane's (round, column) task, 0 = no task
+    uint32_t span[2];  // its span-table entry: lo | hi << 8 (int8 y offsets); decoded in hole_apply8, so that hole_fetch8
+                       // only ISSUES loads and the frame's whole prefetch is one memory round trip
 };
 __device__ __forceinline__ bool holes_small(cptr<uint32_t> holes, int nholes) {
     bool ok = nholes <= 16;
     for (int h = 0; h < nholes; ++h) ok = ok && hole_radius(holes[h]) <= 16;
     return ok;
 }
+// A wave handles two holes per round (its lower and upper 32 lanes): their packed words are read with WAVE-UNIFORM indices --
+// scalar loads like the rest of the descriptor -- and picked per lane, so that the span-table read is the only vector-memory
+// hop of the spotlight layer and leaves together with the frame's other loads (as a lane-indexed load the word cost a
+// round trip of its own in front of the span read).
 __device__ __forceinline__ void hole_fetch8(const RasterCtx& R, cptr<uint32_t> holes, int nholes, HoleRegs8& H) {
     const int sub = R.tid >> 5, col = R.tid & 31;
+    const int wave2 = __builtin_amdgcn_readfirstlane(R.tid >> 6) * 2;
+    const uint16_t* spans = reinterpret_cast<const uint16_t*>(R.A.disc_span);
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
-        H.v[rnd] = 0u;
-        int hI = rnd * 8 + sub;
-        if (hI < nholes) {
-            const uint32_t hv = holes[hI];
-            const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
-            if (col < 2 * r) {
-                int lo = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2], hi = R.A.disc_span[(r * 2 * DISC_RMAX + col) * 2 + 1];
-                int X = hx - r + col, y0 = hy + lo, y1 = hy + hi;
-                y0 = y0 < 0 ? 0 : y0;
-                y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
-                if ((unsigned)X < (unsigned)SCREEN && y0 <= y1) H.v[rnd] = (uint32_t)X | ((uint32_t)y0 << 8) | ((uint32_t)y1 << 16) | (1u << 24);
-            }
-        }
+        const int hI = rnd * 8 + sub, h0 = rnd * 8 + wave2;
+        const uint32_t lo_word = h0 < nholes ? holes[h0] : 0u, hi_word = h0 + 1 < nholes ? holes[h0 + 1] : 0u;
+        const uint32_t hv = (R.tid & 32) ? hi_word : lo_word;
+        const int r = hole_radius(hv);
+        const bool task = hI < nholes && col < 2 * r;
+        H.hole[rnd] = task ? hv : 0u;  // a task's hole has r >= 1, so its packed word is never 0
+        H.span[rnd] = task ? (uint32_t)spans[r * 2 * DISC_RMAX + col] : 0u;
     }
 }
 __device__ __forceinline__ void hole_apply8(const RasterCtx& R, const HoleRegs8& H) {
+    const int col = R.tid & 31;
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
-        const uint32_t hv = H.v[rnd];
-        if (!(hv >> 24)) continue;
-        const int X = (int)(hv & 255u), y0 = (int)((hv >> 8) & 255u), y1 = (int)((hv >> 16) & 255u);
+        const uint32_t hv = H.hole[rnd];
+        if (!hv) continue;
+        const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
+        const int lo = (int8_t)(H.span[rnd] & 0xFFu), hi = (int8_t)(H.span[rnd] >> 8);
+        const int X = hx - r + col;
+        int y0 = hy + lo, y1 = hy + hi;
+        y0 = y0 < 0 ? 0 : y0;
+        y1 = y1 > SCREEN - 1 ? SCREEN - 1 : y1;
+        if ((unsigned)X >= (unsigned)SCREEN || y0 > y1) continue;
         const int w0 = y0 >> 5, w1 = y1 >> 5;
         const uint32_t lo_bits = 0xFFFFFFFFu << (y0 & 31), hi_bits = 0xFFFFFFFFu >> (31 - (y1 & 31));
         if (w0 == w1) {
@@ -302,16 +313,8 @@ __device__ __forceinline__ void templ_apply_dark(const RasterCtx& R, const Templ
 // inside compose() could only be consumed after the previous frame's stores had drained).  A software-pipelined loop
 // (frame i+1's prefetch issued before frame i's stores) was built and measured: no gain over this simple loop for the
 // spotlight frames, a loss for the mortar frames (profiles/r01c_raster_generations.md).
-// Stream-out: mg_stream_out.hpp, with NON-TEMPORAL stores for the uint8 format -- the observation stream then does not
-// displace the logic kernel's state and descriptors from L2 (spotlight workloads: raster -4 %, logic kernel -9 %; for the
-// mortar frames of generation 1 the same hint costs 40 %, profiles/r01c_raster_generations.md).
-#ifdef MG_LAB_PLAIN_STORES  // measurement builds only
-constexpr bool RASTER_NT = false;
-#else
-constexpr bool RASTER_NT = true;
-#endif
-
-template <class Composer, int FMT>
+// Stream-out: mg_stream_out.hpp, buffer stores; NT = non-temporal (uint8 format only, chosen per launch: raster_nt()).
+template <class Composer, int FMT, bool NT>
 __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
                                                      void* __restrict__ obs, int n, const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
         Composer::compose(cdescs + env, P, R);
         __syncthreads();
         Composer::recycle(R);  // overlaps the stream-out, saves a barrier at the start of the next compose()
-        store_frame<FMT, RASTER_NT>(smem, obs, env, tid);
+        store_frame<FMT, NT, true>(smem, obs, env, tid);
         __syncthreads();  // the LDS frame is reused by the next iteration
     }
 }
@@ -341,39 +344,55 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
 // several frames has each next frame's loads queued behind its own stores (gfx9 counts both in vmcnt), a launch of one
 // workgroup per frame pays ~14,000 wave launches: the optimum lies in between and moves with the launch size.  Round 3,
 // Endless-SearingSpotlights at 16,384 frames, same call (profiles/r03_spot_grid.md): 3,584 / 5,120 / 7,168 / 8,960 / 9,728 /
-// 10,752 / 14,336 / 16,384 workgroups at six per CU -> 78.0 / 73.8 / 69.0 / 65.7 / 65.5 / 67.0 / 72.5 / 77.4 us.
+// 10,752 / 14,336 / 16,384 workgroups at six per CU -> 78.0 / 73.8 / 69.0 / 65.7 / 65.5 / 67.0 / 72.5 / 77.4 us; the same
+// optimum with plain stores at seven per CU (profiles/r03_spot_store_lab.md: 7,168 / 9,728 / 14,336 -> 60.7 / 59.7 / 64.5 us).
+// At 32,768 frames and beyond 14,336 workgroups win (32,768: 121.4 against 124.1-127.1 us for 7,168-12,288).
 inline int raster_grid(int n) {
     static const int forced = [] {
         const char* e = getenv("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : 0;
     }();
-    return forced > 0 ? forced : (n <= 32768 ? RASTER_GRID_SMALL : RASTER_GRID);
+    return forced > 0 ? forced : (n <= 24576 ? RASTER_GRID_SMALL : RASTER_GRID);
+}
+
+// Store flavour of the uint8 stream for a launch over n frames.  Plain stores are the faster stream (16,384 frames: 59.7 us
+// = 5.8 TB/s against 63.3 us non-temporal) but pass through the caches, and the logic kernel then finds less of its state
+// there: +2-3 us at 16,384 instances (212 vs 208 M env-steps/s, plain wins), +10 us at 65,536 (223 vs 230 M, non-temporal
+// wins).  MEMGYM_RASTER_NT = 0 / 1 forces one (tuning only).  profiles/r03_spot_store_lab.md.
+inline bool raster_nt(int n) {
+    static const int forced = [] {
+        const char* e = getenv("MEMGYM_RASTER_NT");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    return forced >= 0 ? forced != 0 : n > RASTER_PLAIN_MAX;
 }
 
 template <class Composer>
 inline void launch_raster(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s,
                           const uint8_t* only = nullptr) {
     const int tuned = raster_grid(n);
-    // The kernel needs RASTER_LDS (22,176 B: 7 workgroups per CU); for the uint8 format, whose stores are non-temporal,
-    // it asks for 25 KiB = SIX per CU: that stream is faster with fewer concurrent writers than fit.  Round 1 (grid 14,336:
-    // 7 per CU 78-82 us, 6: 72-77, 5: 72-73, 4: 81) shipped five; re-swept in round 3 TOGETHER with the grid size
-    // (profiles/r03_spot_grid.md, Endless-SearingSpotlights 16,384 frames): six per CU x 8,960-10,240 workgroups 65.4-66.1 us,
-    // five per CU x 14,336 (round 2) 71.4 us, seven x 8,960 68.4, four 80-84.  With plain stores -- the float formats -- it is
-    // the other way round (7: 85, 5: 98: profiles/r01j_ess_raster_ablation.md).  MEMGYM_RASTER_LDS overrides (tuning only).
+    // The kernel needs RASTER_LDS (22,176 B: 7 workgroups per CU).  A NON-TEMPORAL stream is faster with fewer concurrent
+    // writers than fit and asks for 25 KiB = SIX per CU (profiles/r03_spot_grid.md, Endless-SearingSpotlights 16,384 frames: six
+    // per CU x 8,960-10,240 workgroups 65.4-66.1 us, five x 14,336 (round 2) 71.4, seven x 8,960 68.4, four 80-84); plain
+    // stores -- small launches and the float formats -- want all seven (7: 59.7, 6: 62.3 us; profiles/r03_spot_store_lab.md).
+    // MEMGYM_RASTER_LDS overrides (tuning only).
     static const int forced_lds = [] {
         const char* e = getenv("MEMGYM_RASTER_LDS");
         return e && atoi(e) >= RASTER_LDS ? atoi(e) : 0;
     }();
-    const int lds = forced_lds ? forced_lds : (fmt == MG_OBS_U8_XYC ? RASTER_LDS_REQUEST : RASTER_LDS);
+    const bool nt = fmt == MG_OBS_U8_XYC && raster_nt(n);
+    const int lds = forced_lds ? forced_lds : (nt ? RASTER_LDS_REQUEST : RASTER_LDS);
     const int grid = n < tuned ? n : tuned;
     if (fmt == MG_OBS_F32_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F32_CYX, false>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else if (fmt == MG_OBS_BF16_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_BF16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_BF16_CYX, false>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else if (fmt == MG_OBS_F16_CYX)
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX, false>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+    else if (nt)
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC, true>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else
-        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+        hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC, false>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
 }
 
 }  // namespace mg

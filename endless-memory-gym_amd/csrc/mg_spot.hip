@@ -220,14 +220,14 @@ struct SpotComposerT {
     // every global read of the frame (template, sprite / coin / exit pixels, disc spans)
     static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) {
         const Desc MG_CONST_AS& d = *dp;
+        templ_fetch(R, d.bg, P.bg);
         stamp_fetch<1>(R, d.sprite, P.agent);
         if (d.n_coins) stamp_fetch<1>(R, ST_COIN, P.coin);
         else stamp_none<1>(P.coin);
         if (d.exit_stamp != 0xFF) stamp_fetch<1>(R, d.exit_stamp, P.exitp);
         else stamp_none<1>(P.exitp);
-        P.holes.v[0] = P.holes.v[1] = 0u;
+        P.holes.hole[0] = P.holes.hole[1] = P.holes.span[0] = P.holes.span[1] = 0u;
         if (d.alpha && holes_small(d.holes, d.n_holes)) hole_fetch8(R, d.holes, d.n_holes, P.holes);
-        templ_fetch(R, d.bg, P.bg);
     }
     static __device__ __forceinline__ void recycle(const RasterCtx& R) { zero_mask(R); }
     static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
@@ -368,29 +368,34 @@ __device__ __forceinline__ int isqrt_floor(int v) {
 // Each row's blocked set is a union of intervals [cx - hw, cx + hw] with hw = isqrt(r^2 - dy^2 - 1); rows are
 // 84-bit masks built with shifts (no per-cell loops), free cells counted with popcounts.
 typedef unsigned __int128 u128m;
-// The blocked discs (agent, coins, exit; at most 1 + MAX_COINS + 1).  Register resident: every access uses a
-// compile-time index under a predicate, so that loops over the discs / over the coins need not be unrolled around the
-// sampler (an unrolled coin loop made the finite step kernel 30,000 instructions long).
+// The blocked discs (agent, coins, exit; at most 1 + MAX_COINS + 1) of the instance a 16-lane group is resetting live in
+// LDS (x[], y[], r[] of MAX_DISCS ints each in the group's DISC_INTS-int slot; all 16 lanes write the same values, each
+// reads after its own write).  As register arrays -- compile-time indices under predicates -- they pushed the finite
+// variant's fused raster / reset kernel 109 dwords past its 96 VGPRs: 436 B of scratch per lane, which a kernel pays for at
+// EVERY wave launch (profiles/r02_spot_resets.md), and unrolled its loops over the discs.
 constexpr int MAX_DISCS = 1 + MAX_COINS + 1;
+constexpr int DISC_INTS = 3 * MAX_DISCS + MAX_COINS + 2;  // + the coins placed by a finite reset (spot_reset), 16-byte multiple
+static_assert(DISC_INTS % 4 == 0, "group slots stay 16-byte aligned");
 struct Discs {
-    int x[MAX_DISCS], y[MAX_DISCS], r[MAX_DISCS];
+    int* p;  // LDS slot of this lane's group
     int n;
     __device__ __forceinline__ void push(int X, int Y, int R) {
-#pragma unroll
-        for (int q = 0; q < MAX_DISCS; ++q)
-            if (q == n) { x[q] = X; y[q] = Y; r[q] = R; }
+        p[n] = X;
+        p[MAX_DISCS + n] = Y;
+        p[2 * MAX_DISCS + n] = R;
         ++n;
     }
 };
+// the slot of the calling lane's group inside an array of (workgroup size / 16) * DISC_INTS ints
+__device__ __forceinline__ int* disc_slot(int* lds) { return lds + (threadIdx.x >> 4) * DISC_INTS; }
 __device__ __forceinline__ u128m row_mask(const Discs& D, int y) {
     u128m m = 0;
-#pragma unroll
-    for (int d = 0; d < MAX_DISCS; ++d) {
-        if (d >= D.n) break;
-        int ddy = y - D.y[d], rem = D.r[d] * D.r[d] - ddy * ddy - 1;
+    for (int d = 0; d < D.n; ++d) {
+        const int dx = D.p[d], dr = D.p[2 * MAX_DISCS + d];
+        int ddy = y - D.p[MAX_DISCS + d], rem = dr * dr - ddy * ddy - 1;
         if (rem < 0) continue;
         int hw = isqrt_floor(rem);
-        int a = D.x[d] - hw, b = D.x[d] + hw;
+        int a = dx - hw, b = dx + hw;
         a = a < 0 ? 0 : a;
         b = b > SCREEN - 1 ? SCREEN - 1 : b;
         if (a > b) continue;
@@ -522,7 +527,7 @@ __device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore&
 // 0 at reset, i.e. with light_dim_off_duration == 0.  The hole words themselves are still in the descriptor.
 template <bool EN>
 __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
-                                           int stale_holes) {
+                                           int stale_holes, int* slot) {  // slot: disc_slot() of the calling kernel's LDS array
     s.t = 0;
     s.coin_t = 0;
     s.ep_sum = 0.0;
@@ -530,6 +535,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.la0 = s.la1 = 0;
     s.rot8 = (uint8_t)g.integers(0, 8);  // choice([0, 45, ..., 315])
     Discs D;
+    D.p = slot;
     D.n = 0;
     int ax, ay;
     if (P.sample_agent_position) {
@@ -560,7 +566,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.has_coin = 0;
     s.exit_open = 0;
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
-    uint32_t coin_pos[MAX_COINS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int* const coin_pos = slot + 3 * MAX_DISCS;  // the coins as placed (finite variant), next to the disc list
     if constexpr (EN) {
         if (P.coin_enabled) {  // _spawn_coin: the sampler is reset first, self.coin is None -> nothing blocked
             int k = g.integers(0, SCREEN * SCREEN);
@@ -585,9 +591,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
             clamp_spawn(P, cx, cy);
             const uint32_t w = (uint32_t)(cx & 0xFFFF) | ((uint32_t)cy << 16);
             if (ls == 0) coins[k] = w;
-#pragma unroll
-            for (int q = 0; q < MAX_COINS; ++q)
-                if (q == k) coin_pos[q] = w;
+            coin_pos[k] = (int)w;
             s.n_coins++;
         }
         int ex, ey;
@@ -623,7 +627,8 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
 #pragma unroll
         for (int k = 0; k < MAX_COINS; ++k) {
             if (k < s.n_coins) {
-                int cx = (int)(int16_t)(coin_pos[k] & 0xFFFF), cy = (int)(coin_pos[k] >> 16);
+                const uint32_t w = (uint32_t)coin_pos[k];
+                int cx = (int)(int16_t)(w & 0xFFFF), cy = (int)(w >> 16);
                 d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
             }
         }
@@ -668,6 +673,7 @@ static_assert(MAX_COINS == 8, "store_desc_head packs eight coin words");
 template <bool EN>
 __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io, const int64_t* seeds, const uint8_t* mask,
                                                          float* gt) {
+    __shared__ int disc_lds[(256 / 16) * DISC_INTS];
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int i = gid >> 4, ls = gid & 15;
     if (i >= P.n) return;
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     SpotCore s = io.core[i];
     SpotDesc d;
     const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);  // n_holes of the frame drawn last
-    spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes);
+    spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds));
     if (ls == 0) {
         io.core[i] = s;
         g.store(io.rng, i);
@@ -692,6 +698,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
 template <bool EN>
 __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io, const int32_t* actions, float* reward_out,
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset, int defer) {
+    __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int i = gid >> 4, ls = gid & 15;
     if (i >= P.n) return;
@@ -840,6 +847,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
                 s.coin_t = 0;
                 // _spawn_coin: sampler reset, previous coin blocked with r = 28
                 Discs D;
+                D.p = disc_slot(disc_lds);
                 D.n = 0;
                 D.push(s.coin_x, s.coin_y, 28);
                 int cx, cy;
@@ -934,7 +942,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     const bool reset_me = done && autoreset;
     if (defer && reset_me && leader) queue_push(io.queue, &io.qctr[SQ_COUNT], P.n, i, io.err);
     if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
-        spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh);
+        spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds));
     } else {
         d.bg = bg_template(s.pad, s.bg_red);
         d.sprite = s.rot8;
@@ -991,8 +999,10 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
 // one address: 22 ns each, in series).  What bounds the launch is a reset's latency next to the raster's waves (~45-80 us)
 // plus the frames that follow it in the same workgroup; variants measured: profiles/r02_spot_resets.md.
 constexpr int SPOT_SVC_WGS = 512, SPOT_SVC_BATCH = 8;
+constexpr int FUSED_DISC_OFF = 24 * 1024;  // past the frame and the hole mask (RASTER_LDS = 22,176 B)
+static_assert(FUSED_DISC_OFF + SPOT_SVC_BATCH * DISC_INTS * 4 <= RASTER_LDS_FUSED, "disc lists fit into the fused launch's LDS request");
 // (five workgroups per CU: what the 28-KiB LDS request of the uint8 raster allows anyway -- and the reset code needs the 96 VGPRs)
-template <bool EN, bool BORDER>
+template <bool EN, bool BORDER, bool NT>
 __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
                                                                    SpotParams P, SpotIO io, float* gt) {
     typedef SpotComposerT<BORDER> Composer;
@@ -1016,7 +1026,7 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
         Composer::compose(cdescs + env, Pq, R);
         __syncthreads();
         Composer::recycle(R);
-        store_frame<MG_OBS_U8_XYC, RASTER_NT>(smem, obs, env, tid);
+        store_frame<MG_OBS_U8_XYC, NT, true>(smem, obs, env, tid);
         __syncthreads();
     };
     if (service) {
@@ -1029,7 +1039,9 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
                 SpotCore s = io.core[i];
                 SpotDesc d;
                 const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);
-                spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes);
+                // disc lists: behind the frame and the hole mask, in the part of the 28-KiB request the composer does not use
+                spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes,
+                               disc_slot(reinterpret_cast<int*>(smem + FUSED_DISC_OFF)));
                 d.valid = DESC_SERVED;
                 if (ls == 0) {
                     io.core[i] = s;
@@ -1243,10 +1255,12 @@ class SpotFamily : public Family {
         prof.begin(1, s);
         if (defer) {
             const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + SPOT_SVC_WGS;
-#define SPOT_FUSED(EN, BO) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO>), dim3(grid), dim3(256), RASTER_LDS_FUSED, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), gt)
+#define SPOT_FUSED2(EN, BO, NT) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT>), dim3(grid), dim3(256), RASTER_LDS_FUSED, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), gt)
+#define SPOT_FUSED(EN, BO) do { if (fused_nt()) SPOT_FUSED2(EN, BO, true); else SPOT_FUSED2(EN, BO, false); } while (0)
             if (P_.endless) { if (P_.ordered_holes) SPOT_FUSED(true, true); else SPOT_FUSED(true, false); }
             else { if (P_.ordered_holes) SPOT_FUSED(false, true); else SPOT_FUSED(false, false); }
 #undef SPOT_FUSED
+#undef SPOT_FUSED2
             MG_HIP(hipGetLastError());
         } else {
             raster(obs, s);
@@ -1337,6 +1351,15 @@ class SpotFamily : public Family {
     // Resets served inside the raster launch: on for the finite variant (147 -> 173 M env-steps/s: more instances finish
     // per step and their resets place up to five objects), off for the endless one (188 vs 190 M: its step kernel's tail
     // is shorter than what the fused launch adds).  MEMGYM_SPOT_FUSE=0 / 1 forces it off / on for both.
+    // store flavour of the fused launch: it runs five workgroups per CU (the reset code's registers), where only the
+    // non-temporal stream keeps up; MEMGYM_RASTER_NT forces (tuning only)
+    bool fused_nt() const {
+        static const int forced = [] {
+            const char* e = getenv("MEMGYM_RASTER_NT");
+            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        }();
+        return forced >= 0 ? forced != 0 : true;
+    }
     bool fuse_resets() const {
         static const int forced = [] {
             const char* e = getenv("MEMGYM_SPOT_FUSE");

@@ -6,9 +6,12 @@
 //   MG_OBS_U8_XYC    1,323 x 16-byte stores, lane-contiguous (1 KiB per wave instruction), the headline format;
 //   MG_OBS_F32_CYX / MG_OBS_F16_CYX / MG_OBS_BF16_CYX   value / 255 in image order [c][y][x]: the
 //                    transpose is done LDS-side (byte gathers, stride 252 B), the global stores stay 16-byte vectors.
-// NT (uint8 format only): non-temporal stores.  The hint is a per-generation measurement, not a taste: the spotlight
-// frames (generation 2) gain 4 % and their logic kernel 9 % because the observation stream stops displacing state and
-// descriptors from L2; the mortar frames (generation 1) LOSE 40 % with it (profiles/r01c_raster_generations.md).
+// NT (uint8 format only): non-temporal stores.  A measured choice, not a taste: a non-temporal stream does not displace the
+// logic kernel's state from the caches (spotlight family at 65,536 instances: logic kernel 38 vs 48 us) but is itself slower
+// than a plain one (16,384 frames: 63 vs 60 us); the mortar frames (generation 1) lose 40 % with it
+// (profiles/r01c_raster_generations.md, profiles/r03_spot_store_lab.md).  Generation 2 picks per launch size (mg_raster.hpp).
+// BUF (uint8 format only): the same six stores as raw BUFFER stores on a per-frame resource -- the sixth needs no lane
+// predicate (the range check drops what lies beyond the frame); generation 2 uses them (-2 us per 16,384 frames).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,9 +46,23 @@ __device__ __forceinline__ float byte_to_unit(uint8_t b) {
     return __fmaf_rn(__fmaf_rn(-q0, 255.0f, v), r, q0);
 }
 
-template <int FMT, bool NT>
+template <int FMT, bool NT, bool BUF = false>
 __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, void* __restrict__ obs, int env, int tid) {
-    if constexpr (FMT == MG_OBS_U8_XYC) {
+    if constexpr (FMT == MG_OBS_U8_XYC && BUF) {
+        const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
+        // raw buffer over this frame only: stride 0, FRAME_BYTES records, dword 3 = 32-bit untyped data (gfx9 encoding)
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES, 0, FRAME_BYTES, 0x00020000);
+        u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
+        u32x4 v5 = (u32x4)(0u);
+        if (tid < TAIL) v5 = lds16[tid + 1280];
+        constexpr int AUX = NT ? 2 : 0;  // cache policy operand: bit 1 = nt
+        __builtin_amdgcn_raw_buffer_store_b128(v0, rs, tid * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (tid + 256) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v2, rs, (tid + 512) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v3, rs, (tid + 768) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (tid + 1024) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v5, rs, (tid + 1280) * 16, 0, AUX);  // lanes >= TAIL: out of range, dropped
+    } else if constexpr (FMT == MG_OBS_U8_XYC) {
         const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
         u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
         u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];

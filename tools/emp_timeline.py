@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""tools/emp_timeline.py -- when do the workgroups of Endless-MysteryPath's fused raster / service launch start and finish?
+Needs a measurement build (hipcc ... -DMG_LAB_EMP_CLOCK -o lib/lab/libmemgym_empclock.so; MEMGYM_HIP_LIB points at it).
+Prints, for the last step of a short run: service workgroups (end of their last served entry, end), background workgroups,
+frame workgroups -- microseconds from the first workgroup's start (constant-rate clock, 10 ns)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "endless-memory-gym_amd"))
+import memory_gym_amd  # noqa: E402
+from memory_gym_amd import _native  # noqa: E402
+
+n = 32768
+env = memory_gym_amd.make("Endless-MysteryPath-v0", num_envs=n, device=0)
+env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda"))
+g = torch.Generator(device="cuda").manual_seed(1)
+for t in range(260):
+    env.step(torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32))
+torch.cuda.synchronize()
+W = 9728 + 384 if n <= 32768 else 14336 + 384
+W = min(W, 16384)
+buf = np.zeros(3 * 16384, np.uint64)
+_native.LIB.mg_lab_emp_clock.argtypes = [C.c_void_p, C.c_int]
+assert _native.LIB.mg_lab_emp_clock(buf.ctypes.data, 16384) == 0
+c = buf.reshape(16384, 3).astype(np.float64)
+live = c[:, 0] > 0
+t0 = c[live, 0].min()
+us = (c - t0) / 100.0
+svc, bg = 384, 512
+
+
+def stats(name, rows, col):
+    v = us[rows, col]
+    v = v[(c[rows, col] > 0)]
+    if len(v):
+        print("%-34s n=%5d  min %6.1f  median %6.1f  p90 %6.1f  max %6.1f us" % (name, len(v), v.min(), np.median(v), np.percentile(v, 90), v.max()))
+
+
+idx = np.arange(16384)
+stats("service WGs: start", idx < svc, 0)
+stats("service WGs: last entry served", idx < svc, 1)
+stats("service WGs: end (frames drawn)", idx < svc, 2)
+stats("background WGs: lane phase done", (idx >= svc) & (idx < svc + bg), 1)
+stats("frame WGs: start", (idx >= svc) & live, 0)
+stats("frame WGs: end", (idx >= svc) & live, 2)
+print("launch: %.1f us from the first start to the last end" % us[live, 2].max())
