@@ -61,6 +61,17 @@ struct __attribute__((aligned(16))) MysteryCore {
     uint8_t bg;           // endless: -bg_scroll, the scrolling background's phase in pixels (< tile)
 };
 static_assert(sizeof(MysteryCore) == 96, "MysteryCore must be 96 bytes");
+// The whole record as six 16-byte loads issued together.  Field by field the compiler split it into eleven odd-sized loads
+// and issued three of them only after the first uses: a second memory round trip (3-4 us on a cold state array) at the head
+// of the one-lane-per-instance step kernel (profiles/r03_emp.md, section 7).
+__device__ __forceinline__ MysteryCore load_core(const MysteryCore* p) {
+    typedef uint32_t q4 __attribute__((ext_vector_type(4)));
+    const q4* src = reinterpret_cast<const q4*>(p);
+    union { q4 q[6]; MysteryCore c; } u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u.q[k] = src[k];
+    return u.c;
+}
 
 struct __attribute__((aligned(16))) MysteryDesc {
     uint8_t valid, sprite, n_tiles, cross_on;
@@ -756,7 +767,7 @@ __device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float*
 }
 
 __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx, SegRec& R,
-                              const SegRec& Rprev) {
+                              const SegRec Rprev) {  // (by value: as a reference the caller's record stayed in scratch)
     memset(&d, 0, sizeof(d));
     d.valid = 1;
     d.sprite = s.rot8;
@@ -772,6 +783,7 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
         int st = s.stamina < P.stamina_level ? s.stamina : P.stamina_level;
         d.stamina_red = (uint8_t)(int)(SCREEN * (1 - ((double)st / P.stamina_level)));
     }
+    uint64_t mask0 = 0, mask1 = 0;
     if (P.show_past_path) {  // _draw_past_path
         int x = nx - 1;
         if (x >= 0) {
@@ -791,8 +803,10 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
                 int y = node_y(b);
                 int col = x - past_x;
                 if (col >= 0 && col < 16) {
-                    int cell = col * G + y;
-                    d.tile_mask[cell >> 6] |= 1ull << (cell & 63);
+                    const int cell = col * G + y;  // (a run-time index into d.tile_mask would put the descriptor into scratch)
+                    const uint64_t bit = 1ull << (cell & 63);
+                    if (cell < 64) mask0 |= bit;
+                    else mask1 |= bit;
                 } else if (col >= 16) {
                     raise_error(io.err, 16);
                 }
@@ -801,6 +815,8 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
             }
         }
     }
+    d.tile_mask[0] = mask0;
+    d.tile_mask[1] = mask1;
 }
 
 // ---- lazy initial segments --------------------------------------------------------------------------------------------
@@ -859,8 +875,7 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
 
 // EndlessMysteryPathEnv.step (endless_mystery_path.py:282-444), first part: move; returns 1 if a new segment is due
 // (`current_segment > num_segments - 2`, :333-335), which the wave then generates before the second part runs.
-__device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, const int32_t* actions, int& nx, int& ny) {
-    int a = actions[i];
+__device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, int a, int& nx, int& ny) {
     int a0 = a == 1 ? 2 : 0, a1 = a == 2 ? 1 : (a == 3 ? 2 : 0);
     if (!s.off) {
         int before = s.ax;
@@ -900,12 +915,11 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     // The segment store is cold (6.6 KB per instance, evicted by the observation stream): every dependent access is a ~2 us
     // round trip.  The records this step can touch -- the agent's segment, the one before it (past-path tiles), the head of
     // the one after it (the direction to the next node) -- are requested together, before the first of them is used.
-    int nxt_seg = -1;
-    uint32_t nxt_w0 = 0;
-    if (seg + 1 < s.num_seg) {
-        nxt_seg = seg + 1;
-        nxt_w0 = *reinterpret_cast<const uint32_t*>(seg_ptr(io, i, nxt_seg));
-    }
+    // (the next segment's head is read unconditionally, from a clamped index: inside a branch the compiler consumed it there
+    // and waited for it before the two records were even requested)
+    const int nxt_seg = seg + 1 < s.num_seg ? seg + 1 : -1;
+    const int nxt_safe = nxt_seg >= 0 ? nxt_seg : 0;
+    const uint32_t nxt_w0 = *reinterpret_cast<const uint32_t*>(seg_ptr(io, i, nxt_safe));
     if (seg >= 1 && seg - 1 < s.num_seg) Rprev.load(io, i, seg - 1);
     bool on_path = false;
     if (seg < s.num_seg) {
@@ -1172,13 +1186,30 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
 // plain instance = "reset".
 constexpr int EMP_Q_SEGMENT = 1 << 30;
 
+#ifdef MG_LAB_EMP_CLOCK
+__global__ void lab_wbl2_kernel() { asm volatile("buffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+#ifdef MG_LAB_EMP_CLOCK  // measurement builds only: phases of emp_step_kernel per wave (constant-rate clock, 10 ns)
+static __device__ unsigned long long g_lab_step_clock[5 * 4096];
+#define LAB_STEP_CLOCK(slot) do { const int wv_ = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; \
+    __builtin_amdgcn_s_waitcnt(0); /* everything issued so far has completed: the phases are what the wave waited for */ \
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wv_ < 4096) g_lab_step_clock[5 * wv_ + (slot)] = wall_clock64(); } while (0)
+#else
+#define LAB_STEP_CLOCK(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions, float* reward_out,
                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    MysteryCore s = io.core[i];
+    LAB_STEP_CLOCK(0);
+    int act = actions[i];  // requested together with the state record ...
+    MysteryCore s = load_core(&io.core[i]);
+    asm volatile("" : "+v"(act));  // ... (a use the compiler cannot move: without it the request is issued after the record has arrived)
     int nx = 0, ny = 0;
-    if (emp_step_a(P, i, s, actions, nx, ny)) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
+    const int due = emp_step_a(P, i, s, act, nx, ny);
+    LAB_STEP_CLOCK(1);
+    if (due) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         io.core[i] = s;
         queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
         io.desc[i].valid = DESC_QUEUED;  // (the rest of the descriptor is last step's)
@@ -1186,14 +1217,17 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryI
     }
     MysteryDesc d;
     const bool q = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+    LAB_STEP_CLOCK(2);
     if (q) {
         queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         d.valid = DESC_QUEUED;
     } else if (P.lazy && EMP_OWED(s) > 0) {  // one owed segment per step, as a job nobody waits for
         queue_push(io.bgq, &io.qctr[QC_BG_COUNT], P.n, i, io.err);
     }
+    LAB_STEP_CLOCK(3);
     io.core[i] = s;
     io.desc[i] = d;
+    LAB_STEP_CLOCK(4);
 }
 
 __global__ __launch_bounds__(256) void emp_enqueue_kernel(int n, MysteryIO io, const uint8_t* mask) {
@@ -1894,6 +1928,10 @@ class MysteryFamily : public Family {
                                    P_, io(), reward, done, gt, ib, autoreset, svc);
                 MG_HIP(hipGetLastError());
                 prof.end(1, s);
+#ifdef MG_LAB_EMP_CLOCK  // diagnosis: is the next logic kernel slow because the L2 is full of dirty observation lines?
+                static const int wb = [] { const char* e = getenv("MEMGYM_LAB_WBL2"); return e ? atoi(e) : 0; }();
+                if (wb) hipLaunchKernelGGL(lab_wbl2_kernel, dim3(wb), dim3(64), 0, s);
+#endif
                 return;
             }
             hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
@@ -2112,6 +2150,9 @@ Family* make_mystery(int variant, int num_envs) { return new MysteryFamily(varia
 }  // namespace mg
 
 #ifdef MG_LAB_EMP_CLOCK
+extern "C" int mg_lab_step_clock(unsigned long long* host, int n_waves) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_step_clock), sizeof(unsigned long long) * 5 * (size_t)n_waves) == hipSuccess ? 0 : -1;
+}
 extern "C" int mg_lab_emp_clock(unsigned long long* host, int n_wgs) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_emp_clock), sizeof(unsigned long long) * 3 * (size_t)n_wgs) == hipSuccess ? 0 : -1;
 }

@@ -86,6 +86,38 @@ def test_full_size_sample():
     env.close()
 
 
+@pytest.mark.parametrize("n", [20480, 40960])
+def test_large_launch_store_flavour_sample(n):
+    """Launches of more than 16,384 frames stream the observations with NON-TEMPORAL stores (mg_raster.hpp raster_nt(); up to
+    16,384: plain stores) and, beyond 24,576 frames, on the larger persistent grid: another instantiation of the raster kernel
+    than every small parity test runs.  A sample of instances -- both ends, around the grid sizes -- against single-instance
+    oracles, frame by frame."""
+    import memory_gym_amd
+    import oracle_lib
+    import torch
+
+    env = memory_gym_amd.make("Endless-SearingSpotlights-v0", num_envs=n, device=0)
+    obs, _ = env.reset(seed=0)
+    sample = [0, 1, 9727, 9728, 14335, 14336, 16384, n // 2 + 1, n - 2, n - 1]
+    refs = {i: oracle_lib.OracleEnv("Endless-SearingSpotlights-v0") for i in sample}
+    first = obs[sample].cpu().numpy()
+    for k, i in enumerate(sample):
+        assert np.array_equal(first[k], refs[i].reset(i))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(60):
+        a = torch.randint(0, 3, (n, 2), device="cuda", generator=g, dtype=torch.int32)
+        obs, rew, done, _, _ = env.step(a)
+        ac = a[sample].cpu().numpy()
+        got = obs[sample].cpu().numpy()
+        for k, i in enumerate(sample):
+            o, r, d = refs[i].step(ac[k])
+            if d:
+                o = refs[i].reset(None)
+            assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t)
+    env.check_errors()
+    env.close()
+
+
 def test_slot_capacity_is_checked_at_reset():
     """Option sets that must overflow the 16 slots per instance are refused up front; rarer overflows surface as a
     RuntimeError from step() (host-mapped error word, no synchronisation needed to see it)."""

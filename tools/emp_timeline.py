@@ -49,3 +49,22 @@ stats("background WGs: lane phase done", (idx >= svc) & (idx < svc + bg), 1)
 stats("frame WGs: start", (idx >= svc) & live, 0)
 stats("frame WGs: end", (idx >= svc) & live, 2)
 print("launch: %.1f us from the first start to the last end" % us[live, 2].max())
+
+# emp_step_kernel: phases per wave (start, state loaded + move, step logic + descriptor, queue pushes, stores issued)
+nw = n // 64
+sb = np.zeros(5 * nw, np.uint64)
+_native.LIB.mg_lab_step_clock.argtypes = [C.c_void_p, C.c_int]
+assert _native.LIB.mg_lab_step_clock(sb.ctypes.data, nw) == 0
+sc = sb.reshape(nw, 5).astype(np.float64)
+s0 = sc[:, 0].min()
+su = (sc - s0) / 100.0
+print("emp_step_kernel, %d waves: us from the first wave's start" % nw)
+for k, name in enumerate(("wave start", "state loaded, agent moved", "emp_step_b done (logic + descriptor)", "queue pushes done", "state / descriptor stores issued")):
+    v = su[:, k]
+    v = v[sc[:, k] > 0]
+    print("  %-40s n=%4d  min %6.1f  median %6.1f  p90 %6.1f  max %6.1f" % (name, len(v), v.min(), np.median(v), np.percentile(v, 90), v.max()))
+ok = (sc > 0).all(axis=1)
+dur = su[ok]
+for k, name in enumerate(("load + move", "emp_step_b", "queue pushes", "stores")):
+    dd = dur[:, k + 1] - dur[:, k]
+    print("  phase %-20s median %5.2f  p90 %5.2f  max %5.2f us" % (name, np.median(dd), np.percentile(dd, 90), dd.max()))
