@@ -1348,9 +1348,13 @@ class SpotFamily : public Family {
 
     void raster(void* obs, hipStream_t s) { raster_only(obs, nullptr, s); }
 
-    // Resets served inside the raster launch: on for the finite variant (147 -> 173 M env-steps/s: more instances finish
-    // per step and their resets place up to five objects), off for the endless one (188 vs 190 M: its step kernel's tail
-    // is shorter than what the fused launch adds).  MEMGYM_SPOT_FUSE=0 / 1 forces it off / on for both.
+    // Resets served inside the raster launch: on for the finite variant up to FUSE_MAX instances (16,384: 188 vs 160 M
+    // env-steps/s: more instances finish per step and their resets place up to five objects); beyond, the step kernel's reset
+    // tail is amortised and the plain raster's six workgroups per CU win (32,768: 198 vs 194 M fused, 40,960: 202 vs 203,
+    // 49,152: 205 vs 207, 131,072: 214 vs 227); off for the endless variant at every size (16,384: 195 vs 209 M, 65,536: 226 vs
+    // 236: its step kernel's tail is shorter than what the fused launch adds).  MEMGYM_SPOT_FUSE=0 / 1 forces it off / on for
+    // both.  profiles/r03_spot_store_lab.md, section 6.
+    static constexpr int FUSE_MAX = 40960;
     // store flavour of the fused launch: it runs five workgroups per CU (the reset code's registers), where only the
     // non-temporal stream keeps up; MEMGYM_RASTER_NT forces (tuning only)
     bool fused_nt() const {
@@ -1365,7 +1369,7 @@ class SpotFamily : public Family {
             const char* e = getenv("MEMGYM_SPOT_FUSE");
             return e ? (atoi(e) != 0 ? 1 : 0) : -1;
         }();
-        return forced >= 0 ? forced != 0 : !P_.endless;
+        return forced >= 0 ? forced != 0 : (!P_.endless && n_ <= FUSE_MAX);
     }
 
     int n_;
