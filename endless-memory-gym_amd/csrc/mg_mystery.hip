@@ -903,6 +903,18 @@ __device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, int a, 
     if (s.cur_seg > s.num_seg + owed - 2) return 1;
     return (owed > 0 && nx >= (G + 1) * s.num_seg - 2) ? 1 : 0;
 }
+#ifdef MG_LAB_EMP_CLOCK
+__global__ void lab_wbl2_kernel() { asm volatile("buffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+#ifdef MG_LAB_EMP_CLOCK  // measurement builds only: phases of emp_step_kernel per wave (constant-rate clock, 10 ns)
+static __device__ unsigned long long g_lab_step_clock[12 * 4096];
+#define LAB_STEP_CLOCK(slot) do { const int wv_ = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; \
+    __builtin_amdgcn_s_waitcnt(0); /* everything issued so far has completed: the phases are what the wave waited for */ \
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wv_ < 4096) g_lab_step_clock[12 * wv_ + (slot)] = wall_clock64(); } while (0)
+#else
+#define LAB_STEP_CLOCK(slot) do { } while (0)
+#endif
+
 // second part; returns true if the instance finished and is to be reset in this call
 __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
                            uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
@@ -925,6 +937,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     if (seg < s.num_seg) {
         uint8_t* sp = seg_ptr(io, i, seg);
         R.load(io, i, seg);
+        LAB_STEP_CLOCK(5);
         const uint32_t* w = R.w;
         const int n = (int)(w[0] & 0xFFu);
         const int dx = nx - seg * (G + 1);
@@ -961,6 +974,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
             sp[hit] = b;
         }
     }
+    LAB_STEP_CLOCK(6);
     if (!on_path) {
         reward += P.r_fall;
         s.fails++;
@@ -1001,6 +1015,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
         s.cross_on = 0;
         s.off = 0;
     }
+    LAB_STEP_CLOCK(7);
     s.cross_x = (int16_t)(s.ax - s.camera_x);
     s.cross_y = s.ay;
     reward += P.r_step;
@@ -1009,6 +1024,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     s.t++;
     if (s.t == P.max_steps) done = true;
     emp_direction(io, i, s, gt, R, nxt_seg, nxt_w0);
+    LAB_STEP_CLOCK(8);
     if (nx > s.max_x && on_path) s.max_x = nx;
     s.ep_sum += reward;
     s.ep_len++;
@@ -1022,8 +1038,10 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     reward_out[i] = (float)reward;
     if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
+    LAB_STEP_CLOCK(9);
     if (done && autoreset) return true;
     emp_fill_desc(P, io, i, s, d, nx, R, Rprev);
+    LAB_STEP_CLOCK(10);
     return false;
 }
 
@@ -1185,18 +1203,6 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
 // graph.  Entries: instance | EMP_Q_SEGMENT = "append one segment, then finish the step (which may end in a reset)";
 // plain instance = "reset".
 constexpr int EMP_Q_SEGMENT = 1 << 30;
-
-#ifdef MG_LAB_EMP_CLOCK
-__global__ void lab_wbl2_kernel() { asm volatile("buffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
-#ifdef MG_LAB_EMP_CLOCK  // measurement builds only: phases of emp_step_kernel per wave (constant-rate clock, 10 ns)
-static __device__ unsigned long long g_lab_step_clock[5 * 4096];
-#define LAB_STEP_CLOCK(slot) do { const int wv_ = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; \
-    __builtin_amdgcn_s_waitcnt(0); /* everything issued so far has completed: the phases are what the wave waited for */ \
-    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wv_ < 4096) g_lab_step_clock[5 * wv_ + (slot)] = wall_clock64(); } while (0)
-#else
-#define LAB_STEP_CLOCK(slot) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions, float* reward_out,
                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
@@ -2151,7 +2157,7 @@ Family* make_mystery(int variant, int num_envs) { return new MysteryFamily(varia
 
 #ifdef MG_LAB_EMP_CLOCK
 extern "C" int mg_lab_step_clock(unsigned long long* host, int n_waves) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_step_clock), sizeof(unsigned long long) * 5 * (size_t)n_waves) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_step_clock), sizeof(unsigned long long) * 12 * (size_t)n_waves) == hipSuccess ? 0 : -1;
 }
 extern "C" int mg_lab_emp_clock(unsigned long long* host, int n_wgs) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_emp_clock), sizeof(unsigned long long) * 3 * (size_t)n_wgs) == hipSuccess ? 0 : -1;

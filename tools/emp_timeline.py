@@ -50,21 +50,26 @@ stats("frame WGs: start", (idx >= svc) & live, 0)
 stats("frame WGs: end", (idx >= svc) & live, 2)
 print("launch: %.1f us from the first start to the last end" % us[live, 2].max())
 
-# emp_step_kernel: phases per wave (start, state loaded + move, step logic + descriptor, queue pushes, stores issued)
+# emp_step_kernel: phases per wave; every stamp follows an s_waitcnt 0, so a phase is what the wave waited for
 nw = n // 64
-sb = np.zeros(5 * nw, np.uint64)
+K = 12
+sb = np.zeros(K * nw, np.uint64)
 _native.LIB.mg_lab_step_clock.argtypes = [C.c_void_p, C.c_int]
 assert _native.LIB.mg_lab_step_clock(sb.ctypes.data, nw) == 0
-sc = sb.reshape(nw, 5).astype(np.float64)
+sc = sb.reshape(nw, K).astype(np.float64)
 s0 = sc[:, 0].min()
 su = (sc - s0) / 100.0
-print("emp_step_kernel, %d waves: us from the first wave's start" % nw)
-for k, name in enumerate(("wave start", "state loaded, agent moved", "emp_step_b done (logic + descriptor)", "queue pushes done", "state / descriptor stores issued")):
-    v = su[:, k]
-    v = v[sc[:, k] > 0]
-    print("  %-40s n=%4d  min %6.1f  median %6.1f  p90 %6.1f  max %6.1f" % (name, len(v), v.min(), np.median(v), np.percentile(v, 90), v.max()))
-ok = (sc > 0).all(axis=1)
-dur = su[ok]
-for k, name in enumerate(("load + move", "emp_step_b", "queue pushes", "stores")):
-    dd = dur[:, k + 1] - dur[:, k]
-    print("  phase %-20s median %5.2f  p90 %5.2f  max %5.2f us" % (name, np.median(dd), np.percentile(dd, 90), dd.max()))
+names = {0: "wave start", 1: "state loaded, agent moved", 5: "segment records arrived", 6: "on-path test done (+ byte store)",
+         7: "fall-off list / stamina flags done", 8: "direction done", 9: "reward / done / info stores issued", 10: "descriptor built",
+         2: "emp_step_b returned", 3: "queue pushes done", 4: "state / descriptor stores issued"}
+order = [0, 1, 5, 6, 7, 8, 9, 10, 2, 3, 4]
+print("emp_step_kernel, %d waves: us from the first wave's start (stamps of waves that passed them)" % nw)
+for k in order:
+    v = su[:, k][sc[:, k] > 0]
+    if len(v):
+        print("  %-40s n=%4d  min %6.1f  median %6.1f  p90 %6.1f  max %6.1f" % (names[k], len(v), v.min(), np.median(v), np.percentile(v, 90), v.max()))
+for a_, b_ in zip(order[:-1], order[1:]):
+    ok = (sc[:, a_] > 0) & (sc[:, b_] > 0)
+    if ok.any():
+        dd = su[ok, b_] - su[ok, a_]
+        print("  phase %-34s -> %-34s median %5.2f  p90 %5.2f  max %5.2f us" % (names[a_][:34], names[b_][:34], np.median(dd), np.percentile(dd, 90), dd.max()))
