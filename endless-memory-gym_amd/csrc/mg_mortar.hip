@@ -266,7 +266,14 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
                                                           mg_info_buffers info, int autoreset) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // the action is requested together with the state record (read where it is used -- behind a test of the state -- it was
+    // a second memory round trip at the head of the kernel)
+    // (both reads unconditional, the grid variant's second one a repeat of the first: a load inside the variant's branch was
+    // waited for at the end of that branch)
+    const bool one_action = P.variant == V_GRID;
+    int act0 = actions[one_action ? i : 2 * i], act1 = actions[one_action ? i : 2 * i + 1];
     MortarState s = io.state[i];
+    asm volatile("" : "+v"(act0), "+v"(act1));  // (a use the compiler cannot move below the record's first use)
     uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     double reward = 0.0;
     bool done = false;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     } else {
         int ax = s.ax, ay = s.ay;
         if (P.variant == V_GRID) {
-            int a = actions[i];
+            int a = act0;
             int rot = s.rot8 * 45;
             if (a == 1) rot = (rot + 90) % 360;
             if (a == 2) rot = (rot + 270) % 360;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
             s.gy = (uint8_t)gy;
             s.rot8 = (uint8_t)(rot / 45);
         } else {
-            int a0 = actions[2 * i], a1 = actions[2 * i + 1];
+            int a0 = act0, a1 = act1;
             int dxs = a0 == 1 ? -1 : (a0 == 2 ? 1 : 0), dys = a1 == 1 ? -1 : (a1 == 2 ? 1 : 0);
             int rot = s.rot8 * 45;
             if (a0 == 1) rot = 90;

@@ -558,13 +558,13 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
 
 // MysteryPathEnv.step (mystery_path.py:202-276).  Returns true if the instance finished and is to be reset in this call
 // (the caller then runs mp_pre_reset / serve_mp / mp_post_reset); otherwise the frame descriptor is filled here.
-__device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, const int32_t* actions, float* reward_out,
+__device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, int act0, int act1, float* reward_out,
                         uint8_t* done_out, const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
     double reward = 0.0;
     bool done = false;
     int success = 0;
     if (P.grid) {  // GridCharacterController.step / reset_position (character_controller.py:177-216)
-        int a = s.off ? 0 : actions[i];
+        int a = s.off ? 0 : act0;
         int gx = s.off ? s.sx : s.gx, gy = s.off ? s.sy : s.gy;
         int rot = s.rot8 * 45;
         if (a == 1) rot = (rot + 90) % 360;
@@ -582,7 +582,7 @@ __device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, const int
         s.ax = (int16_t)(gx * P.tile + P.tile / 2);
         s.ay = (int16_t)(gy * P.tile + P.tile / 2);
     } else if (!s.off) {
-        move_agent(P, s, actions[2 * i], actions[2 * i + 1], true);
+        move_agent(P, s, act0, act1, true);
     } else {
         s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
         s.ay = (int16_t)(s.sy * P.tile + P.agent_radius);
@@ -1162,16 +1162,24 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
     MysteryCore s;
     Pcg g;
     MysteryDesc d;
+    int act0 = 0, act1 = 0;
     if (active) {
-        s = io.core[i];
+        // the action is requested together with the state record (read where it is used -- behind a test of the state -- it
+        // was a second memory round trip at the head of the kernel)
+        // (both reads unconditional, the grid variant's second one a repeat of the first: a load inside the variant's branch
+        // is waited for at the end of that branch)
+        act0 = actions[P.grid ? i : 2 * i];
+        act1 = actions[P.grid ? i : 2 * i + 1];
+        s = load_core(&io.core[i]);
         g.load(io.rng, i);
+        asm volatile("" : "+v"(act0), "+v"(act1));  // (a use the compiler cannot move below the record's first use)
     } else {
         memset(&s, 0, sizeof(s));
         g.state = g.inc = 0; g.buf = 0; g.has = false;
     }
     bool reset_me = false;
     {
-        if (active) reset_me = mp_step(P, i, s, actions, reward_out, done_out, info, autoreset, d);
+        if (active) reset_me = mp_step(P, i, s, act0, act1, reward_out, done_out, info, autoreset, d);
         PathReq req;
         req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
         if (reset_me) req = mp_pre_reset(P, s, g);
