@@ -11,3 +11,15 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("env_id", ["MortarMayhem-Grid-v0", "Endless-MysteryPath-v0", "Endless-SearingSpotlights-v0", "MysteryPath-Grid-v0"])
 def test_odd_batch_sizes(env_id, n):
     run_parity(env_id, None, n=n, steps=24 if n > 1000 else 90, check_every=1 if n < 1000 else 6)
+
+
+# The spotlight family changes kernels with the launch size (mg_raster.hpp raster_nt() / raster_grid(), mg_spot.hip FUSE_MAX):
+# plain stores up to 16,384 frames, non-temporal beyond; 9,728 workgroups up to 24,576 frames, 14,336 beyond; the finite
+# variant serves its resets inside the raster launch up to 40,960 instances.  One size on either side of every switch, every
+# instance against the oracle.
+@pytest.mark.parametrize("env_id,n", [
+    ("Endless-SearingSpotlights-v0", 16385), ("Endless-SearingSpotlights-v0", 24577),
+    ("SearingSpotlights-v0", 16385), ("SearingSpotlights-v0", 40960), ("SearingSpotlights-v0", 40961),
+])
+def test_spotlight_launch_size_switches(env_id, n):
+    run_parity(env_id, None, n=n, steps=36, check_every=9)
