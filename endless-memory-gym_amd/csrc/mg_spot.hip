@@ -475,7 +475,17 @@ __device__ __forceinline__ void clamp_spawn(const SpotParams& P, int& x, int& y)
 
 // Spotlight.__init__: 5 draws (radius, speed, start angle, target delta, offset delta)
 // `ls` = this lane's slot id: every lane of the instance draws the same numbers, the owner of the chosen slot stores them
-__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g) {
+// The record of a spotlight as the lane owning its slot holds it in registers.
+struct SlotRec {
+    double t, speed, sx, sy, tx, ty, ox, oy;
+    int r;        // bit 7: has_border
+    bool done;
+    bool mine;    // new_spot: this lane's slot was taken by the new spotlight and the fields above are its record
+};
+// Spotlight.__init__ for the slot the free mask hands out; the owning lane stores the record AND returns it in `rec` (the step
+// kernel used to read it back from memory: store, wait, load, wait -- two round trips in every wave in which any instance
+// spawned, i.e. in every launch).
+__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SlotRec* rec = nullptr) {
     int radius = g.integers(P.r_lo, P.r_hi);
     double speed = g.uniform(P.speed_lo, P.speed_hi);
     int start = g.integers(0, 360);
@@ -492,16 +502,29 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, S
     if (slot != ls) return;
     size_t k = (size_t)i * SLOTS + slot;
     double R = P.half_diag + (double)radius, c = SCREEN / 2;
-    io.sp_r[k] = (uint8_t)(radius | (P.black_background ? 0x80 : 0));  // bit 7: Spotlight.has_border
+    SlotRec n;
+    n.r = radius | (P.black_background ? 0x80 : 0);  // bit 7: Spotlight.has_border
+    n.done = false;
+    n.t = 0.0;
+    n.speed = speed;
+    n.sx = c + P.cos_tab[start % 360] * R;
+    n.sy = c + P.sin_tab[start % 360] * R;
+    n.tx = c + P.cos_tab[target % 360] * R;
+    n.ty = c + P.sin_tab[target % 360] * R;
+    n.ox = c + P.cos_tab[offset % 360] * R;
+    n.oy = c + P.sin_tab[offset % 360] * R;
+    n.mine = true;
+    io.sp_r[k] = (uint8_t)n.r;
     io.sp_done[k] = 0;
-    io.sp_t[k] = 0.0;
-    io.sp_speed[k] = speed;
-    io.sp_sx[k] = c + P.cos_tab[start % 360] * R;
-    io.sp_sy[k] = c + P.sin_tab[start % 360] * R;
-    io.sp_tx[k] = c + P.cos_tab[target % 360] * R;
-    io.sp_ty[k] = c + P.sin_tab[target % 360] * R;
-    io.sp_ox[k] = c + P.cos_tab[offset % 360] * R;
-    io.sp_oy[k] = c + P.sin_tab[offset % 360] * R;
+    io.sp_t[k] = n.t;
+    io.sp_speed[k] = n.speed;
+    io.sp_sx[k] = n.sx;
+    io.sp_sy[k] = n.sy;
+    io.sp_tx[k] = n.tx;
+    io.sp_ty[k] = n.ty;
+    io.sp_ox[k] = n.ox;
+    io.sp_oy[k] = n.oy;
+    if (rec) *rec = n;
 }
 
 template <bool EN>
@@ -745,23 +768,25 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     double reward = 0.0, r = 0.0;
     bool spot_done = false;
     s.spawn_timer++;
+    SlotRec born;
+    born.mine = false;
     if constexpr (EN) {
         if (__builtin_expect(s.spawn_timer >= P.spawn_interval, 0)) {
-            new_spot(P, io, i, ls, s, g);
+            new_spot(P, io, i, ls, s, g, &born);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
         if (__builtin_expect(s.spawn_timer >= P.interval0, 0)) {
-            new_spot(P, io, i, ls, s, g);
+            new_spot(P, io, i, ls, s, g, &born);
             s.n_intervals--;
             s.spawn_timer = 0;
         }
     }
-    if (((free_before >> ls) & 1u) && !((s.free_mask >> ls) & 1u)) {  // spawned into my slot just now (rare): re-read it
-        p_t = io.sp_t[k]; p_speed = io.sp_speed[k];
-        p_sx = io.sp_sx[k]; p_sy = io.sp_sy[k]; p_tx = io.sp_tx[k]; p_ty = io.sp_ty[k]; p_ox = io.sp_ox[k]; p_oy = io.sp_oy[k];
-        p_r = io.sp_r[k];
-        p_done = io.sp_done[k] != 0;
+    if (born.mine) {  // spawned into my slot just now: the record this lane has just written
+        p_t = born.t; p_speed = born.speed;
+        p_sx = born.sx; p_sy = born.sy; p_tx = born.tx; p_ty = born.ty; p_ox = born.ox; p_oy = born.oy;
+        p_r = born.r;
+        p_done = born.done;
     }
     const bool used = !((s.free_mask >> ls) & 1u);
     const bool my_done = used && p_done;
