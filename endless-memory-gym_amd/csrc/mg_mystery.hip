@@ -1716,7 +1716,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
     R.tid = threadIdx.x;
     const int tid = threadIdx.x;
     LAB_CLOCK(0);
-    if (blockIdx.x < svc) {
+    if ((int)blockIdx.x < svc) {
         // the service waves run a long dependent instruction chain next to memory-bound raster waves: let them issue first
         if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
         uint8_t* ws = smem + FRAME_BYTES;  // the path workspace lives in the (unused) mask words behind the frame

@@ -739,7 +739,6 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     double p_sx = io.sp_sx[k], p_sy = io.sp_sy[k], p_tx = io.sp_tx[k], p_ty = io.sp_ty[k], p_ox = io.sp_ox[k], p_oy = io.sp_oy[k];
     int p_r = io.sp_r[k];  // bit 7: has_border
     bool p_done = io.sp_done[k] != 0;
-    const uint32_t free_before = s.free_mask;
 
     // CharacterController.step(action, walkable_rect = (0, 4, 84, 80))
     int a0 = actions[2 * i], a1 = actions[2 * i + 1];
