@@ -38,6 +38,14 @@ struct Pcg {
         buf = (uint32_t)b;
         has = (b >> 32) & 1;
     }
+    // A use the compiler cannot move: placed behind other requests, it keeps a speculative load() up front among them
+    // instead of where the (rare) first draw is -- which would be a memory round trip of its own in that path.
+    __device__ __forceinline__ void pin() {
+        uint64_t a = (uint64_t)state, b = (uint64_t)(state >> 64), c = (uint64_t)inc, d = (uint64_t)(inc >> 64);
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(buf));
+        state = ((u128)b << 64) | a;
+        inc = ((u128)d << 64) | c;
+    }
     __device__ __forceinline__ void store(const RngSoA& r, int i) const {
         r.s_hi[i] = (uint64_t)(state >> 64);
         r.s_lo[i] = (uint64_t)state;

@@ -272,15 +272,19 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     // waited for at the end of that branch)
     const bool one_action = P.variant == V_GRID;
     int act0 = actions[one_action ? i : 2 * i], act1 = actions[one_action ? i : 2 * i + 1];
+    // ... and so is the instance's RNG stream (40 bytes): only a finishing instance or an Endless list extension draws, but
+    // read where it is drawn it was a third round trip, in the reset's tail of every launch
+    Pcg g;
+    g.load(io.rng, i);
     MortarState s = io.state[i];
     asm volatile("" : "+v"(act0), "+v"(act1));  // (a use the compiler cannot move below the record's first use)
+    g.pin();
     uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     double reward = 0.0;
     bool done = false;
     int success = 0;
     uint8_t glyph = 0xFF;
-    Pcg g;
-    bool rng_loaded = false;
+    bool rng_used = false;
 
     if (s.vis_pos < s.vis_len) {
         // display phase: pop the next schedule entry, agent frozen
@@ -377,8 +381,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
             }
             if (s.cur_cmd >= s.num_cmds) {
                 if (P.variant == V_ENDLESS) {
-                    g.load(io.rng, i);
-                    rng_loaded = true;
+                    rng_used = true;
                     int nc = g.integers(0, P.allowed);
                     if (s.num_cmds < P.cmd_cap) {
                         cmds[s.num_cmds] = (uint8_t)nc;
@@ -455,8 +458,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     memset(&d, 0, sizeof(d));
     d.glyph_x0 = (int16_t)P.glyph_x0;
     if (done && autoreset) {
-        if (!rng_loaded) g.load(io.rng, i);
-        rng_loaded = true;
+        rng_used = true;
         mortar_reset(P, s, g, cmds, d, (gt && P.variant == V_ENDLESS) ? gt + 2 * i : nullptr, io.vec ? io.vec + (size_t)i * VEC_DIM : nullptr);
     } else {
         int cx = s.disp_is_agent ? s.ax : s.disp_x, cy = s.disp_is_agent ? s.ay : s.disp_y;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
             gt[2 * i + 1] = (float)(s.ty / 5.0);
         }
     }
-    if (rng_loaded) g.store(io.rng, i);
+    if (rng_used) g.store(io.rng, i);
     io.state[i] = s;
     io.desc[i] = d;
 }
