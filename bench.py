@@ -519,7 +519,10 @@ def main():
                                           "%s (profiles/pmc_latest.json, regenerated by tools/profile_round.sh)" % j.get("source", "committed profile"))
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # (mortar family: the step's workgroups ride in front of the raster's in ONE launch, so `avg_launch_ms` is the whole
+            # step's launch and there is no separate logic kernel to time; the algorithmic bytes stay the raster's)
+            one_launch = not r["logic_avg_ms"]
+            out["roofline"] = {"bound": "hbm", "kernel": "step + raster in one launch (rank 0)" if one_launch else "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                                "traffic_passes": traffic_meta,
                                "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],

@@ -71,7 +71,9 @@ struct __attribute__((aligned(16))) MortarDesc {
     uint8_t glyph;     // 0..9 (9 = blank), 0xFF none
     int16_t glyph_x0;  // blit position of the glyph (x == y)
     int16_t ring_x, ring_y;  // debug view only: top-left of the target ring stamp
-    uint16_t ring_on;
+    uint8_t ring_on;
+    uint8_t epoch;     // one-launch step (mortar_step_raster_kernel): the step this descriptor belongs to, mod 256; the LAST
+                       // byte of the record, so that the word that carries it can be published last
 };
 static_assert(sizeof(MortarDesc) == 16, "MortarDesc must be 16 bytes");
 constexpr int STAMP_SPRITE0 = 0, STAMP_GLYPH0 = 8, STAMP_RING = 18;
@@ -261,11 +263,13 @@ __global__ __launch_bounds__(256) void mortar_init_kernel(int n, MortarState* st
     state[i] = s;
 }
 
-__global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n, MortarIO io, const int32_t* actions,
-                                                          float* reward_out, uint8_t* done_out, float* gt,
-                                                          mg_info_buffers info, int autoreset) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// The step of instance i.  FUSED (the one-launch step, mortar_step_raster_kernel): the RNG stream is read where it is drawn
+// (ten registers less: that kernel must fit the raster's 72 VGPRs without scratch) and the descriptor is published for the
+// frame workgroups of the SAME launch: agent-scope (write-through) stores, the word that carries the epoch last.
+template <bool FUSED>
+__device__ __forceinline__ void mortar_step_body(int i, const MortarParams& P, int n, const MortarIO& io, const int32_t* actions,
+                                                 float* reward_out, uint8_t* done_out, float* gt, const mg_info_buffers& info,
+                                                 int autoreset, uint32_t epoch) {
     // the action is requested together with the state record (read where it is used -- behind a test of the state -- it was
     // a second memory round trip at the head of the kernel)
     // (both reads unconditional, the grid variant's second one a repeat of the first: a load inside the variant's branch was
@@ -275,10 +279,11 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     // ... and so is the instance's RNG stream (40 bytes): only a finishing instance or an Endless list extension draws, but
     // read where it is drawn it was a third round trip, in the reset's tail of every launch
     Pcg g;
-    g.load(io.rng, i);
+    bool rng_loaded = !FUSED;
+    if constexpr (!FUSED) g.load(io.rng, i);
     MortarState s = io.state[i];
     asm volatile("" : "+v"(act0), "+v"(act1));  // (a use the compiler cannot move below the record's first use)
-    g.pin();
+    if constexpr (!FUSED) g.pin();
     uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     double reward = 0.0;
     bool done = false;
@@ -381,6 +386,8 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
             }
             if (s.cur_cmd >= s.num_cmds) {
                 if (P.variant == V_ENDLESS) {
+                    if (!rng_loaded) g.load(io.rng, i);
+                    rng_loaded = true;
                     rng_used = true;
                     int nc = g.integers(0, P.allowed);
                     if (s.num_cmds < P.cmd_cap) {
@@ -458,6 +465,8 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     memset(&d, 0, sizeof(d));
     d.glyph_x0 = (int16_t)P.glyph_x0;
     if (done && autoreset) {
+        if (!rng_loaded) g.load(io.rng, i);
+        rng_loaded = true;
         rng_used = true;
         mortar_reset(P, s, g, cmds, d, (gt && P.variant == V_ENDLESS) ? gt + 2 * i : nullptr, io.vec ? io.vec + (size_t)i * VEC_DIM : nullptr);
     } else {
@@ -474,8 +483,83 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n,
     }
     if (rng_used) g.store(io.rng, i);
     io.state[i] = s;
-    io.desc[i] = d;
+    if constexpr (FUSED) {
+        d.epoch = (uint8_t)epoch;
+        uint32_t w[4];
+        memcpy(w, &d, sizeof(w));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&io.desc[i]);
+        __hip_atomic_store(dst + 0, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the three words have reached the coherence point before the fourth leaves
+        __hip_atomic_store(dst + 3, w[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        io.desc[i] = d;
+    }
 }
+
+__global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n, MortarIO io, const int32_t* actions,
+                                                          float* reward_out, uint8_t* done_out, float* gt,
+                                                          mg_info_buffers info, int autoreset) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mortar_step_body<false>(i, P, n, io, actions, reward_out, done_out, gt, info, autoreset, 0u);
+}
+
+// ONE launch per step (uint8 observations).  The first `logic_wgs` workgroups run the step (one lane per instance), all others
+// are the raster's persistent workgroups; a frame's workgroup waits for ITS descriptor -- the epoch in the descriptor's last
+// word, read at agent scope past the caches -- instead of for the slowest wave of a separate logic launch plus that launch's
+// fixed cost: the first frames leave ~8 us earlier (MortarMayhem-Grid 65,536: 233 -> 224 us per step, 281 -> 292 M env-steps/s;
+// 16,384: 69 -> 65 us; profiles/r03_one_launch.md).  68 VGPRs, no scratch, seven workgroups per CU like the raster alone.
+// Liveness rests on workgroups being dispatched in index order (the logic workgroups are resident before the frame workgroups
+// fill the chip; they never wait).  The wait is bounded all the same: a frame that never sees its epoch within ~50 ms is drawn
+// from what is there and error bit 128 is raised.  MEMGYM_MORTAR_FUSE=0: the two-launch form (also used while a stream is
+// being captured into a HIP graph: the epoch is a launch argument, a replay would find it satisfied already).
+constexpr int STEP_RASTER_SPIN_LIMIT = 1 << 16;
+constexpr int ERR_FRAME_WAIT = 128;  // include/memgym.h
+__global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarParams P, int n, MortarIO io, const int32_t* actions,
+                                                                    float* reward_out, uint8_t* done_out, float* gt,
+                                                                    mg_info_buffers info, int autoreset, int logic_wgs, uint32_t epoch,
+                                                                    RasterAtlas A, void* __restrict__ obs) {
+    if ((int)blockIdx.x < logic_wgs) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n) mortar_step_body<true>(i, P, n, io, actions, reward_out, done_out, gt, info, autoreset, epoch);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = A.tables;
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int stride = (int)gridDim.x - logic_wgs;
+    for (int env = (int)blockIdx.x - logic_wgs; env < n; env += stride) {
+        // every lane reads the same four words (one transaction per wave); no barrier: the waves of a workgroup wait separately
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(io.desc + env);
+        uint32_t w[4];
+        int spins = 0;
+        for (;;) {
+            w[3] = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w[3] >> 24) == epoch || ++spins >= STEP_RASTER_SPIN_LIMIT) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (spins >= STEP_RASTER_SPIN_LIMIT && tid == 0) raise_error(io.err, ERR_FRAME_WAIT);
+        // (the publisher's first three words had reached the coherence point before its fourth left)
+        w[0] = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[2] = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        MortarDesc d;
+        memcpy(&d, w, sizeof(d));
+        if (MortarComposer::skip(&d)) continue;
+        MortarComposer::compose(&d, R);
+        __syncthreads();
+        store_frame<MG_OBS_U8_XYC, false>(smem, obs, env, tid);
+        __syncthreads();
+    }
+}
+
+
 
 // Debug view: the frame descriptors of the current frames with (a) the glyph the reference's CLONE of the display schedule
 // yields -- its next entry, popped (dbg_pops, the only state a debug render changes), only while the real schedule still
@@ -626,6 +710,17 @@ class MortarFamily : public Family {
         mg_info_buffers ib;
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
+        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !capturing(s)) {  // one launch: mortar_step_raster_kernel
+            epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never the 0 a reset's (or the two-launch step's) descriptors carry
+            const int logic_wgs = (n_ + 255) / 256;
+            const int frames = n_ < raster_grid(n_) ? n_ : raster_grid(n_);
+            prof.begin(1, s);
+            hipLaunchKernelGGL(mortar_step_raster_kernel, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, P_, n_, io(), actions, reward,
+                               done, gt_dim() ? gt : nullptr, ib, autoreset, logic_wgs, epoch_, atlas_->dev(), obs);
+            MG_HIP(hipGetLastError());
+            prof.end(1, s);
+            return;
+        }
         prof.begin(0, s);
         const int sb = step_block(256);
         hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, n_, io(), actions, reward, done,
@@ -650,6 +745,19 @@ class MortarFamily : public Family {
     int peek_errors() override { return err_.peek(); }
 
    private:
+    uint32_t epoch_ = 0;  // the one-launch step's descriptor epoch, 1 .. 255 (every step rewrites every descriptor, so the only stale
+                          // values a frame workgroup can meet are the previous step's and the 0 of a reset / two-launch step)
+    static bool fuse_step() {
+        static const bool on = [] {
+            const char* e = getenv("MEMGYM_MORTAR_FUSE");
+            return !(e && atoi(e) == 0);
+        }();
+        return on;
+    }
+    static bool capturing(hipStream_t s) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+    }
     MortarIO io() {
         MortarIO o;
         o.state = state_.p;

@@ -353,7 +353,8 @@ class VecMemoryGym:
                   4: "endless path longer than 128 segments", 8: "more than 128 distinct fall-off cells",
                   16: "past-path window wider than 16 columns",
                   32: "Endless Mortar Mayhem command list reached its 512-entry capacity (the episode was ended)",
-                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)"}
+                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)",
+                  128: "one-launch step: a frame workgroup gave up waiting for its descriptor (set MEMGYM_MORTAR_FUSE=0)"}
 
     def check_errors(self):
         """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device).

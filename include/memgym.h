@@ -168,7 +168,10 @@ int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
  *  32  Endless Mortar Mayhem: the command list reached its capacity of 512 entries (the reference's list is unbounded,
  *      endless_mortar_mayhem.py:316-318); the episode of that instance was ended
  *  64  a deferred-reset queue was found over-full (an earlier fused launch failed before draining it); the excess
- *      entries were dropped */
+ *      entries were dropped
+ * 128  mortar family, one-launch step: a frame workgroup gave up waiting (~50 ms) for the descriptor the step's workgroups of
+ *      the same launch publish -- workgroups were not dispatched in index order; that frame shows the previous step.
+ *      MEMGYM_MORTAR_FUSE=0 selects the two-launch form */
 int mg_poll_errors(mg_env* env, int* flags);
 
 /* The same bits as they stand right now: no synchronisation, nothing cleared.  The error word lives in pinned host
