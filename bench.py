@@ -3,7 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--env ID] [--envs-per-gpu M] [--gather [rccl|peer]]
 
-A "step" is one mg_step() over every instance of the workload: logic kernel + raster kernel, with
+A "step" is one mg_step() over every instance of the workload: logic kernel + raster kernel (one launch that holds both for
+the mortar family), with
 same-step auto-reset, 84x84x3 uint8 observations written to HBM.  Inputs (actions) are generated on the device
 before the timed region.
 
@@ -312,7 +313,7 @@ def c1_leg(episodes=200):
     hip = c1_loop.run("hip", "MortarMayhem-Grid-v0", episodes)
     out = {"recipe": "MortarMayhem-Grid-v0 x1, reset(seed=1), PCG64(12345) actions, %d episodes, resets inside the timed region" % episodes,
            "hip_adapter": hip,
-           "note": "one instance is latency-bound on a GPU (two launches and one device->host round trip per step); the batched "
+           "note": "one instance is latency-bound on a GPU (one or two launches and one device->host round trip per step); the batched "
                    "path is the product, this leg is the plumbing check BASELINE.md asks for"}
     try:
         env = dict(os.environ, OMP_NUM_THREADS="1")
