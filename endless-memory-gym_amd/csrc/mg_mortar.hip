@@ -521,9 +521,6 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarParams
                                                                     mg_info_buffers info, int autoreset, int logic_wgs, uint32_t epoch,
                                                                     RasterAtlas A, void* __restrict__ obs) {
     if ((int)blockIdx.x < logic_wgs) {
-#ifdef MG_LAB_STEP_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i < n) mortar_step_body<true>(i, P, n, io, actions, reward_out, done_out, gt, info, autoreset, epoch);
         return;
