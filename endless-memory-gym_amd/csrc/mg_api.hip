@@ -5,6 +5,8 @@
 #include <mutex>
 
 #include "mg_family.hpp"
+#include "mg_lab.hpp"
+using mg::lab_env;
 
 namespace mg {
 static thread_local std::string g_last_error;
@@ -156,7 +158,7 @@ void for_groups(mg_env* e, hipStream_t s, bool stagger, F&& body) {
     // measurement switches (tools/groups_probe.py): MEMGYM_GROUPS_LAB bit 0 = no fork from / join into the caller's stream
     // (results are then NOT ordered with it), bit 1 = no stagger
     static const int lab = [] {
-        const char* v = getenv("MEMGYM_GROUPS_LAB");
+        const char* v = lab_env("MEMGYM_GROUPS_LAB");
         return v ? atoi(v) : 0;
     }();
     if (!(lab & 1)) MG_HIP(hipEventRecord(e->ev_in, s));
@@ -517,6 +519,20 @@ int mg_enable_peer_access(int device, int peer_device) {
         mg::set_error(e.what());
         return -1;
     }
+}
+
+int mg_debug_counter(mg_env* env, const char* name, int64_t* value) {
+    return guarded(env, [&] {
+        if (!name || !value) throw std::runtime_error("mg_debug_counter: NULL");
+        MG_HIP(hipDeviceSynchronize());
+        int64_t total = 0;
+        for (auto* f : env->fams) {
+            int64_t v = 0;
+            if (!f->debug_counter(name, &v)) throw std::runtime_error(std::string("mg_debug_counter: no counter named ") + name + " for " + env->id);
+            total += v;
+        }
+        *value = total;
+    });
 }
 
 int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/memgym.h"
+#include "mg_lab.hpp"
 #include "mg_device.hpp"
 
 namespace mg {
@@ -208,6 +209,8 @@ class Family {
     virtual int poll_errors() { return 0; }
     // the same bits as seen right now, without synchronising or clearing
     virtual int peek_errors() { return 0; }
+    // test / telemetry counters by name (mg_debug_counter); false = this family has no such counter.  Synchronous.
+    virtual bool debug_counter(const std::string& /*name*/, int64_t* /*out*/) { return false; }
 };
 
 Family* make_mortar(int variant, int num_envs);
@@ -218,7 +221,7 @@ Family* make_mystery(int variant, int num_envs);
 // MEMGYM_STEP_BLOCK overrides `shipped` per process (measurements: profiles/r03_step_blocks.md).
 inline int step_block(int shipped) {
     static const int forced = [] {
-        const char* e = getenv("MEMGYM_STEP_BLOCK");
+        const char* e = lab_env("MEMGYM_STEP_BLOCK");
         const int v = e ? atoi(e) : 0;
         return (v == 64 || v == 128 || v == 256) ? v : 0;
     }();

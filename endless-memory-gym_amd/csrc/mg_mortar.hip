@@ -7,17 +7,19 @@
 //   memory_gym/character_controller.py   free :89-146  grid :177-210  screen-wrap :226-283
 //   memory_gym/pygame_assets.py          Command :241-304  MortarTile/MortarArena :306-418
 //
-// Two kernels per step:
-//   mortar_logic  : one LANE per environment instance.  Episode state machine, RNG, reward/done/info; emits a
+// The step is ONE launch for uint8 observations (mortar_step_raster_kernel: the step's workgroups lead the raster's grid and a
+// frame waits for its own descriptor), two launches otherwise (float formats, HIP-graph capture, instance groups):
+//   mortar_step_kernel : one LANE per environment instance.  Episode state machine, RNG, reward/done/info; emits a
 //                   16-byte frame descriptor per instance.  State is small fixed-size records in HBM, read and
 //                   written fully coalesced (lane i <-> record i).
-//   raster_kernel<MortarComposer> : (mg_raster.hpp) persistent workgroups, one frame at a time in LDS: arena
+//   raster_kernel<MortarComposer> : (mg_raster_v1.hpp) persistent workgroups, one frame at a time in LDS: arena
 //                   template (selected by tiles-on / target tile) -> agent sprite stamp -> command glyph stamp.
 #include <memory>
 
 #include "mg_atlas_v1.hpp"
 #include "mg_device.hpp"
 #include "mg_family.hpp"
+#include "mg_lab.hpp"
 #include "mg_raster_v1.hpp"
 #include "mg_stamps.hpp"
 
@@ -266,10 +268,41 @@ __global__ __launch_bounds__(256) void mortar_init_kernel(int n, MortarState* st
 // The step of instance i.  FUSED (the one-launch step, mortar_step_raster_kernel): the RNG stream is read where it is drawn
 // (ten registers less: that kernel must fit the raster's 72 VGPRs without scratch) and the descriptor is published for the
 // frame workgroups of the SAME launch: agent-scope (write-through) stores, the word that carries the epoch last.
-template <bool FUSED>
-__device__ __forceinline__ void mortar_step_body(int i, const MortarParams& P, int n, const MortarIO& io, const int32_t* actions,
-                                                 float* reward_out, uint8_t* done_out, float* gt, const mg_info_buffers& info,
-                                                 int autoreset, uint32_t epoch) {
+// What a step needs besides the instance index: ONE struct, so that it is the head of the kernel-argument segment of both
+// step kernels (mortar_step_raster_kernel reads it a second time through the segment pointer, see there).
+struct MortarStepArgs {
+    MortarParams P;
+    int n;
+    MortarIO io;
+    const int32_t* actions;
+    float* reward_out;
+    uint8_t* done_out;
+    float* gt;
+    mg_info_buffers info;
+    int autoreset;
+};
+
+// CLAIM (the step workgroups of the one-launch step): the wave steps its 64 instances only if it is the first to exchange this
+// step's ticket into `claim_word` (see mortar_step_raster_kernel).  The exchange is ISSUED first and its answer awaited together
+// with the state record: as a round trip of its own in front of the loads it delayed every descriptor, i.e. the whole launch,
+// by 5-8 us (16,384 instances: 65 -> 73 us).
+template <bool FUSED, bool CLAIM = false>
+__device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a, uint32_t epoch, uint32_t* claim_word = nullptr,
+                                                 uint32_t ticket = 0u) {
+    uint32_t claimed_by = 0u;
+    if constexpr (CLAIM) {
+        claimed_by = ticket + 1u;  // lanes other than the wave's first: any value but the ticket
+        if ((threadIdx.x & 63) == 0) claimed_by = __hip_atomic_exchange(claim_word, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the caller has dropped lanes with i >= n: the wave's first lane has its smallest i, so it is active whenever any lane is)
+    }
+    const MortarParams& P = a.P;
+    const MortarIO& io = a.io;
+    const int32_t* const actions = a.actions;
+    float* const reward_out = a.reward_out;
+    uint8_t* const done_out = a.done_out;
+    float* const gt = a.gt;
+    const mg_info_buffers& info = a.info;
+    const int autoreset = a.autoreset;
     // the action is requested together with the state record (read where it is used -- behind a test of the state -- it was
     // a second memory round trip at the head of the kernel)
     // (both reads unconditional, the grid variant's second one a repeat of the first: a load inside the variant's branch was
@@ -284,6 +317,10 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarParams& P, i
     MortarState s = io.state[i];
     asm volatile("" : "+v"(act0), "+v"(act1));  // (a use the compiler cannot move below the record's first use)
     if constexpr (!FUSED) g.pin();
+    if constexpr (CLAIM) {
+        asm volatile("" : "+v"(claimed_by));
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)claimed_by) == ticket) return;  // a frame wave has stepped this slot already
+    }
     uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     double reward = 0.0;
     bool done = false;
@@ -498,31 +535,61 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarParams& P, i
     }
 }
 
-__global__ __launch_bounds__(256) void mortar_step_kernel(MortarParams P, int n, MortarIO io, const int32_t* actions,
-                                                          float* reward_out, uint8_t* done_out, float* gt,
-                                                          mg_info_buffers info, int autoreset) {
+__global__ __launch_bounds__(256) void mortar_step_kernel(MortarStepArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mortar_step_body<false>(i, P, n, io, actions, reward_out, done_out, gt, info, autoreset, 0u);
+    if (i < a.n) mortar_step_body<false>(i, a, 0u);
 }
 
-// ONE launch per step (uint8 observations).  The first `logic_wgs` workgroups run the step (one lane per instance), all others
+// ONE launch per step (uint8 observations).  `logic_wgs` workgroups of the grid run the step (one lane per instance), all others
 // are the raster's persistent workgroups; a frame's workgroup waits for ITS descriptor -- the epoch in the descriptor's last
 // word, read at agent scope past the caches -- instead of for the slowest wave of a separate logic launch plus that launch's
 // fixed cost: the first frames leave ~8 us earlier (MortarMayhem-Grid 65,536: 233 -> 224 us per step, 281 -> 292 M env-steps/s;
-// 16,384: 69 -> 65 us; profiles/r03_one_launch.md).  68 VGPRs, no scratch, seven workgroups per CU like the raster alone.
-// Liveness rests on workgroups being dispatched in index order (the logic workgroups are resident before the frame workgroups
-// fill the chip; they never wait).  The wait is bounded all the same: a frame that never sees its epoch within ~50 ms is drawn
-// from what is there and error bit 128 is raised.  MEMGYM_MORTAR_FUSE=0: the two-launch form (also used while a stream is
-// being captured into a HIP graph: the epoch is a launch argument, a replay would find it satisfied already).
-constexpr int STEP_RASTER_SPIN_LIMIT = 1 << 16;
-constexpr int ERR_FRAME_WAIT = 128;  // include/memgym.h
-__global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarParams P, int n, MortarIO io, const int32_t* actions,
-                                                                    float* reward_out, uint8_t* done_out, float* gt,
-                                                                    mg_info_buffers info, int autoreset, int logic_wgs, uint32_t epoch,
+// 16,384: 69 -> 65 us; profiles/r03_one_launch.md).
+//
+// Liveness does NOT rest on the order in which the hardware dispatches workgroups (round 4).  The instances are stepped in
+// slots of 64 (one wave); a slot belongs to whichever wave first exchanges this step's ticket into its claim word.  Normally
+// that is the step workgroup's wave (the step workgroups come first in the grid and are resident before the frame workgroups
+// fill the chip).  A frame wave whose descriptor has not shown the epoch after RESCUE_AFTER_TICKS (200 us) tries the claim of the
+// slot its frame belongs to ITSELF: if it wins, the step wave has not started yet (e.g. no free slot on the chip because frame
+// workgroups were dispatched first) and the frame wave steps those 64 instances with its own lanes, then draws; if it loses,
+// the slot's owner is a resident wave that never waits for anything, so the descriptor is on its way.  Every wait therefore
+// ends, no frame is ever drawn from a stale descriptor, and there is no time-out to report (error bit 128 of rounds <= 3 is
+// gone).  tests/test_gpu_one_launch.py runs the launch with the step workgroups LAST in the grid (lab build) -- every frame
+// workgroup resident before any step workgroup -- and under a concurrent stream.
+//
+// Hand-over of the 16-byte descriptor: the publisher writes words 0..2 with agent-scope (write-through) stores, waits until they
+// have reached the coherence point (s_waitcnt vmcnt(0)) and only then writes word 3, which carries the epoch; the reader polls
+// word 3 with agent-scope loads and, once it shows the epoch, reads words 0..2 with agent-scope loads issued AFTER that
+// observation.  Release / acquire atomics would be the textbook form; at agent scope on gfx950 they write back / invalidate
+// the whole L2 of the XCD around every hand-over (buffer_wbl2 / buffer_inv sc1), with the observation stream in that L2.
+// The two-launch form is used while a stream is being captured into a HIP graph (epoch and ticket are launch arguments: a
+// replay would find them satisfied already) and for handles with instance groups (their stagger needs the logic launch's end).
+#define MG_KERNARG_AS __attribute__((address_space(4)))
+// A frame wave tries the claim after it has waited this long (real-time clock, 100 MHz).  The step workgroups normally publish
+// within 15-20 us; the first version counted 32 polls (~15 us as it turned out): every early frame wave then sent its one
+// exchange at the few cache lines of claim words, and those ~7,000 serialised atomics cost the 16,384-instance launch 6 of
+// its 66 us (profiles/r04_one_launch.md).
+constexpr unsigned long long RESCUE_AFTER_TICKS = 20000;  // 200 us
+__global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepArgs a, int logic_wgs, int logic_base, uint32_t epoch,
+                                                                    uint32_t ticket, uint32_t* claims, uint32_t* rescues,
                                                                     RasterAtlas A, void* __restrict__ obs) {
-    if ((int)blockIdx.x < logic_wgs) {
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < n) mortar_step_body<true>(i, P, n, io, actions, reward_out, done_out, gt, info, autoreset, epoch);
+    const int n = a.n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rel = (int)blockIdx.x - logic_base;
+    const bool is_logic = rel >= 0 && rel < logic_wgs;
+    // true: this wave owns slot `q` (instances 64 q .. 64 q + 63) for this step
+    auto claim = [&](int q) -> bool {
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_exchange(claims + q, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ticket;
+    };
+    if (is_logic) {  // a step workgroup: wave w steps slot 4 rel + w unless a frame wave got there first
+        const int q = rel * 4 + (tid >> 6), i = q * 64 + lane;
+#if defined(MG_LABV) && MG_LABV >= 1
+        if (i < n) mortar_step_body<true, false>(i, a, epoch);
+#else
+        if (i < n) mortar_step_body<true, true>(i, a, epoch, claims + q, ticket);
+#endif
         return;
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -531,35 +598,58 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarParams
     R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
     R.A = A;
     R.T = A.tables;
-    R.tid = threadIdx.x;
-    const int tid = threadIdx.x;
+    R.tid = tid;
     const int stride = (int)gridDim.x - logic_wgs;
-    for (int env = (int)blockIdx.x - logic_wgs; env < n; env += stride) {
-        // every lane reads the same four words (one transaction per wave); no barrier: the waves of a workgroup wait separately
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(io.desc + env);
+    for (int env = (int)blockIdx.x < logic_base ? (int)blockIdx.x : (int)blockIdx.x - logic_wgs; env < n; env += stride) {
+        // every lane reads the same words (one transaction per wave); no barrier: the waves of a workgroup wait separately
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.io.desc + env);
         uint32_t w[4];
-        int spins = 0;
-        for (;;) {
-            w[3] = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((w[3] >> 24) == epoch || ++spins >= STEP_RASTER_SPIN_LIMIT) break;
+        bool tried = false;
+        unsigned long long t0 = 0;
+        for (int polls = 0;; ++polls) {
+            // (all lanes read the same word; readfirstlane tells the compiler so: the wait loop's control stays scalar)
+            w[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if ((w[3] >> 24) == epoch) break;
+#if defined(MG_LABV) && MG_LABV >= 2
+            if (false) {
+#else
+            if (polls == 0) t0 = wall_clock64();
+            if (!tried && (polls & 15) == 15 && wall_clock64() - t0 >= RESCUE_AFTER_TICKS) {  // (the clock is read every 16th poll)
+#endif
+                tried = true;  // (a lost claim is not retried: its owner is running)
+                if (claim(env >> 6)) {  // rare: step the 64 instances around this frame here; the next poll finds the epoch
+                    // The step's arguments are read AGAIN, from the kernel-argument segment, through a pointer the compiler
+                    // cannot see through: as loop invariants they were hoisted out of the frame loop and kept in ~80 scalar
+                    // registers for its whole length (spilled to vector lanes, those to scratch: 232 B per lane).
+                    const MortarStepArgs MG_KERNARG_AS* ka = (const MortarStepArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ka));
+                    int i = (env >> 6) * 64 + lane;
+                    asm volatile("" : "+v"(i));  // (nor may what the step derives from `i` be computed at the head of every frame)
+                    if (i < n) mortar_step_body<true>(i, *(const MortarStepArgs*)ka, epoch);
+                    if (lane == 0) atomicAdd(rescues, 1u);
+                    continue;
+                }
+            }
             __builtin_amdgcn_s_sleep(4);
         }
-        if (spins >= STEP_RASTER_SPIN_LIMIT && tid == 0) raise_error(io.err, ERR_FRAME_WAIT);
-        // (the publisher's first three words had reached the coherence point before its fourth left)
+        asm volatile("" ::: "memory");  // the loads below stay behind the observation of the epoch
         w[0] = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w[1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w[2] = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MortarDesc d;
         memcpy(&d, w, sizeof(d));
         if (MortarComposer::skip(&d)) continue;
+        // the lane's frame offsets are derived from an opaque copy of its index, i.e. inside the iteration: as loop invariants
+        // they were live across the (rare) step code above, which needs every register the kernel has
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        R.tid = t;
         MortarComposer::compose(&d, R);
         __syncthreads();
-        store_frame<MG_OBS_U8_XYC, false>(smem, obs, env, tid);
+        store_frame<MG_OBS_U8_XYC, false>(smem, obs, env, t);
         __syncthreads();
     }
 }
-
-
 
 // Debug view: the frame descriptors of the current frames with (a) the glyph the reference's CLONE of the display schedule
 // yields -- its next entry, popped (dbg_pops, the only state a debug render changes), only while the real schedule still
@@ -617,9 +707,9 @@ class MortarFamily : public Family {
         P_.max_steps = -1;
         P_.initial_count = 1;
         P_.cmd_cap = variant == V_ENDLESS ? 512 : 32;
-        if (variant == V_ENDLESS) {  // tests only (tests/test_gpu_error_bits.py): a small capacity makes the overflow reachable
-            const char* e = getenv("MEMGYM_EMM_CMD_CAP");
-            if (e && atoi(e) >= 4 && atoi(e) <= 512) P_.cmd_cap = atoi(e);
+        if (variant == V_ENDLESS) {  // lab build only (tests/test_gpu_error_bits.py): a small capacity makes the overflow reachable
+            const int cap = lab_int("MEMGYM_EMM_CMD_CAP", 0);
+            if (cap >= 4 && cap <= 512) P_.cmd_cap = cap;
         }
         st_command_count_.set(P_.command_count, {10});
         st_show_dur_.set(P_.show_dur, {3});
@@ -635,6 +725,8 @@ class MortarFamily : public Family {
         desc_.alloc(n);
         rng_.alloc(n);
         err_.alloc();
+        claims_.alloc((size_t)((n + 255) / 256) * 4);
+        rescues_.alloc(1);
         hipLaunchKernelGGL(mortar_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, state_.p);
         MG_HIP(hipDeviceSynchronize());
         rebuild();
@@ -710,21 +802,24 @@ class MortarFamily : public Family {
         mg_info_buffers ib;
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
-        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !capturing(s)) {  // one launch: mortar_step_raster_kernel
+        const MortarStepArgs sa{P_, n_, io(), actions, reward, done, gt_dim() ? gt : nullptr, ib, autoreset};
+        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !logic_event && !capturing(s)) {  // one launch: mortar_step_raster_kernel
             epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never the 0 a reset's (or the two-launch step's) descriptors carry
+            ++ticket_;                    // claim words hold the ticket of the last one-launch step: never this one
             const int logic_wgs = (n_ + 255) / 256;
             const int frames = n_ < raster_grid(n_) ? n_ : raster_grid(n_);
+            // lab build, MEMGYM_LAB_LOGIC_LAST=1: the step workgroups at the END of the grid -- the dispatch order the design must survive
+            static const bool logic_last = lab_int("MEMGYM_LAB_LOGIC_LAST", 0) != 0;
             prof.begin(1, s);
-            hipLaunchKernelGGL(mortar_step_raster_kernel, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, P_, n_, io(), actions, reward,
-                               done, gt_dim() ? gt : nullptr, ib, autoreset, logic_wgs, epoch_, atlas_->dev(), obs);
+            hipLaunchKernelGGL(mortar_step_raster_kernel, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, sa, logic_wgs,
+                               logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs);
             MG_HIP(hipGetLastError());
             prof.end(1, s);
             return;
         }
         prof.begin(0, s);
         const int sb = step_block(256);
-        hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, n_, io(), actions, reward, done,
-                           gt_dim() ? gt : nullptr, ib, autoreset);
+        hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, sa);
         end_logic(s);
         prof.begin(1, s);
         raster(obs, s);
@@ -743,15 +838,20 @@ class MortarFamily : public Family {
         return err_.take();
     }
     int peek_errors() override { return err_.peek(); }
+    bool debug_counter(const std::string& name, int64_t* out) override {
+        if (name != "one_launch_rescues") return false;  // 64-instance slots stepped by a frame wave since the handle was created
+        uint32_t v = 0;
+        MG_HIP(hipMemcpy(&v, rescues_.p, sizeof v, hipMemcpyDeviceToHost));
+        *out = (int64_t)v;
+        return true;
+    }
 
    private:
+    uint32_t ticket_ = 0;  // one-launch step: number of the step, the value a slot's claim word takes when a wave claims it
     uint32_t epoch_ = 0;  // the one-launch step's descriptor epoch, 1 .. 255 (every step rewrites every descriptor, so the only stale
                           // values a frame workgroup can meet are the previous step's and the 0 of a reset / two-launch step)
-    static bool fuse_step() {
-        static const bool on = [] {
-            const char* e = getenv("MEMGYM_MORTAR_FUSE");
-            return !(e && atoi(e) == 0);
-        }();
+    static bool fuse_step() {  // lab build: MEMGYM_MORTAR_FUSE=0 selects the two-launch form for A/B measurements
+        static const bool on = lab_int("MEMGYM_MORTAR_FUSE", 1) != 0;
         return on;
     }
     static bool capturing(hipStream_t s) {
@@ -840,6 +940,7 @@ class MortarFamily : public Family {
     DevArray<MortarDesc> desc_;
     RngStore rng_;
     ErrorWord err_;
+    DevArray<uint32_t> claims_, rescues_;  // one-launch step: one claim word per 64 instances; slots stepped by frame waves
     OptListStore st_command_count_, st_show_dur_, st_show_delay_, st_expl_dur_, st_expl_delay_;
 };
 

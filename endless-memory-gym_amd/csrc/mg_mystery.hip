@@ -17,6 +17,7 @@
 #include <memory>
 
 #include "mg_atlas_v1.hpp"
+#include "mg_lab.hpp"
 #include "mg_device.hpp"
 #include "mg_family.hpp"
 #include "mg_raster_v1.hpp"
@@ -1810,9 +1811,9 @@ class MysteryFamily : public Family {
         agent_speed_ = 12.0 * SCALE;
         P_.visual_feedback = 1;
         // Endless-MysteryPath: 187-189 -> 175-182 us per fused launch (profiles/r03_emp.md); no effect on MysteryPath-Grid's
-        P_.svc_prio = [endless] { const char* e = getenv("MEMGYM_SVC_PRIO"); return e ? atoi(e) : (endless ? 1 : 0); }();
-        P_.path_help = [] { const char* e = getenv("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
-        lazy_wanted_ = endless && [] { const char* e = getenv("MEMGYM_EMP_LAZY"); return e ? atoi(e) != 0 : true; }();
+        P_.svc_prio = [endless] { const char* e = lab_env("MEMGYM_SVC_PRIO"); return e ? atoi(e) : (endless ? 1 : 0); }();
+        P_.path_help = [] { const char* e = lab_env("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
+        lazy_wanted_ = endless && [] { const char* e = lab_env("MEMGYM_EMP_LAZY"); return e ? atoi(e) != 0 : true; }();
         P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
         if (endless) {
             P_.max_steps = -1; P_.show_past_path = 1; camera_offset_scale_ = 5.0; P_.stamina_level = 20;
@@ -1943,7 +1944,7 @@ class MysteryFamily : public Family {
                 MG_HIP(hipGetLastError());
                 prof.end(1, s);
 #ifdef MG_LAB_EMP_CLOCK  // diagnosis: is the next logic kernel slow because the L2 is full of dirty observation lines?
-                static const int wb = [] { const char* e = getenv("MEMGYM_LAB_WBL2"); return e ? atoi(e) : 0; }();
+                static const int wb = [] { const char* e = lab_env("MEMGYM_LAB_WBL2"); return e ? atoi(e) : 0; }();
                 if (wb) hipLaunchKernelGGL(lab_wbl2_kernel, dim3(wb), dim3(64), 0, s);
 #endif
                 return;
@@ -1985,7 +1986,7 @@ class MysteryFamily : public Family {
     // instance-carrying lanes per wave (see instance_of_lane); MEMGYM_MYSTERY_LPW overrides for tuning
     int lpw() const {
         static const int forced = [] {
-            const char* e = getenv("MEMGYM_MYSTERY_LPW");
+            const char* e = lab_env("MEMGYM_MYSTERY_LPW");
             return e ? atoi(e) : 0;
         }();
         if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
@@ -1994,7 +1995,7 @@ class MysteryFamily : public Family {
     // workgroups (4 waves each) of emp_serve_kernel; MEMGYM_EMP_SERVERS overrides for tuning
     int servers(bool all) const {
         static const int forced = [] {
-            const char* e = getenv("MEMGYM_EMP_SERVERS");
+            const char* e = lab_env("MEMGYM_EMP_SERVERS");
             return e ? atoi(e) : 0;
         }();
         const int want = forced > 0 ? forced : (all ? 1024 : 512);  // measured: profiles/r01e_logic_tails.md section 4
@@ -2009,7 +2010,7 @@ class MysteryFamily : public Family {
     // MEMGYM_EMP_FUSE=0: separate queue-server launch in front of the raster (the round-1 arrangement)
     bool fuse_serve() const {
         static const bool on = [] {
-            const char* e = getenv("MEMGYM_EMP_FUSE");
+            const char* e = lab_env("MEMGYM_EMP_FUSE");
             return !(e && atoi(e) == 0);
         }();
         return on;
@@ -2017,7 +2018,7 @@ class MysteryFamily : public Family {
     // MEMGYM_EMP_RESET_LANES=0: a full reset through the queue server, one wave per instance (round 1)
     bool reset_by_lanes() const {
         static const bool on = [] {
-            const char* e = getenv("MEMGYM_EMP_RESET_LANES");
+            const char* e = lab_env("MEMGYM_EMP_RESET_LANES");
             return !(e && atoi(e) == 0);
         }();
         return on;
@@ -2028,7 +2029,7 @@ class MysteryFamily : public Family {
     // in which all survivors are truncated at once was a 450-us launch).  MEMGYM_MYSTERY_DEFER=0 / 1 / 2 forces a mode.
     int defer_mode() const {
         static const int forced = [] {
-            const char* e = getenv("MEMGYM_MYSTERY_DEFER");
+            const char* e = lab_env("MEMGYM_MYSTERY_DEFER");
             return e ? atoi(e) : -1;
         }();
         return forced >= 0 && forced <= 2 ? forced : (P_.grid != 0 ? 1 : 2);

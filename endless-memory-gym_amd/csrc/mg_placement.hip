@@ -24,6 +24,8 @@
 #include <vector>
 
 #include "mg_family.hpp"
+#include "mg_lab.hpp"
+using mg::lab_env;
 
 namespace {
 
@@ -39,8 +41,8 @@ constexpr int PROBE_GRID = 14336;
 // become relative: the geometric mean of the extremes -/+ 3 %.  A
 // search whose earlier decisions the calibrated thresholds would change starts over once.  (A piece paired with ITSELF is no
 // calibration: both windows then hit the same cache lines, 11.6 TB/s.)  MEMGYM_OBS_SAME_TBPS / MEMGYM_OBS_CROSS_TBPS set the prior.
-static const double PRIOR_SAME_TBPS = getenv("MEMGYM_OBS_SAME_TBPS") ? atof(getenv("MEMGYM_OBS_SAME_TBPS")) : 5.35;
-static const double PRIOR_CROSS_TBPS = getenv("MEMGYM_OBS_CROSS_TBPS") ? atof(getenv("MEMGYM_OBS_CROSS_TBPS")) : 5.85;
+static const double PRIOR_SAME_TBPS = lab_env("MEMGYM_OBS_SAME_TBPS") ? atof(lab_env("MEMGYM_OBS_SAME_TBPS")) : 5.35;
+static const double PRIOR_CROSS_TBPS = lab_env("MEMGYM_OBS_CROSS_TBPS") ? atof(lab_env("MEMGYM_OBS_CROSS_TBPS")) : 5.85;
 struct Calib {
     double lo = 1e30, hi = 0;
     bool relative = false;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void zone_probe_kernel(u32x4* w0, u32x4* w1) {
 // scribble over memory that belongs to somebody else by now.  A reservation costs address space only (a few GiB of the
 // 128-TiB space per call), so unmapped ranges simply stay reserved.  MEMGYM_OBS_REUSE_VA=1 restores the frees (experiments).
 inline void va_free(void* va, size_t bytes) {
-    static const bool reuse = getenv("MEMGYM_OBS_REUSE_VA") && atoi(getenv("MEMGYM_OBS_REUSE_VA")) != 0;
+    static const bool reuse = lab_env("MEMGYM_OBS_REUSE_VA") && atoi(lab_env("MEMGYM_OBS_REUSE_VA")) != 0;
     if (reuse) (void)hipMemAddressFree(va, bytes);
 }
 
@@ -136,7 +138,7 @@ hipError_t va_reserve(void** va, size_t bytes) {
 }
 
 bool create_piece(int device, size_t bytes, Piece* out, bool exportable = false) {
-    static const bool no_vmm = getenv("MEMGYM_OBS_NO_VMM") && atoi(getenv("MEMGYM_OBS_NO_VMM")) != 0;  // tests: a runtime without hipMemCreate
+    static const bool no_vmm = lab_env("MEMGYM_OBS_NO_VMM") && atoi(lab_env("MEMGYM_OBS_NO_VMM")) != 0;  // tests: a runtime without hipMemCreate
     if (no_vmm) return false;
     hipMemAllocationProp p = prop_for(device);
     if (exportable) p.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
@@ -291,7 +293,7 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             ~Restore() { (void)hipSetDevice(d); }
         } restore{prev};
         const auto t0 = std::chrono::steady_clock::now();
-        const bool debug = getenv("MEMGYM_OBS_DEBUG") != nullptr;
+        const bool debug = lab_env("MEMGYM_OBS_DEBUG") != nullptr;
         *out = nullptr;
         size_t free_b = 0, total_b = 0;
         MG_HIP(hipMemGetInfo(&free_b, &total_b));

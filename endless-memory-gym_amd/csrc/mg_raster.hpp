@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "../../include/memgym.h"
+#include "mg_lab.hpp"
 #include "mg_device.hpp"
 #include "mg_stream_out.hpp"
 
@@ -169,12 +170,15 @@ __device__ __forceinline__ int hole_radius(uint32_t hv) { return (int)((hv >> 18
 __device__ __forceinline__ void zero_mask(const RasterCtx& R) {
     if (R.tid < SCREEN * MASK_WORDS) R.mask[R.tid] = 0u;
 }
-__device__ __forceinline__ void hole_mask(const RasterCtx& R, cptr<uint32_t> holes, int nholes) {
-    const int sub = R.tid >> 6, col0 = R.tid & 63;
+// (hole_at(h): the h-th packed hole of the frame's descriptor, h workgroup- or wave-uniform; the descriptor may sit behind scalar
+// loads or in a register: mg_spot.hip SpotView)
+template <class HoleAt>
+__device__ __forceinline__ void hole_mask(const RasterCtx& R, HoleAt hole_at, int nholes) {
+    const int sub = __builtin_amdgcn_readfirstlane(R.tid >> 6), col0 = R.tid & 63;
     for (int base = 0; base < nholes; base += 4) {
         int hI = base + sub;
         if (hI >= nholes) continue;
-        const uint32_t hv = holes[hI];
+        const uint32_t hv = hole_at(hI);
         const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
         for (int col = col0; col < 2 * r; col += 64) {
             int X = hx - r + col;
@@ -203,23 +207,25 @@ struct HoleRegs8 {
     uint32_t span[2];  // its span-table entry: lo | hi << 8 (int8 y offsets); decoded in hole_apply8, so that hole_fetch8
                        // only ISSUES loads and the frame's whole prefetch is one memory round trip
 };
-__device__ __forceinline__ bool holes_small(cptr<uint32_t> holes, int nholes) {
+template <class HoleAt>
+__device__ __forceinline__ bool holes_small(HoleAt hole_at, int nholes) {
     bool ok = nholes <= 16;
-    for (int h = 0; h < nholes; ++h) ok = ok && hole_radius(holes[h]) <= 16;
+    for (int h = 0; h < nholes; ++h) ok = ok && hole_radius(hole_at(h)) <= 16;
     return ok;
 }
 // A wave handles two holes per round (its lower and upper 32 lanes): their packed words are read with WAVE-UNIFORM indices --
 // scalar loads like the rest of the descriptor -- and picked per lane, so that the span-table read is the only vector-memory
 // hop of the spotlight layer and leaves together with the frame's other loads (as a lane-indexed load the word cost a
 // round trip of its own in front of the span read).
-__device__ __forceinline__ void hole_fetch8(const RasterCtx& R, cptr<uint32_t> holes, int nholes, HoleRegs8& H) {
+template <class HoleAt>
+__device__ __forceinline__ void hole_fetch8(const RasterCtx& R, HoleAt hole_at, int nholes, HoleRegs8& H) {
     const int sub = R.tid >> 5, col = R.tid & 31;
     const int wave2 = __builtin_amdgcn_readfirstlane(R.tid >> 6) * 2;
     const uint16_t* spans = reinterpret_cast<const uint16_t*>(R.A.disc_span);
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
         const int hI = rnd * 8 + sub, h0 = rnd * 8 + wave2;
-        const uint32_t lo_word = h0 < nholes ? holes[h0] : 0u, hi_word = h0 + 1 < nholes ? holes[h0 + 1] : 0u;
+        const uint32_t lo_word = h0 < nholes ? hole_at(h0) : 0u, hi_word = h0 + 1 < nholes ? hole_at(h0 + 1) : 0u;
         const uint32_t hv = (R.tid & 32) ? hi_word : lo_word;
         const int r = hole_radius(hv);
         const bool task = hI < nholes && col < 2 * r;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
 // At 32,768 frames and beyond 14,336 workgroups win (32,768: 121.4 against 124.1-127.1 us for 7,168-12,288).
 inline int raster_grid(int n) {
     static const int forced = [] {
-        const char* e = getenv("MEMGYM_RASTER_GRID");
+        const char* e = lab_env("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : 0;
     }();
     return forced > 0 ? forced : (n <= 24576 ? RASTER_GRID_SMALL : RASTER_GRID);
@@ -361,7 +367,7 @@ inline int raster_grid(int n) {
 // wins).  MEMGYM_RASTER_NT = 0 / 1 forces one (tuning only).  profiles/r03_spot_store_lab.md.
 inline bool raster_nt(int n) {
     static const int forced = [] {
-        const char* e = getenv("MEMGYM_RASTER_NT");
+        const char* e = lab_env("MEMGYM_RASTER_NT");
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     return forced >= 0 ? forced != 0 : n > RASTER_PLAIN_MAX;
@@ -377,7 +383,7 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
     // stores -- small launches and the float formats -- want all seven (7: 59.7, 6: 62.3 us; profiles/r03_spot_store_lab.md).
     // MEMGYM_RASTER_LDS overrides (tuning only).
     static const int forced_lds = [] {
-        const char* e = getenv("MEMGYM_RASTER_LDS");
+        const char* e = lab_env("MEMGYM_RASTER_LDS");
         return e && atoi(e) >= RASTER_LDS ? atoi(e) : 0;
     }();
     const bool nt = fmt == MG_OBS_U8_XYC && raster_nt(n);

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "../../include/memgym.h"
+#include "mg_lab.hpp"
 #include "mg_device.hpp"
 #include "mg_stream_out.hpp"
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
 // Workgroups of a raster launch over n frames (MEMGYM_RASTER_GRID overrides: tuning experiments)
 inline int raster_grid(int n) {
     static const int forced = [] {
-        const char* e = getenv("MEMGYM_RASTER_GRID");
+        const char* e = lab_env("MEMGYM_RASTER_GRID");
         return e ? atoi(e) : 0;
     }();
     (void)n;
@@ -206,7 +207,7 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
     // fits) is the optimum once the observation buffer sits in a fast allocation (profiles/r01l_placement.md):
     // MortarMayhem-Grid 223.4-224.5 us at 7, 229.4 at 6, 243-244 at 5; in a slow allocation 6 was 1-3 % ahead of 7.
     static const int lds = [] {
-        const char* e = getenv("MEMGYM_RASTER_LDS");
+        const char* e = lab_env("MEMGYM_RASTER_LDS");
         return e && atoi(e) >= RASTER_LDS ? atoi(e) : RASTER_LDS;
     }();
     if (fmt == MG_OBS_F32_CYX)

@@ -20,6 +20,7 @@
 #include <memory>
 
 #include "mg_atlas.hpp"
+#include "mg_lab.hpp"
 #include "mg_device.hpp"
 #include "mg_family.hpp"
 #include "mg_raster.hpp"
@@ -29,7 +30,7 @@ namespace mg {
 
 constexpr int SLOTS = 16;
 constexpr int MAX_COINS = 8;
-constexpr int MAX_HOLES = 24;
+constexpr int MAX_HOLES = 16;  // = SLOTS: a frame shows at most one disc per slot
 constexpr int LAYER_COIN_ABOVE = 1, LAYER_EXIT_ABOVE = 2, LAYER_AGENT_TOP = 4;  // SpotDesc::coin_above: what is drawn over the dark layer
 
 struct SpotParams {
@@ -68,19 +69,72 @@ struct __attribute__((aligned(16))) SpotCore {
 };
 static_assert(sizeof(SpotCore) == 80, "SpotCore must be 80 bytes");
 
-struct __attribute__((aligned(16))) SpotDesc {
-    // 32-bit bit-fields: the raster kernel reads these with scalar dword loads (there is no sub-dword scalar load)
+// The frame descriptor: 32 dwords = ONE 128-byte line, two 64-byte halves with an epoch word each (the one-launch step,
+// spot_step_raster_kernel, hands descriptors from its step waves to its frame waves inside the launch; a reader that finds this
+// launch's epoch in BOTH halves of one load holds a consistent record).
+//   w0  valid | bg << 8 | sprite << 16 | alpha << 24          w1  sx | sy << 16 (int16 each)
+//   w2  n_holes | n_coins << 8 | coin_above << 16 | red_w << 24
+//   w3  c_base | c_act0 << 8 | c_act1 << 16 | c_bar << 24      w4  bar_x | bar_w << 8 | quarter << 16 | exit_stamp << 24
+//   w5  exit_x | exit_y << 16                                  w6  holes[15]        w7  epoch (first half)
+//   w8 .. w15  coins: (x + 128) | (y + 128) << 16, top-left of the coin stamp
+//   w16 .. w30 holes[0 .. 14]                                  w31 epoch (second half)
+// Readers address it by WORD (SpotView below), through scalar loads (a pointer in the constant address space) or through lane
+// reads of a register that holds word k in lane k.
+struct __attribute__((aligned(128))) SpotDesc {
     uint32_t valid : 8, bg : 8, sprite : 8, alpha : 8;
     int32_t sx : 16, sy : 16;
     uint32_t n_holes : 8, n_coins : 8, coin_above : 8, red_w : 8;
     uint32_t c_base : 8, c_act0 : 8, c_act1 : 8, c_bar : 8;
     uint32_t bar_x : 8, bar_w : 8, quarter : 8, exit_stamp : 8;
     int32_t exit_x : 16, exit_y : 16;
-    uint32_t pad[2];
-    uint32_t coins[MAX_COINS];  // (x+128) | (y+128)<<16 : top-left of the coin stamp
-    uint32_t holes[MAX_HOLES];
+    uint32_t hole15;
+    uint32_t epoch_a;
+    uint32_t coins[MAX_COINS];
+    uint32_t holes[MAX_HOLES - 1];
+    uint32_t epoch_b;
 };
-static_assert(sizeof(SpotDesc) == 160, "SpotDesc must be 160 bytes");
+static_assert(sizeof(SpotDesc) == 128 && MAX_HOLES == 16 && MAX_COINS == 8, "SpotDesc is one 128-byte line");
+constexpr int DW_HOLE15 = 6, DW_EPOCH_A = 7, DW_COINS = 8, DW_HOLES = 16, DW_EPOCH_B = 31, DESC_WORDS = 32;
+__device__ __forceinline__ int hole_word(int h) { return h < MAX_HOLES - 1 ? DW_HOLES + h : DW_HOLE15; }
+
+struct DescWordsMem {  // the descriptor in memory, written by an EARLIER launch: scalar loads
+    cptr<uint32_t> p;
+    __device__ __forceinline__ uint32_t w(int k) const { return p[k]; }
+};
+struct DescWordsReg {  // word k in lane k (k < 32) of one vector register: v_readlane, the result is a scalar like a scalar load's
+    uint32_t v;
+    __device__ __forceinline__ uint32_t w(int k) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); }
+};
+template <class W>
+struct SpotView {
+    W s;
+    __device__ __forceinline__ uint32_t valid() const { return s.w(0) & 0xFFu; }
+    __device__ __forceinline__ uint32_t bg() const { return (s.w(0) >> 8) & 0xFFu; }
+    __device__ __forceinline__ uint32_t sprite() const { return (s.w(0) >> 16) & 0xFFu; }
+    __device__ __forceinline__ uint32_t alpha() const { return s.w(0) >> 24; }
+    __device__ __forceinline__ int sx() const { return (int)(int16_t)(s.w(1) & 0xFFFFu); }
+    __device__ __forceinline__ int sy() const { return (int)s.w(1) >> 16; }
+    __device__ __forceinline__ int n_holes() const { return (int)(s.w(2) & 0xFFu); }
+    __device__ __forceinline__ int n_coins() const { return (int)((s.w(2) >> 8) & 0xFFu); }
+    __device__ __forceinline__ uint32_t coin_above() const { return (s.w(2) >> 16) & 0xFFu; }
+    __device__ __forceinline__ int red_w() const { return (int)(s.w(2) >> 24); }
+    __device__ __forceinline__ uint32_t c_base() const { return s.w(3) & 0xFFu; }
+    __device__ __forceinline__ uint32_t c_act0() const { return (s.w(3) >> 8) & 0xFFu; }
+    __device__ __forceinline__ uint32_t c_act1() const { return (s.w(3) >> 16) & 0xFFu; }
+    __device__ __forceinline__ uint32_t c_bar() const { return s.w(3) >> 24; }
+    __device__ __forceinline__ int bar_x() const { return (int)(s.w(4) & 0xFFu); }
+    __device__ __forceinline__ int bar_w() const { return (int)((s.w(4) >> 8) & 0xFFu); }
+    __device__ __forceinline__ int quarter() const { return (int)((s.w(4) >> 16) & 0xFFu); }
+    __device__ __forceinline__ uint32_t exit_stamp() const { return s.w(4) >> 24; }
+    __device__ __forceinline__ int exit_x() const { return (int)(int16_t)(s.w(5) & 0xFFFFu); }
+    __device__ __forceinline__ int exit_y() const { return (int)s.w(5) >> 16; }
+    __device__ __forceinline__ int coin_x(int k) const { return (int)(s.w(DW_COINS + k) & 0xFFFFu) - 128; }
+    __device__ __forceinline__ int coin_y(int k) const { return (int)(s.w(DW_COINS + k) >> 16) - 128; }
+    __device__ __forceinline__ uint32_t hole(int h) const { return s.w(hole_word(h)); }
+};
+typedef SpotView<DescWordsMem> SpotViewMem;
+typedef SpotView<DescWordsReg> SpotViewReg;
+__device__ __forceinline__ SpotViewMem view_of(cptr<SpotDesc> dp) { return SpotViewMem{DescWordsMem{(cptr<uint32_t>)dp}}; }
 
 constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
 // hide_chessboard / black_background paint over the two background surfaces an environment object keeps for its lifetime
@@ -103,12 +157,13 @@ constexpr int BAR_H = 4;  // top bar height: int(16 * SCALE)
 // a border iff the LAST disc covering it has one and the pixel lies on it.  One lane per column walks the hole words in
 // order: a disc clears the ring bits of its column span, a border sets its own (draw_circle_bresenham_thin: the end points
 // of the spans draw_circle_filled walks, for every x step).  Only the border composer does this.
-__device__ __forceinline__ void ring_mask(const RasterCtx& R, cptr<uint32_t> holes, int nholes, uint32_t* ring) {
+template <class HoleAt>
+__device__ __forceinline__ void ring_mask(const RasterCtx& R, HoleAt hole_at, int nholes, uint32_t* ring) {
     if (R.tid >= SCREEN) return;
     const int X = R.tid;
     uint32_t rg[MASK_WORDS] = {0u, 0u, 0u};
     for (int h = 0; h < nholes; ++h) {
-        const uint32_t hv = holes[h];
+        const uint32_t hv = hole_at(h);
         const int hx = (int)(hv & 511u) - 128, hy = (int)((hv >> 9) & 511u) - 128, r = hole_radius(hv);
         const int col = X - (hx - r);
         if (col < 0 || col >= 2 * r) continue;
@@ -181,22 +236,25 @@ __device__ __forceinline__ uint32_t* ring_words() {  // LDS of the border compos
 template <bool BORDER>
 struct SpotComposerT {
     typedef SpotDesc Desc;
-    static __device__ __forceinline__ bool skip(cptr<Desc> dp) { return dp->valid == 0; }
+    static __device__ __forceinline__ bool skip(cptr<Desc> dp) { return view_of(dp).valid() == 0; }
     // top bar (rows y < BAR_H of every column); priority reward bar > action rects > red > green > base.
     // Returns false where no bar element covers column x (the scene shows through).
-    static __device__ __forceinline__ bool bar_colour(const Desc MG_CONST_AS& d, cptr<AtlasTables> T, int x, uint32_t* c) {
-        bool has = d.c_base != 0xFF;
-        uint8_t id = d.c_base;
-        if (x < 2 * d.quarter) { id = x < d.red_w ? (uint8_t)C_RED : (uint8_t)C_GREEN; has = true; }
-        else if (d.c_act0 != 0xFF) { id = x < 3 * d.quarter ? d.c_act0 : d.c_act1; has = true; }
-        if (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w) { id = d.c_bar; has = true; }
+    template <class V>
+    static __device__ __forceinline__ bool bar_colour(const V& d, cptr<AtlasTables> T, int x, uint32_t* c) {
+        bool has = d.c_base() != 0xFF;
+        uint32_t id = d.c_base();
+        if (x < 2 * d.quarter()) { id = x < d.red_w() ? (uint32_t)C_RED : (uint32_t)C_GREEN; has = true; }
+        else if (d.c_act0() != 0xFF) { id = x < 3 * d.quarter() ? d.c_act0() : d.c_act1(); has = true; }
+        if (d.c_bar() != 0xFF && x >= d.bar_x() && x < d.bar_x() + d.bar_w()) { id = d.c_bar(); has = true; }
         if (has) *c = T->palette[id];
         return has;
     }
-    static __device__ __forceinline__ bool bar_covers(const Desc MG_CONST_AS& d, int x) {
-        return d.c_base != 0xFF || x < 2 * d.quarter || d.c_act0 != 0xFF || (d.c_bar != 0xFF && x >= d.bar_x && x < d.bar_x + d.bar_w);
+    template <class V>
+    static __device__ __forceinline__ bool bar_covers(const V& d, int x) {
+        return d.c_base() != 0xFF || x < 2 * d.quarter() || d.c_act0() != 0xFF || (d.c_bar() != 0xFF && x >= d.bar_x() && x < d.bar_x() + d.bar_w());
     }
-    static __device__ __forceinline__ void bar_columns(const Desc MG_CONST_AS& d, cptr<AtlasTables> T, const RasterCtx& R) {
+    template <class V>
+    static __device__ __forceinline__ void bar_columns(const V& d, cptr<AtlasTables> T, const RasterCtx& R) {
         static_assert(BAR_H == 4, "one bar column = 4 pixels = 3 dwords");
         if (R.tid < SCREEN) {
             uint32_t c = 0u;
@@ -218,82 +276,82 @@ struct SpotComposerT {
         HoleRegs8 holes;
     };
     // every global read of the frame (template, sprite / coin / exit pixels, disc spans)
-    static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) {
-        const Desc MG_CONST_AS& d = *dp;
-        templ_fetch(R, d.bg, P.bg);
-        stamp_fetch<1>(R, d.sprite, P.agent);
-        if (d.n_coins) stamp_fetch<1>(R, ST_COIN, P.coin);
+    template <class V>
+    static __device__ __forceinline__ void prefetch_v(const V& d, const RasterCtx& R, Pre& P) {
+        templ_fetch(R, d.bg(), P.bg);
+        stamp_fetch<1>(R, d.sprite(), P.agent);
+        if (d.n_coins()) stamp_fetch<1>(R, ST_COIN, P.coin);
         else stamp_none<1>(P.coin);
-        if (d.exit_stamp != 0xFF) stamp_fetch<1>(R, d.exit_stamp, P.exitp);
+        if (d.exit_stamp() != 0xFF) stamp_fetch<1>(R, d.exit_stamp(), P.exitp);
         else stamp_none<1>(P.exitp);
         P.holes.hole[0] = P.holes.hole[1] = P.holes.span[0] = P.holes.span[1] = 0u;
-        if (d.alpha && holes_small(d.holes, d.n_holes)) hole_fetch8(R, d.holes, d.n_holes, P.holes);
+        auto hole_at = [&](int h) { return d.hole(h); };
+        if (d.alpha() && holes_small(hole_at, d.n_holes())) hole_fetch8(R, hole_at, d.n_holes(), P.holes);
     }
+    static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) { prefetch_v(view_of(dp), R, P); }
     static __device__ __forceinline__ void recycle(const RasterCtx& R) { zero_mask(R); }
-    static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
-        const Desc MG_CONST_AS& d = *dp;
+    static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) { compose_v(view_of(dp), P, R); }
+    template <class V>
+    static __device__ __forceinline__ void compose_v(const V& d, const Pre& P, const RasterCtx& R) {
         const cptr<AtlasTables> T = R.T;
-        const uint32_t alpha = d.alpha;
+        const uint32_t alpha = d.alpha();
         const StampRegs<1>&agent = P.agent, &coin = P.coin, &exitp = P.exitp;
         uint32_t* const ring = ring_words<BORDER>();
+        auto hole_at = [&](int h) { return d.hole(h); };
+        const int n_holes = d.n_holes(), n_coins = d.n_coins();
         if (alpha) {  // the hole mask is zero on entry (recycle())
-            if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
-            else hole_mask(R, d.holes, d.n_holes);  // radii beyond the reference's range: span table read in place
-            if constexpr (BORDER) ring_mask(R, d.holes, d.n_holes, ring);
+            if (holes_small(hole_at, n_holes)) hole_apply8(R, P.holes);
+            else hole_mask(R, hole_at, n_holes);  // radii beyond the reference's range: span table read in place
+            if constexpr (BORDER) ring_mask(R, hole_at, n_holes, ring);
             __syncthreads();
         }
         templ_apply_dark(R, P.bg, alpha);
         __syncthreads();
         auto under_bar = [&](int X, int Y) { return Y < BAR_H && bar_covers(d, X); };
+        const uint32_t lf = d.coin_above();
+        const bool exit_here = d.exit_stamp() != 0xFF;
+        const int sx = d.sx(), sy = d.sy(), exit_x = d.exit_x(), exit_y = d.exit_y();
         if constexpr (BORDER) {  // the same layers, with the border pixels blended in where the spotlight layer sits
-            const uint32_t lfb = d.coin_above;
-            const bool exit_b = d.exit_stamp != 0xFF;
-            if (!(lfb & LAYER_COIN_ABOVE))
-                for (int k = 0; k < d.n_coins; ++k)
-                    stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, alpha, never_skip);
-            if (exit_b && !(lfb & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
+            if (!(lf & LAYER_COIN_ABOVE))
+                for (int k = 0; k < n_coins; ++k) stamp_apply_lit<1>(R, coin, d.coin_x(k), d.coin_y(k), alpha, never_skip);
+            if (exit_here && !(lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, exit_x, exit_y, alpha, never_skip);
             __syncthreads();
-            if (!(lfb & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, never_skip);
+            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, sx, sy, alpha, never_skip);
             __syncthreads();
             if (alpha) {
                 ring_apply(R, ring, alpha);
                 __syncthreads();
             }
-            if (lfb & LAYER_COIN_ABOVE)
-                for (int k = 0; k < d.n_coins; ++k)
-                    stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
-            if (exit_b && (lfb & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, 0u, under_bar);
+            if (lf & LAYER_COIN_ABOVE)
+                for (int k = 0; k < n_coins; ++k) stamp_apply_lit<1>(R, coin, d.coin_x(k), d.coin_y(k), 0u, under_bar);
+            if (exit_here && (lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, exit_x, exit_y, 0u, under_bar);
             bar_columns(d, T, R);
-            if (lfb & LAYER_AGENT_TOP) {
+            if (lf & LAYER_AGENT_TOP) {
                 __syncthreads();
-                stamp_apply_lit<1>(R, agent, d.sx, d.sy, 0u, never_skip);
+                stamp_apply_lit<1>(R, agent, sx, sy, 0u, never_skip);
             }
             return;
         }
         // coins keep their distance from each other and from the exit (sampler block radius): no overlap among them.
         // coins_visible / exit_visible / agent_visible move a layer from below the dark layer to above it (the agent:
         // to the very top, over the bar -- the reference's list.insert index is past the end of its surface list).
-        const uint32_t lf = d.coin_above;
-        const bool exit_here = d.exit_stamp != 0xFF;
         if (!(lf & LAYER_COIN_ABOVE))
-            for (int k = 0; k < d.n_coins; ++k)
-                stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, alpha, never_skip);
-        if (exit_here && !(lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, alpha, never_skip);
+            for (int k = 0; k < n_coins; ++k) stamp_apply_lit<1>(R, coin, d.coin_x(k), d.coin_y(k), alpha, never_skip);
+        if (exit_here && !(lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, exit_x, exit_y, alpha, never_skip);
         __syncthreads();
         if (!(lf & (LAYER_COIN_ABOVE | LAYER_EXIT_ABOVE))) {  // the bar follows without a barrier: leave its pixels alone
-            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, under_bar);
+            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, sx, sy, alpha, under_bar);
         } else {
-            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, d.sx, d.sy, alpha, never_skip);
+            if (!(lf & LAYER_AGENT_TOP)) stamp_apply_lit<1>(R, agent, sx, sy, alpha, never_skip);
             __syncthreads();
             if (lf & LAYER_COIN_ABOVE)
-                for (int k = 0; k < d.n_coins; ++k)
-                    stamp_apply_lit<1>(R, coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
-            if (exit_here && (lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, d.exit_x, d.exit_y, 0u, under_bar);
+                for (int k = 0; k < n_coins; ++k) stamp_apply_lit<1>(R, coin, d.coin_x(k), d.coin_y(k), 0u, under_bar);
+            if (exit_here && (lf & LAYER_EXIT_ABOVE)) stamp_apply_lit<1>(R, exitp, exit_x, exit_y, 0u, under_bar);
         }
         bar_columns(d, T, R);
         if (lf & LAYER_AGENT_TOP) {
             __syncthreads();
-            stamp_apply_lit<1>(R, agent, d.sx, d.sy, 0u, never_skip);
+            stamp_apply_lit<1>(R, agent, sx, sy, 0u, never_skip);
         }
     }
 };
@@ -311,13 +369,14 @@ struct SpotDebugComposerT {
     static __device__ __forceinline__ void prefetch(cptr<Desc> dp, const RasterCtx& R, Pre& P) { Obs::prefetch(dp, R, P); }
     static __device__ __forceinline__ void recycle(const RasterCtx& R) { zero_mask(R); }
     static __device__ __forceinline__ void compose(cptr<Desc> dp, const Pre& P, const RasterCtx& R) {
-        const Desc MG_CONST_AS& d = *dp;
-        const uint32_t alpha = d.alpha;
+        const SpotViewMem d = view_of(dp);
+        const uint32_t alpha = d.alpha();
         uint32_t* const ring = ring_words<BORDER>();
+        auto hole_at = [&](int h) { return d.hole(h); };
         if (alpha) {
-            if (holes_small(d.holes, d.n_holes)) hole_apply8(R, P.holes);
-            else hole_mask(R, d.holes, d.n_holes);
-            if constexpr (BORDER) ring_mask(R, d.holes, d.n_holes, ring);
+            if (holes_small(hole_at, d.n_holes())) hole_apply8(R, P.holes);
+            else hole_mask(R, hole_at, d.n_holes());
+            if constexpr (BORDER) ring_mask(R, hole_at, d.n_holes(), ring);
             __syncthreads();
         }
         templ_apply_dark(R, P.bg, alpha);
@@ -329,11 +388,10 @@ struct SpotDebugComposerT {
             }
         }
         auto under_bar = [&](int X, int Y) { return Y < BAR_H && Obs::bar_covers(d, X); };
-        if (d.exit_stamp != 0xFF) stamp_apply_lit<1>(R, P.exitp, d.exit_x, d.exit_y, 0u, under_bar);
-        for (int k = 0; k < d.n_coins; ++k)
-            stamp_apply_lit<1>(R, P.coin, (int)(d.coins[k] & 0xFFFF) - 128, (int)(d.coins[k] >> 16) - 128, 0u, under_bar);
+        if (d.exit_stamp() != 0xFF) stamp_apply_lit<1>(R, P.exitp, d.exit_x(), d.exit_y(), 0u, under_bar);
+        for (int k = 0; k < d.n_coins(); ++k) stamp_apply_lit<1>(R, P.coin, d.coin_x(k), d.coin_y(k), 0u, under_bar);
         __syncthreads();
-        stamp_apply_lit<1>(R, P.agent, d.sx, d.sy, 0u, under_bar);
+        stamp_apply_lit<1>(R, P.agent, d.sx(), d.sy(), 0u, under_bar);
         Obs::bar_columns(d, R.T, R);
     }
 };
@@ -676,8 +734,9 @@ __global__ __launch_bounds__(256) void spot_init_kernel(int n, SpotCore* core) {
     core[i] = s;
 }
 
-// the leader stores the descriptor's header + coin positions (first 64 bytes); hole words are written by the slot
+// the leader stores the descriptor's header + coin positions (words 0..5 and 8..15); hole words are written by the slot
 // lanes.  Packed field by field (the layout of the bit-fields above) so that `d` never has to exist in memory.
+template <bool COHERENT = false>  // COHERENT: agent-scope (write-through) stores, for readers inside the same launch
 __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d) {
     uint4* out = reinterpret_cast<uint4*>(dst);
     const uint32_t w0 = (uint32_t)d.valid | ((uint32_t)d.bg << 8) | ((uint32_t)d.sprite << 16) | ((uint32_t)d.alpha << 24);
@@ -686,8 +745,20 @@ __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d
     const uint32_t w3 = (uint32_t)d.c_base | ((uint32_t)d.c_act0 << 8) | ((uint32_t)d.c_act1 << 16) | ((uint32_t)d.c_bar << 24);
     const uint32_t w4 = (uint32_t)d.bar_x | ((uint32_t)d.bar_w << 8) | ((uint32_t)d.quarter << 16) | ((uint32_t)d.exit_stamp << 24);
     const uint32_t w5 = ((uint32_t)d.exit_x & 0xFFFFu) | ((uint32_t)d.exit_y << 16);
+    if constexpr (COHERENT) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(dst);
+        auto put = [&](int q, uint32_t lo, uint32_t hi) { __hip_atomic_store(o + q, (uint64_t)lo | ((uint64_t)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        put(0, w0, w1);
+        put(1, w2, w3);
+        put(2, w4, w5);
+        put(4, d.coins[0], d.coins[1]);
+        put(5, d.coins[2], d.coins[3]);
+        put(6, d.coins[4], d.coins[5]);
+        put(7, d.coins[6], d.coins[7]);
+        return;
+    }
     out[0] = make_uint4(w0, w1, w2, w3);
-    out[1] = make_uint4(w4, w5, 0u, 0u);
+    reinterpret_cast<uint2*>(dst)[2] = make_uint2(w4, w5);  // (w6 is holes[15], a slot lane's; w7 the one-launch step's epoch)
     out[2] = make_uint4(d.coins[0], d.coins[1], d.coins[2], d.coins[3]);
     out[3] = make_uint4(d.coins[4], d.coins[5], d.coins[6], d.coins[7]);
 }
@@ -718,27 +789,57 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     }
 }
 
-template <bool EN>
-__global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io, const int32_t* actions, float* reward_out,
-                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset, int defer) {
-    __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = gid >> 4, ls = gid & 15;
-    if (i >= P.n) return;
+// What a step needs besides the instance: ONE struct, the head of the kernel-argument segment of both step kernels.
+struct SpotStepArgs {
+    SpotParams P;
+    SpotIO io;
+    const int32_t* actions;
+    float* reward_out;
+    uint8_t* done_out;
+    float* gt;
+    mg_info_buffers info;
+    int autoreset, defer;
+};
+
+// The step of instance i as its 16 lanes execute it (lane ls owns spotlight slot ls).  FUSED (spot_step_raster_kernel): the
+// descriptor is handed to the frame waves of the SAME launch -- every word written with agent-scope (write-through) stores, the
+// two epoch words last (SpotDesc).  The body is written to need few registers at once, because in that launch it shares a
+// kernel with the raster (80 VGPRs at six workgroups per CU): the RNG stream is read where the first draw happens (spawns, coin
+// re-sampling and resets are rare), the slot record after the spawn, and a newborn spotlight is read back from memory.
+// CLAIM (a step workgroup's wave of that launch): the wave steps its four instances only if it is the first to exchange this step's
+// ticket into its claim word; the exchange is issued first and awaited together with the state record.
+template <bool EN, bool FUSED, bool CLAIM = false>
+__device__ __forceinline__ void spot_step_body(int i, int ls, const SpotStepArgs& a, int* disc_lds, uint32_t epoch, uint32_t* claim_word = nullptr,
+                                               uint32_t ticket = 0u) {
+    uint32_t claimed_by = 0u;
+    if constexpr (CLAIM) {
+        claimed_by = ticket + 1u;  // lanes other than the wave's first: any value but the ticket
+        // (the caller has dropped lanes with i >= n; the wave's first lane has its smallest i, so it is active whenever any lane is)
+        if ((threadIdx.x & 63) == 0) claimed_by = __hip_atomic_exchange(claim_word, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const SpotParams& P = a.P;
+    const SpotIO& io = a.io;
+    const int32_t* const actions = a.actions;
+    float* const reward_out = a.reward_out;
+    uint8_t* const done_out = a.done_out;
+    float* const gt = a.gt;
+    const mg_info_buffers& info = a.info;
+    const int autoreset = a.autoreset, defer = FUSED ? 0 : a.defer;
     const int group_shift = (threadIdx.x & 63) & 48;  // bit position of this instance's 16 lanes in a wave ballot
     const bool leader = ls == 0;
     SpotCore s = io.core[i];
+    if constexpr (CLAIM) {
+        asm volatile("" : "+v"(claimed_by));
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)claimed_by) == ticket) return;  // a frame wave has stepped this slot already
+    }
     Pcg g;
-    g.load(io.rng, i);
+    bool rng_loaded = false;
+    auto need_rng = [&]() {  // (all 16 lanes of the instance take the same branch: they hold the same state)
+        if (!rng_loaded) g.load(io.rng, i);
+        rng_loaded = true;
+    };
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
-    // lane ls looks after slot ls.  Its slot record is requested NOW, together with the core / RNG / action loads (one
-    // memory round trip for the whole step instead of core -> sp_done -> ballot -> slot fields in sequence); the
-    // addresses are valid whether or not the slot is in use.
-    const size_t k = (size_t)i * SLOTS + ls;
-    double p_t = io.sp_t[k], p_speed = io.sp_speed[k];
-    double p_sx = io.sp_sx[k], p_sy = io.sp_sy[k], p_tx = io.sp_tx[k], p_ty = io.sp_ty[k], p_ox = io.sp_ox[k], p_oy = io.sp_oy[k];
-    int p_r = io.sp_r[k];  // bit 7: has_border
-    bool p_done = io.sp_done[k] != 0;
+    const size_t k = (size_t)i * SLOTS + ls;  // lane ls looks after slot ls
 
     // CharacterController.step(action, walkable_rect = (0, 4, 84, 80))
     int a0 = actions[2 * i], a1 = actions[2 * i + 1];
@@ -767,26 +868,25 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     double reward = 0.0, r = 0.0;
     bool spot_done = false;
     s.spawn_timer++;
-    SlotRec born;
-    born.mine = false;
     if constexpr (EN) {
         if (__builtin_expect(s.spawn_timer >= P.spawn_interval, 0)) {
-            new_spot(P, io, i, ls, s, g, &born);
+            need_rng();
+            new_spot(P, io, i, ls, s, g);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
         if (__builtin_expect(s.spawn_timer >= P.interval0, 0)) {
-            new_spot(P, io, i, ls, s, g, &born);
+            need_rng();
+            new_spot(P, io, i, ls, s, g);
             s.n_intervals--;
             s.spawn_timer = 0;
         }
     }
-    if (born.mine) {  // spawned into my slot just now: the record this lane has just written
-        p_t = born.t; p_speed = born.speed;
-        p_sx = born.sx; p_sy = born.sy; p_tx = born.tx; p_ty = born.ty; p_ox = born.ox; p_oy = born.oy;
-        p_r = born.r;
-        p_done = born.done;
-    }
+    // the slot record, AFTER the spawn (a spotlight born into this lane's slot just now is read back: the lane wrote it itself)
+    double p_t = io.sp_t[k], p_speed = io.sp_speed[k];
+    double p_sx = io.sp_sx[k], p_sy = io.sp_sy[k], p_tx = io.sp_tx[k], p_ty = io.sp_ty[k], p_ox = io.sp_ox[k], p_oy = io.sp_oy[k];
+    int p_r = io.sp_r[k];  // bit 7: has_border
+    bool p_done = io.sp_done[k] != 0;
     const bool used = !((s.free_mask >> ls) & 1u);
     const bool my_done = used && p_done;
     const uint32_t done_mask = (uint32_t)(__ballot(my_done) >> group_shift) & 0xFFFFu;
@@ -829,7 +929,12 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
                 rank += (int)((processed >> slot) & 1u);
             }
         }
-        io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius) | ((uint32_t)(p_r >> 7) << 31);
+        {
+            uint32_t* const hw = reinterpret_cast<uint32_t*>(&io.desc[i]) + hole_word(rank);
+            const uint32_t hv = pack_hole((int)cx, (int)cy, radius) | ((uint32_t)(p_r >> 7) << 31);
+            if constexpr (FUSED) __hip_atomic_store(hw, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *hw = hv;
+        }
         t += p_speed;
         if (t >= 1.0) {
             t = 1.0;
@@ -870,6 +975,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
                 s.coins_collected++;
                 s.coin_t = 0;
                 // _spawn_coin: sampler reset, previous coin blocked with r = 28
+                need_rng();
                 Discs D;
                 D.p = disc_slot(disc_lds);
                 D.n = 0;
@@ -966,6 +1072,7 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
     const bool reset_me = done && autoreset;
     if (defer && reset_me && leader) queue_push(io.queue, &io.qctr[SQ_COUNT], P.n, i, io.err);
     if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
+        need_rng();
         spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds));
     } else {
         d.bg = bg_template(s.pad, s.bg_red);
@@ -1009,9 +1116,116 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotParams P, SpotIO io,
         }
     }
     if (leader) {
-        g.store(io.rng, i);
+        if (rng_loaded) g.store(io.rng, i);
         io.core[i] = s;
-        store_desc_head(&io.desc[i], d);
+        store_desc_head<FUSED>(&io.desc[i], d);
+    }
+    if constexpr (FUSED) {
+        // every word of the descriptor (this wave's hole and head stores) has reached the coherence point before the epochs leave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (leader) {
+            uint32_t* const dw = reinterpret_cast<uint32_t*>(&io.desc[i]);
+            __hip_atomic_store(dw + DW_EPOCH_A, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dw + DW_EPOCH_B, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <bool EN>
+__global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
+    __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid >> 4, ls = gid & 15;
+    if (i < a.P.n) spot_step_body<EN, false, false>(i, ls, a, disc_lds, 0u);
+}
+
+// ONE launch per step (uint8 observations; round 4).  Like the mortar family's (mg_mortar.hip mortar_step_raster_kernel): the
+// first `logic_wgs` workgroups run the step -- sixteen lanes per instance, resets included: their 30-us tail now runs beside the
+// frames of the other instances instead of in front of all of them -- every other workgroup is one of the raster's persistent
+// workgroups and waits, per frame, for the descriptor a step wave of the SAME launch publishes (both epoch words of the
+// 128-byte record, SpotDesc).  The two kernels it replaces sat one behind the other: the step kernel 17-21 us (its slowest wave)
+// + a launch gap + the raster 58-61 us.  The step's code needs more registers than the raster's (123 as it stood; written for
+// the purpose, spot_step_body: 80 without scratch), so this launch runs six workgroups per CU where the raster alone runs seven.
+// A frame wave reads its descriptor with ONE vector load (lane k <- word k, agent scope: past the caches) and picks the fields
+// with v_readlane (SpotViewReg): scalars, like the scalar loads of the two-launch raster; the NEXT frame's descriptor is
+// requested together with this frame's template and stamps, so that only a workgroup's first frame pays a round trip for it.
+// Liveness does not rest on dispatch order: claim words per wave-slot (four instances), a frame wave that has polled
+// SPOT_RESCUE_AFTER_POLLS times steps the slot itself if nobody has claimed it (see the mortar kernel for the argument).
+constexpr int SPOT_FUSED_OCC = 6;
+constexpr int SPOT_FUSED_DISC_OFF = (RASTER_LDS + 15) / 16 * 16;  // the step's disc lists: behind the frame and the hole mask
+constexpr int SPOT_FUSED_LDS = 25 * 1024;                         // six workgroups per CU
+static_assert(SPOT_FUSED_DISC_OFF + (256 / 16) * DISC_INTS * 4 <= SPOT_FUSED_LDS, "disc lists fit into the one-launch step's LDS request");
+constexpr int SPOT_RESCUE_AFTER_POLLS = 48;
+#define MG_KERNARG_AS __attribute__((address_space(4)))
+template <bool EN, bool BORDER, bool NT>
+__global__ __launch_bounds__(256, SPOT_FUSED_OCC) void spot_step_raster_kernel(SpotStepArgs a, int logic_wgs, int logic_base, uint32_t epoch,
+                                                                               uint32_t ticket, uint32_t* claims, uint32_t* rescues, RasterAtlas A,
+                                                                               void* __restrict__ obs) {
+    typedef SpotComposerT<BORDER> Composer;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rel = (int)blockIdx.x - logic_base;
+    const int n = a.P.n;
+    int* const disc_lds = reinterpret_cast<int*>(smem + SPOT_FUSED_DISC_OFF);
+    if (rel >= 0 && rel < logic_wgs) {  // a step workgroup: 16 instances, wave w steps slot 4 rel + w unless a frame wave got there first
+        const int i = rel * 16 + (tid >> 4);
+        if (i < n) spot_step_body<EN, true, true>(i, tid & 15, a, disc_lds, epoch, claims + rel * 4 + (tid >> 6), ticket);
+        return;
+    }
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = as_const(A.tables);
+    R.tid = tid;
+    Composer::recycle(R);
+    __syncthreads();
+    const int stride = (int)gridDim.x - logic_wgs;
+    const uint32_t* const words = reinterpret_cast<const uint32_t*>(a.io.desc);
+    auto fetch = [&](int e) -> uint32_t {  // lanes 0..31 (and 32..63 again) <- words 0..31 of descriptor e
+        return __hip_atomic_load(words + (size_t)e * DESC_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    int env = (int)blockIdx.x < logic_base ? (int)blockIdx.x : (int)blockIdx.x - logic_wgs;
+    uint32_t v = env < n ? fetch(env) : 0u;
+    for (; env < n; env += stride) {
+        bool tried = false;
+        for (int polls = 0;; ++polls) {  // (readlane results are scalars: the wait loop's control is scalar)
+            const DescWordsReg dr{v};
+            if (dr.w(DW_EPOCH_A) == epoch && dr.w(DW_EPOCH_B) == epoch) break;
+            if (polls >= SPOT_RESCUE_AFTER_POLLS && !tried) {
+                tried = true;  // (a lost claim is not retried: its owner is running)
+                uint32_t old = 0u;
+                if (lane == 0) old = __hip_atomic_exchange(claims + (env >> 2), ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ticket) {
+                    // rare: step the four instances around this frame here (arguments re-read through an opaque pointer to the
+                    // kernel-argument segment, see mortar_step_raster_kernel), then poll again
+                    const SpotStepArgs MG_KERNARG_AS* ka = (const SpotStepArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ka));
+                    int i = (env >> 2) * 4 + (lane >> 4);
+                    asm volatile("" : "+v"(i));
+                    if (i < n) spot_step_body<EN, true, false>(i, lane & 15, *(const SpotStepArgs*)ka, disc_lds, epoch);
+                    if (lane == 0) atomicAdd(rescues, 1u);
+                }
+            }
+            __builtin_amdgcn_s_sleep(4);
+            v = fetch(env);
+        }
+        const SpotViewReg d{DescWordsReg{v}};
+        const int next = env + stride;
+        const uint32_t vn = next < n ? fetch(next) : 0u;  // leaves with this frame's loads
+        if (d.valid() == 1u) {
+            int t = tid;
+            asm volatile("" : "+v"(t));  // (the lane's frame offsets are derived inside the iteration, not kept across the step code above)
+            R.tid = t;
+            typename Composer::Pre P;
+            Composer::prefetch_v(d, R, P);
+            Composer::compose_v(d, P, R);
+            __syncthreads();
+            Composer::recycle(R);
+            store_frame<MG_OBS_U8_XYC, NT, true>(smem, obs, env, t);
+            __syncthreads();
+        }
+        v = vn;
     }
 }
 
@@ -1273,8 +1487,9 @@ class SpotFamily : public Family {
         prof.begin(0, s);
         const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets()) ? 1 : 0;
         const int sb = step_block(256);
-        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
-        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset, defer);
+        const SpotStepArgs sa{P_, io(), actions, reward, done, gt, ib, autoreset, defer};
+        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, sa);
+        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, sa);
         end_logic(s);
         prof.begin(1, s);
         if (defer) {
@@ -1383,14 +1598,14 @@ class SpotFamily : public Family {
     // non-temporal stream keeps up; MEMGYM_RASTER_NT forces (tuning only)
     bool fused_nt() const {
         static const int forced = [] {
-            const char* e = getenv("MEMGYM_RASTER_NT");
+            const char* e = lab_env("MEMGYM_RASTER_NT");
             return e ? (atoi(e) != 0 ? 1 : 0) : -1;
         }();
         return forced >= 0 ? forced != 0 : true;
     }
     bool fuse_resets() const {
         static const int forced = [] {
-            const char* e = getenv("MEMGYM_SPOT_FUSE");
+            const char* e = lab_env("MEMGYM_SPOT_FUSE");
             return e ? (atoi(e) != 0 ? 1 : 0) : -1;
         }();
         return forced >= 0 ? forced != 0 : (!P_.endless && n_ <= FUSE_MAX);

@@ -72,6 +72,8 @@ def _load():
     L.mg_obs_debug_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.mg_enable_peer_access.argtypes = [C.c_int, C.c_int]
     L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    if hasattr(L, "mg_debug_counter"):  # (absent from builds of earlier rounds that tools/ A/B against through MEMGYM_HIP_LIB)
+        L.mg_debug_counter.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     return L
 
 

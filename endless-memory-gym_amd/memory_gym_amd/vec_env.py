@@ -353,8 +353,7 @@ class VecMemoryGym:
                   4: "endless path longer than 128 segments", 8: "more than 128 distinct fall-off cells",
                   16: "past-path window wider than 16 columns",
                   32: "Endless Mortar Mayhem command list reached its 512-entry capacity (the episode was ended)",
-                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)",
-                  128: "one-launch step: a frame workgroup gave up waiting for its descriptor (set MEMGYM_MORTAR_FUSE=0)"}
+                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)"}
 
     def check_errors(self):
         """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device).
@@ -370,6 +369,12 @@ class VecMemoryGym:
         w = np.zeros(6, np.uint64)
         _native.check(_native.LIB.mg_debug_rng(self._h, int(i), w.ctypes.data), "mg_debug_rng")
         return w
+
+    def debug_counter(self, name):
+        """Named test / telemetry counter of the handle (include/memgym.h: mg_debug_counter), e.g. "one_launch_rescues"."""
+        v = C.c_int64()
+        _native.check(_native.LIB.mg_debug_counter(self._h, name.encode(), C.byref(v)), "mg_debug_counter")
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):

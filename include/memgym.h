@@ -169,9 +169,9 @@ int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
  *      endless_mortar_mayhem.py:316-318); the episode of that instance was ended
  *  64  a deferred-reset queue was found over-full (an earlier fused launch failed before draining it); the excess
  *      entries were dropped
- * 128  mortar family, one-launch step: a frame workgroup gave up waiting (~50 ms) for the descriptor the step's workgroups of
- *      the same launch publish -- workgroups were not dispatched in index order; that frame shows the previous step.
- *      MEMGYM_MORTAR_FUSE=0 selects the two-launch form */
+ * 128  reserved (rounds <= 3: a frame workgroup of the mortar family's one-launch step gave up waiting for its descriptor.
+ *      Since round 4 that launch cannot time out -- a frame wave that waits too long steps the instances itself,
+ *      mg_mortar.hip mortar_step_raster_kernel -- and the bit is never raised) */
 int mg_poll_errors(mg_env* env, int* flags);
 
 /* The same bits as they stand right now: no synchronisation, nothing cleared.  The error word lives in pinned host
@@ -221,6 +221,11 @@ int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* rese
  * hipDeviceCanAccessPeer(device, peer_device) and switches peer access on for `device`.  0 = the kernels of a handle on
  * `device` may be given pointers into `peer_device`'s memory; -1 = no peer access (fall back to a gather). */
 int mg_enable_peer_access(int device, int peer_device);
+
+/* Test / telemetry hook: named counters of a handle.  "one_launch_rescues" (mortar family): 64-instance slots of the one-launch
+ * step that a frame wave stepped itself because the step workgroup's wave had not claimed them in time (0 on a GPU that
+ * dispatches the step workgroups first; tests/test_gpu_one_launch.py forces the other order).  Unknown name: -1.  Synchronous. */
+int mg_debug_counter(mg_env* env, const char* name, int64_t* value);
 
 /* Test hook: copy the numpy-compatible PCG64 words of instance i to host:
  * out[6] = {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}.  Synchronous. */

@@ -11,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAB_LIB = os.path.join(ROOT, "endless-memory-gym_amd", "lib", "lab", "libmemgym_hip_lab.so")  # the hook exists in the -DMG_LAB build only (csrc/mg_lab.hpp)
 
 WORKER = r'''
 import os, sys
@@ -49,5 +50,5 @@ print("OVERFLOW_FLAGGED at step", raised[0])
 
 
 def test_endless_mortar_mayhem_command_list_capacity_is_flagged():
-    out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=dict(os.environ, MEMGYM_EMM_CMD_CAP="5"), capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=dict(os.environ, MEMGYM_EMM_CMD_CAP="5", MEMGYM_HIP_LIB=LAB_LIB), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OVERFLOW_FLAGGED" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

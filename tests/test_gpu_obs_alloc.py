@@ -13,6 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAB_LIB = os.path.join(ROOT, "endless-memory-gym_amd", "lib", "lab", "libmemgym_hip_lab.so")  # the hook exists in the -DMG_LAB build only (csrc/mg_lab.hpp)
 
 
 def _stats():
@@ -104,5 +105,5 @@ print("NO_VMM_OK")
 
 
 def test_runtime_without_the_virtual_memory_api_gets_a_plain_buffer():
-    out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=dict(os.environ, MEMGYM_OBS_NO_VMM="1"), capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=dict(os.environ, MEMGYM_OBS_NO_VMM="1", MEMGYM_HIP_LIB=LAB_LIB), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "NO_VMM_OK" in out.stdout, out.stderr[-2000:]

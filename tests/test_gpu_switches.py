@@ -1,6 +1,7 @@
 """The A/B switches of the library select whole launch arrangements (resets / path generation inside
 the raster launch or not, full resets by lanes or by waves).  The defaults are what the rest of the suite runs; this runs
-a lock-step parity check (HIP vs oracle, every frame) under the OTHER setting of each switch, in fresh processes."""
+a lock-step parity check (HIP vs oracle, every frame) under the OTHER setting of each switch, in fresh processes.
+The shipped library reads no switch (csrc/mg_lab.hpp); the workers load the -DMG_LAB build of the same sources."""
 import os
 import subprocess
 import sys
@@ -10,6 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+LAB_LIB = os.path.join(os.path.dirname(HERE), "endless-memory-gym_amd", "lib", "lab", "libmemgym_hip_lab.so")
 
 CASES = [
     ("MEMGYM_EMP_FUSE", "0", "Endless-MysteryPath-v0", 160, 150),          # queue server as a launch of its own
@@ -20,12 +22,13 @@ CASES = [
     ("MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 200),            # ... and not, for the finite variant
     ("MEMGYM_MORTAR_FUSE", "0", "MortarMayhem-Grid-v0", 300, 150),          # step and raster as two launches
     ("MEMGYM_MORTAR_FUSE", "0", "Endless-MortarMayhem-v0", 300, 150),
+    ("MEMGYM_LAB_NONE", "1", "MortarMayhem-Grid-v0", 300, 60),             # the lab build itself, no switch set
 ]
 
 
 @pytest.mark.parametrize("var,value,env_id,n,steps", CASES)
 def test_other_setting_is_bit_exact_too(var, value, env_id, n, steps):
-    env = dict(os.environ)
+    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB)
     env[var] = value
     r = subprocess.run([sys.executable, os.path.join(HERE, "switch_worker.py"), env_id, str(n), str(steps)], env=env,
                        capture_output=True, text=True, timeout=600)
