@@ -445,7 +445,15 @@ struct Discs {
     }
 };
 // the slot of the calling lane's group inside an array of (workgroup size / 16) * DISC_INTS ints
-__device__ __forceinline__ int* disc_slot(int* lds) { return lds + (threadIdx.x >> 4) * DISC_INTS; }
+__device__ __forceinline__ int* disc_slot(int* lds, int grp) { return lds + grp * DISC_INTS; }
+// Where a lane sits: its slot id, the group (= instance) of 16 lanes it belongs to within the workgroup, and that group's bit
+// position in a wave ballot.  Handed down instead of being derived from threadIdx in place: inside the one-launch step's loop
+// (spot_step_raster_kernel) everything derived from threadIdx is a loop invariant that the compiler keeps in a register for the
+// whole kernel -- twenty of them, in a kernel without a register to spare; that kernel derives the context from an opaque copy.
+struct LaneCtx {
+    int ls, grp, gshift;
+};
+__device__ __forceinline__ LaneCtx lane_ctx(int tix) { return LaneCtx{tix & 15, tix >> 4, ((tix >> 4) & 3) * 16}; }
 __device__ __forceinline__ u128m row_mask(const Discs& D, int y) {
     u128m m = 0;
     for (int d = 0; d < D.n; ++d) {
@@ -470,7 +478,8 @@ __device__ __forceinline__ int popc128(u128m m) { return __popcll((unsigned long
 // instance re-spawned its coin).
 constexpr int ROWS_PER_LANE = 6;
 static_assert(ROWS_PER_LANE * 14 == SCREEN, "14 lanes x 6 rows cover the sampler grid");
-__device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, int ls, int* ox, int* oy) {
+__device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx& L, int* ox, int* oy) {
+    const int ls = L.ls;
     if (D.n == 0) {  // empty mask: cell k itself
         int k = g.integers(0, SCREEN * SCREEN);
         *oy = k / SCREEN;
@@ -519,7 +528,7 @@ __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, int ls, int* 
             kk -= fr;
         }
     }
-    const int owner = __ffs((unsigned)(__ballot(fx >= 0) >> ((threadIdx.x & 63) & 48)) & 0xFFFFu) - 1;
+    const int owner = __ffs((unsigned)(__ballot(fx >= 0) >> L.gshift) & 0xFFFFu) - 1;
     *ox = __shfl(fx, owner, 16);
     *oy = __shfl(fy, owner, 16);
     return free_total;
@@ -607,8 +616,9 @@ __device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore&
 // the first frame of an episode shows the holes of the last frame drawn before it; they only show when the alpha is not
 // 0 at reset, i.e. with light_dim_off_duration == 0.  The hole words themselves are still in the descriptor.
 template <bool EN>
-__device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
+__device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, const LaneCtx& L, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
                                            int stale_holes, int* slot) {  // slot: disc_slot() of the calling kernel's LDS array
+    const int ls = L.ls;
     s.t = 0;
     s.coin_t = 0;
     s.ep_sum = 0.0;
@@ -665,7 +675,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         s.num_coins = nc;
         for (int k = 0; k < nc && k < MAX_COINS; ++k) {  // deliberately not unrolled (code size)
             int cx, cy;
-            sample_cell(g, D, ls, &cx, &cy);
+            sample_cell(g, D, L, &cx, &cy);
             D.push(cx, cy, 21);
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
@@ -676,7 +686,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
             s.n_coins++;
         }
         int ex, ey;
-        sample_cell(g, D, ls, &ex, &ey);
+        sample_cell(g, D, L, &ex, &ey);
         ex += g.integers(2, 4);
         ey += g.integers(2, 4);
         clamp_spawn(P, ex, ey);
@@ -745,16 +755,17 @@ __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d
     const uint32_t w3 = (uint32_t)d.c_base | ((uint32_t)d.c_act0 << 8) | ((uint32_t)d.c_act1 << 16) | ((uint32_t)d.c_bar << 24);
     const uint32_t w4 = (uint32_t)d.bar_x | ((uint32_t)d.bar_w << 8) | ((uint32_t)d.quarter << 16) | ((uint32_t)d.exit_stamp << 24);
     const uint32_t w5 = ((uint32_t)d.exit_x & 0xFFFFu) | ((uint32_t)d.exit_y << 16);
-    if constexpr (COHERENT) {
-        uint64_t* o = reinterpret_cast<uint64_t*>(dst);
-        auto put = [&](int q, uint32_t lo, uint32_t hi) { __hip_atomic_store(o + q, (uint64_t)lo | ((uint64_t)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        put(0, w0, w1);
-        put(1, w2, w3);
-        put(2, w4, w5);
-        put(4, d.coins[0], d.coins[1]);
-        put(5, d.coins[2], d.coins[3]);
-        put(6, d.coins[4], d.coins[5]);
-        put(7, d.coins[6], d.coins[7]);
+    if constexpr (COHERENT) {  // (dword stores: 64-bit ones need aligned register pairs, which cost this tight kernel its last free registers)
+        uint32_t* o = reinterpret_cast<uint32_t*>(dst);
+        auto put = [&](int q, uint32_t w) { __hip_atomic_store(o + q, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        put(0, w0);
+        put(1, w1);
+        put(2, w2);
+        put(3, w3);
+        put(4, w4);
+        put(5, w5);
+#pragma unroll
+        for (int c = 0; c < MAX_COINS; ++c) put(DW_COINS + c, d.coins[c]);
         return;
     }
     out[0] = make_uint4(w0, w1, w2, w3);
@@ -781,7 +792,8 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io
     SpotCore s = io.core[i];
     SpotDesc d;
     const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);  // n_holes of the frame drawn last
-    spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds));
+    const LaneCtx L = lane_ctx((int)threadIdx.x);
+    spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds, L.grp));
     if (ls == 0) {
         io.core[i] = s;
         g.store(io.rng, i);
@@ -806,16 +818,18 @@ struct SpotStepArgs {
 // two epoch words last (SpotDesc).  The body is written to need few registers at once, because in that launch it shares a
 // kernel with the raster (80 VGPRs at six workgroups per CU): the RNG stream is read where the first draw happens (spawns, coin
 // re-sampling and resets are rare), the slot record after the spawn, and a newborn spotlight is read back from memory.
-// CLAIM (a step workgroup's wave of that launch): the wave steps its four instances only if it is the first to exchange this step's
-// ticket into its claim word; the exchange is issued first and awaited together with the state record.
+// CLAIM with a claim word (a step workgroup's wave of that launch): the wave steps its four instances only if it is the first to
+// exchange this step's ticket into the word; the exchange is issued first and awaited together with the state record.  Without
+// a word (a frame wave that has won the claim already) the step is unconditional.
 template <bool EN, bool FUSED, bool CLAIM = false>
-__device__ __forceinline__ void spot_step_body(int i, int ls, const SpotStepArgs& a, int* disc_lds, uint32_t epoch, uint32_t* claim_word = nullptr,
-                                               uint32_t ticket = 0u) {
+__device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const SpotStepArgs& a, int* disc_lds, SpotCore* core_lds, uint32_t epoch,
+                                               uint32_t* claim_word = nullptr, uint32_t ticket = 0u) {
+    const int ls = L.ls;
     uint32_t claimed_by = 0u;
     if constexpr (CLAIM) {
         claimed_by = ticket + 1u;  // lanes other than the wave's first: any value but the ticket
         // (the caller has dropped lanes with i >= n; the wave's first lane has its smallest i, so it is active whenever any lane is)
-        if ((threadIdx.x & 63) == 0) claimed_by = __hip_atomic_exchange(claim_word, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (claim_word && (L.ls | L.gshift) == 0) claimed_by = __hip_atomic_exchange(claim_word, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const SpotParams& P = a.P;
     const SpotIO& io = a.io;
@@ -825,9 +839,13 @@ __device__ __forceinline__ void spot_step_body(int i, int ls, const SpotStepArgs
     float* const gt = a.gt;
     const mg_info_buffers& info = a.info;
     const int autoreset = a.autoreset, defer = FUSED ? 0 : a.defer;
-    const int group_shift = (threadIdx.x & 63) & 48;  // bit position of this instance's 16 lanes in a wave ballot
+    const int group_shift = L.gshift;  // bit position of this instance's 16 lanes in a wave ballot
     const bool leader = ls == 0;
-    SpotCore s = io.core[i];
+    // The instance's core record lives in LDS for the length of the step (its 16 lanes write the same values to the same words):
+    // twenty registers less at every point of a kernel that has to share its register budget with the raster (round 4:
+    // 89 -> 65-73 VGPRs for this body), for a handful of LDS round trips on its critical path.
+    SpotCore& s = core_lds[L.grp];
+    s = io.core[i];
     if constexpr (CLAIM) {
         asm volatile("" : "+v"(claimed_by));
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)claimed_by) == ticket) return;  // a frame wave has stepped this slot already
@@ -977,11 +995,11 @@ __device__ __forceinline__ void spot_step_body(int i, int ls, const SpotStepArgs
                 // _spawn_coin: sampler reset, previous coin blocked with r = 28
                 need_rng();
                 Discs D;
-                D.p = disc_slot(disc_lds);
+                D.p = disc_slot(disc_lds, L.grp);
                 D.n = 0;
                 D.push(s.coin_x, s.coin_y, 28);
                 int cx, cy;
-                sample_cell(g, D, ls, &cx, &cy);
+                sample_cell(g, D, L, &cx, &cy);
                 cx += g.integers(2, 4);
                 cy += g.integers(2, 4);
                 clamp_spawn(P, cx, cy);
@@ -1073,7 +1091,7 @@ __device__ __forceinline__ void spot_step_body(int i, int ls, const SpotStepArgs
     if (defer && reset_me && leader) queue_push(io.queue, &io.qctr[SQ_COUNT], P.n, i, io.err);
     if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
         need_rng();
-        spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds));
+        spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds, L.grp));
     } else {
         d.bg = bg_template(s.pad, s.bg_red);
         d.sprite = s.rot8;
@@ -1131,12 +1149,16 @@ __device__ __forceinline__ void spot_step_body(int i, int ls, const SpotStepArgs
     }
 }
 
+#ifndef MG_SPOT_OCC
+#define MG_SPOT_OCC 1
+#endif
 template <bool EN>
-__global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
+__global__ __launch_bounds__(256, MG_SPOT_OCC) void spot_step_kernel(SpotStepArgs a) {
     __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
+    __shared__ SpotCore core_lds[256 / 16];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gid >> 4, ls = gid & 15;
-    if (i < a.P.n) spot_step_body<EN, false, false>(i, ls, a, disc_lds, 0u);
+    const int i = gid >> 4;
+    if (i < a.P.n) spot_step_body<EN, false, false>(i, lane_ctx((int)threadIdx.x), a, disc_lds, core_lds, 0u);
 }
 
 // ONE launch per step (uint8 observations; round 4).  Like the mortar family's (mg_mortar.hip mortar_step_raster_kernel): the
@@ -1150,82 +1172,145 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
 // with v_readlane (SpotViewReg): scalars, like the scalar loads of the two-launch raster; the NEXT frame's descriptor is
 // requested together with this frame's template and stamps, so that only a workgroup's first frame pays a round trip for it.
 // Liveness does not rest on dispatch order: claim words per wave-slot (four instances), a frame wave that has polled
-// SPOT_RESCUE_AFTER_POLLS times steps the slot itself if nobody has claimed it (see the mortar kernel for the argument).
-constexpr int SPOT_FUSED_OCC = 6;
-constexpr int SPOT_FUSED_DISC_OFF = (RASTER_LDS + 15) / 16 * 16;  // the step's disc lists: behind the frame and the hole mask
-constexpr int SPOT_FUSED_LDS = 25 * 1024;                         // six workgroups per CU
-static_assert(SPOT_FUSED_DISC_OFF + (256 / 16) * DISC_INTS * 4 <= SPOT_FUSED_LDS, "disc lists fit into the one-launch step's LDS request");
-constexpr int SPOT_RESCUE_AFTER_POLLS = 48;
+// 200 us steps the slot itself if nobody has claimed it (see the mortar kernel for the argument).
+// LDS: a step workgroup keeps the disc lists and core records of its 16 instances where a frame workgroup keeps its frame.  A
+// frame workgroup needs room for FOUR instances behind the frame and the hole mask: its four waves wait for the same frame, so at
+// most one of them wins that frame's claim and steps a wave-slot at a time.
+constexpr int SPOT_STEP_LDS_PER_INSTANCE = DISC_INTS * 4 + (int)sizeof(SpotCore);
+constexpr int SPOT_FUSED_RESCUE_OFF = (RASTER_LDS + 15) / 16 * 16;
+constexpr int SPOT_FUSED_LDS = SPOT_FUSED_RESCUE_OFF + 4 * SPOT_STEP_LDS_PER_INSTANCE;
+static_assert(16 * SPOT_STEP_LDS_PER_INSTANCE <= RASTER_LDS && SPOT_FUSED_LDS % 16 == 0 && SPOT_FUSED_LDS * 7 <= 160 * 1024, "seven workgroups of the one-launch step per CU");
+// Workgroups per CU: the endless variant's kernel needs 72 VGPRs (seven), the finite one's 80 (six: its reset places up to ten objects).
+// Both only without LLVM's machine-level loop-invariant code motion (this file is compiled with -mllvm -disable-machine-licm,
+// __graft_entry__.py): it hoisted a dozen constants and lane offsets of the step's code out of the kernel's loop and held them in
+// registers across the raster's code, 12-36 B of scratch per lane at 80 VGPRs.
+template <bool EN>
+constexpr int spot_fused_occ() { return EN ? 7 : 6; }
+constexpr unsigned long long SPOT_RESCUE_AFTER_TICKS = 20000;  // 200 us on the 100-MHz real-time clock (see RESCUE_AFTER_TICKS, mg_mortar.hip)
 #define MG_KERNARG_AS __attribute__((address_space(4)))
+// ALL arguments of the launch in one struct = the kernel-argument segment: every iteration of the kernel's loop reads what it needs
+// from the segment through a pointer the compiler cannot see through.  Passed and used the ordinary way, ~50 scalar and ~20
+// vector registers of loop invariants (pointers, the epoch, strides, lane offsets) stayed live across the step's code in the
+// middle of the loop, which needs every register the kernel has: 80 B of scratch per lane, paid at every wave launch.
+struct SpotFusedArgs {
+    SpotStepArgs step;
+    int logic_wgs, logic_base;
+    uint32_t epoch, ticket;
+    uint32_t* claims;
+    uint32_t* rescues;
+    RasterAtlas A;
+    void* obs;
+};
+#ifdef MG_LAB_SPOT_CLOCK  // measurement builds only (tools/spot_timeline.py): four stamps per workgroup, constant-rate clock (10 ns)
+static __device__ unsigned long long g_lab_spot_clock[4 * 16384];
+#define SPOT_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_spot_clock[4 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define SPOT_CLOCK(slot) do { } while (0)
+#endif
 template <bool EN, bool BORDER, bool NT>
-__global__ __launch_bounds__(256, SPOT_FUSED_OCC) void spot_step_raster_kernel(SpotStepArgs a, int logic_wgs, int logic_base, uint32_t epoch,
-                                                                               uint32_t ticket, uint32_t* claims, uint32_t* rescues, RasterAtlas A,
-                                                                               void* __restrict__ obs) {
+__global__ __launch_bounds__(256, spot_fused_occ<EN>()) void spot_step_raster_kernel(SpotFusedArgs args) {
     typedef SpotComposerT<BORDER> Composer;
+    SPOT_CLOCK(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int rel = (int)blockIdx.x - logic_base;
-    const int n = a.P.n;
-    int* const disc_lds = reinterpret_cast<int*>(smem + SPOT_FUSED_DISC_OFF);
-    if (rel >= 0 && rel < logic_wgs) {  // a step workgroup: 16 instances, wave w steps slot 4 rel + w unless a frame wave got there first
-        const int i = rel * 16 + (tid >> 4);
-        if (i < n) spot_step_body<EN, true, true>(i, tid & 15, a, disc_lds, epoch, claims + rel * 4 + (tid >> 6), ticket);
-        return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool is_logic = (int)blockIdx.x >= args.logic_base && (int)blockIdx.x < args.logic_base + args.logic_wgs;
+    // the wave-slot (four instances) this wave steps next: a step workgroup's wave starts with its own; a frame wave gets one only
+    // by winning a claim below
+    int slot = is_logic ? ((int)blockIdx.x - args.logic_base) * 4 + wave : -1;
+    int env = is_logic ? args.step.P.n : ((int)blockIdx.x < args.logic_base ? (int)blockIdx.x : (int)blockIdx.x - args.logic_wgs);
+    if (!is_logic) {
+        RasterCtx R0;
+        R0.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+        R0.tid = threadIdx.x;
+        Composer::recycle(R0);
+        __syncthreads();
     }
-    RasterCtx R;
-    R.frame = smem;
-    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
-    R.A = A;
-    R.T = as_const(A.tables);
-    R.tid = tid;
-    Composer::recycle(R);
-    __syncthreads();
-    const int stride = (int)gridDim.x - logic_wgs;
-    const uint32_t* const words = reinterpret_cast<const uint32_t*>(a.io.desc);
-    auto fetch = [&](int e) -> uint32_t {  // lanes 0..31 (and 32..63 again) <- words 0..31 of descriptor e
-        return __hip_atomic_load(words + (size_t)e * DESC_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    int env = (int)blockIdx.x < logic_base ? (int)blockIdx.x : (int)blockIdx.x - logic_wgs;
-    uint32_t v = env < n ? fetch(env) : 0u;
-    for (; env < n; env += stride) {
+    uint32_t v = 0u;
+    bool have = false;  // v holds (a snapshot of) descriptor `env`
+    for (;;) {
+        const SpotFusedArgs MG_KERNARG_AS* ka = (const SpotFusedArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));  // (opaque per iteration: nothing derived from it is kept across the step code, see LaneCtx)
+        const int n = ka->step.P.n;
+        if (slot >= 0) {  // ONE copy of the step's code for both kinds of wave
+            int i = slot * 4 + (lane >> 4);
+            asm volatile("" : "+v"(i));
+            bool mine = true;  // (a frame wave has won the claim already)
+            if (is_logic) {    // a step wave steps its slot unless a frame wave got there first
+                uint32_t old = 0u;
+                if (lane == 0) old = __hip_atomic_exchange(ka->claims + slot, ka->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ka->ticket;
+            }
+            // (group index within the LDS area: a step workgroup's 16 instances in the frame area, a frame wave's four behind it)
+            uint8_t* const area = is_logic ? smem : smem + SPOT_FUSED_RESCUE_OFF;
+            const int groups = is_logic ? 16 : 4;
+            const LaneCtx L{lane & 15, (is_logic ? wave * 4 : 0) + (lane >> 4), (lane >> 4) * 16};
+            if (mine && i < n)
+                spot_step_body<EN, true, false>(i, L, *(const SpotStepArgs*)&ka->step, reinterpret_cast<int*>(area),
+                                                reinterpret_cast<SpotCore*>(area + groups * DISC_INTS * 4), ka->epoch);
+            SPOT_CLOCK(is_logic ? 3 : 2);
+            if (is_logic) return;
+            if (lane == 0) atomicAdd(ka->rescues, 1u);
+            slot = -1;
+            have = false;
+            continue;
+        }
+        if (env >= n) return;
+        const uint32_t epoch = ka->epoch;
+        const int stride = (int)gridDim.x - ka->logic_wgs;
+        const uint32_t* const words = reinterpret_cast<const uint32_t*>(ka->step.io.desc);
+        auto fetch = [&](int e) -> uint32_t {  // lanes 0..31 (and 32..63 again) <- words 0..31 of descriptor e
+            return __hip_atomic_load(words + (size_t)e * DESC_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (!have) v = fetch(env);
+        have = true;
         bool tried = false;
+        unsigned long long t0 = 0;
         for (int polls = 0;; ++polls) {  // (readlane results are scalars: the wait loop's control is scalar)
             const DescWordsReg dr{v};
             if (dr.w(DW_EPOCH_A) == epoch && dr.w(DW_EPOCH_B) == epoch) break;
-            if (polls >= SPOT_RESCUE_AFTER_POLLS && !tried) {
+            if (polls == 0) t0 = wall_clock64();
+            if (!tried && (polls & 15) == 15 && wall_clock64() - t0 >= SPOT_RESCUE_AFTER_TICKS) {
                 tried = true;  // (a lost claim is not retried: its owner is running)
                 uint32_t old = 0u;
-                if (lane == 0) old = __hip_atomic_exchange(claims + (env >> 2), ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ticket) {
-                    // rare: step the four instances around this frame here (arguments re-read through an opaque pointer to the
-                    // kernel-argument segment, see mortar_step_raster_kernel), then poll again
-                    const SpotStepArgs MG_KERNARG_AS* ka = (const SpotStepArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
-                    asm volatile("" : "+s"(ka));
-                    int i = (env >> 2) * 4 + (lane >> 4);
-                    asm volatile("" : "+v"(i));
-                    if (i < n) spot_step_body<EN, true, false>(i, lane & 15, *(const SpotStepArgs*)ka, disc_lds, epoch);
-                    if (lane == 0) atomicAdd(rescues, 1u);
+                if (lane == 0) old = __hip_atomic_exchange(ka->claims + (env >> 2), ka->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ka->ticket) {
+                    slot = env >> 2;  // nobody has: step the four instances around this frame here
+                    break;
                 }
             }
             __builtin_amdgcn_s_sleep(4);
             v = fetch(env);
         }
+        if (slot >= 0) continue;
+#ifdef MG_LAB_SPOT_CLOCK
+        if (threadIdx.x == 0 && blockIdx.x < 16384 && g_lab_spot_clock[4 * blockIdx.x + 1] == 0) g_lab_spot_clock[4 * blockIdx.x + 1] = wall_clock64();
+#endif
         const SpotViewReg d{DescWordsReg{v}};
         const int next = env + stride;
         const uint32_t vn = next < n ? fetch(next) : 0u;  // leaves with this frame's loads
         if (d.valid() == 1u) {
-            int t = tid;
-            asm volatile("" : "+v"(t));  // (the lane's frame offsets are derived inside the iteration, not kept across the step code above)
-            R.tid = t;
+            RasterCtx R;
+            R.frame = smem;
+            R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+            R.A.templates = ka->A.templates;
+            R.A.stamp_data = ka->A.stamp_data;
+            R.A.disc_span = ka->A.disc_span;
+            R.A.tables = ka->A.tables;
+            R.T = as_const(ka->A.tables);
+            R.tid = wave * 64 + lane;
             typename Composer::Pre P;
             Composer::prefetch_v(d, R, P);
             Composer::compose_v(d, P, R);
             __syncthreads();
             Composer::recycle(R);
-            store_frame<MG_OBS_U8_XYC, NT, true>(smem, obs, env, t);
+            store_frame<MG_OBS_U8_XYC, NT, true>(smem, ka->obs, env, R.tid);
             __syncthreads();
         }
         v = vn;
+        env = next;
+        SPOT_CLOCK(3);
     }
 }
 
@@ -1278,8 +1363,9 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
                 SpotDesc d;
                 const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);
                 // disc lists: behind the frame and the hole mask, in the part of the 28-KiB request the composer does not use
-                spot_reset<EN>(P, io, i, ls, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes,
-                               disc_slot(reinterpret_cast<int*>(smem + FUSED_DISC_OFF)));
+                const LaneCtx L = lane_ctx(tid);
+                spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes,
+                               disc_slot(reinterpret_cast<int*>(smem + FUSED_DISC_OFF), L.grp));
                 d.valid = DESC_SERVED;
                 if (ls == 0) {
                     io.core[i] = s;
@@ -1355,6 +1441,8 @@ class SpotFamily : public Family {
         sp_done_.alloc((size_t)SLOTS * n);
         flags_.alloc(4);
         queue_.alloc((size_t)n + SQ_WORDS);
+        claims_.alloc((size_t)(n + 3) / 4);
+        rescues_.alloc(1);
 
         coins_.alloc((size_t)MAX_COINS * n);
         desc_.alloc(n);
@@ -1484,6 +1572,33 @@ class SpotFamily : public Family {
         mg_info_buffers ib;
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
+        if (obs_format == MG_OBS_U8_XYC && one_launch(n_) && !logic_event && !capturing(s)) {  // spot_step_raster_kernel
+            epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never what a reset's or a two-launch step's descriptors carry in their epoch words
+            ++ticket_;
+            SpotFusedArgs fa;
+            fa.step = SpotStepArgs{P_, io(), actions, reward, done, gt, ib, autoreset, 0};
+            fa.logic_wgs = (n_ + 15) / 16;
+            const int frames = n_ < raster_grid(n_) ? n_ : raster_grid(n_);
+            static const bool logic_last = lab_int("MEMGYM_LAB_LOGIC_LAST", 0) != 0;  // lab build: the dispatch order the design must survive
+            fa.logic_base = logic_last ? frames : 0;
+            fa.epoch = epoch_;
+            fa.ticket = ticket_;
+            fa.claims = claims_.p;
+            fa.rescues = rescues_.p;
+            fa.A = atlas_->dev();
+            fa.obs = obs;
+            const dim3 grid(fa.logic_wgs + frames);
+            const bool nt = raster_nt(n_);
+            prof.begin(1, s);
+#define SPOT_ONE(EN, BO) do { if (nt) hipLaunchKernelGGL((spot_step_raster_kernel<EN, BO, true>), grid, dim3(256), SPOT_FUSED_LDS, s, fa); \
+                              else hipLaunchKernelGGL((spot_step_raster_kernel<EN, BO, false>), grid, dim3(256), SPOT_FUSED_LDS, s, fa); } while (0)
+            if (P_.endless) { if (P_.ordered_holes) SPOT_ONE(true, true); else SPOT_ONE(true, false); }
+            else { if (P_.ordered_holes) SPOT_ONE(false, true); else SPOT_ONE(false, false); }
+#undef SPOT_ONE
+            MG_HIP(hipGetLastError());
+            prof.end(1, s);
+            return;
+        }
         prof.begin(0, s);
         const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets()) ? 1 : 0;
         const int sb = step_block(256);
@@ -1521,8 +1636,26 @@ class SpotFamily : public Family {
         return err_.take();
     }
     int peek_errors() override { return err_.peek(); }
+    bool debug_counter(const std::string& name, int64_t* out) override {
+        if (name != "one_launch_rescues") return false;  // wave-slots (four instances) stepped by a frame wave since the handle was created
+        uint32_t v = 0;
+        MG_HIP(hipMemcpy(&v, rescues_.p, sizeof v, hipMemcpyDeviceToHost));
+        *out = (int64_t)v;
+        return true;
+    }
 
    private:
+    uint32_t epoch_ = 0, ticket_ = 0;  // the one-launch step's descriptor epoch (1 .. 255) and claim ticket (the step's number)
+    // The one-launch step by launch size (first measurement, profiles/r04_spot_one_launch.md: 65,536 instances 228 vs 215-222 M
+    // env-steps/s, 16,384 instances 199-201 vs 208-210 M).  Lab build: MEMGYM_SPOT_ONE_LAUNCH=0 / 1 forces it off / on.
+    static bool one_launch(int n) {
+        static const int forced = lab_int("MEMGYM_SPOT_ONE_LAUNCH", -1);
+        return forced >= 0 ? forced != 0 : n >= 32768;
+    }
+    static bool capturing(hipStream_t s) {  // (epoch and ticket are launch arguments: a replayed graph would find them satisfied)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+    }
     SpotIO io() {
         SpotIO o;
         o.core = core_.p;
@@ -1632,6 +1765,7 @@ class SpotFamily : public Family {
     DevArray<SpotCore> core_;
     DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;
     DevArray<uint8_t> sp_r_, sp_done_;
+    DevArray<uint32_t> claims_, rescues_;  // one-launch step: one claim word per wave-slot (four instances); slots stepped by frame waves
     DevArray<int> queue_;  // deferred resets: the counters + n entries
     DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)
     DevArray<uint32_t> coins_;
@@ -1655,3 +1789,14 @@ void SpotFamily::raster_debug(void* frames, hipStream_t s) {
 Family* make_spot(int endless, int num_envs) { return new SpotFamily(endless, num_envs); }
 
 }  // namespace mg
+
+#ifdef MG_LAB_SPOT_CLOCK
+extern "C" int mg_lab_spot_clock(unsigned long long* host, int n_wgs, int clear) {
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mg::g_lab_spot_clock)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 4 * 16384) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_spot_clock), sizeof(unsigned long long) * 4 * (size_t)n_wgs) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -22,7 +22,7 @@ def main():  # noqa: C901
         print("COMPILE FAILED:\n" + "\n".join(l for l in out.splitlines() if "error" in l.lower())[:2000])
     rows, cur = [], None
     for line in out.splitlines():
-        m = re.search(r"remark: +(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
+        m = re.search(r"remark: +(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
         if not m:
             continue
         k, v = m.group(1), m.group(2)
@@ -30,13 +30,13 @@ def main():  # noqa: C901
             cur = {"name": subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()}
             rows.append(cur)
         elif cur is not None:
-            cur[k.split(" ")[0]] = v
-    print("%-100s %5s %5s %5s %7s %4s %6s" % ("kernel", "vgpr", "agpr", "sgpr", "scratch", "occ", "lds"))
+            cur[{"SGPRs Spill": "sspill", "VGPRs Spill": "vspill"}.get(k, k.split(" ")[0])] = v
+    print("%-100s %5s %5s %5s %7s %6s %6s %4s %6s" % ("kernel", "vgpr", "agpr", "sgpr", "scratch", "sspill", "vspill", "occ", "lds"))
     for r in rows:
         if flt and flt not in r["name"]:
             continue
-        print("%-100s %5s %5s %5s %7s %4s %6s" % (r["name"][:100], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"),
-                                                 r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS")))
+        print("%-100s %5s %5s %5s %7s %6s %6s %4s %6s" % (r["name"][:100], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"),
+                                                         r.get("ScratchSize"), r.get("sspill"), r.get("vspill"), r.get("Occupancy"), r.get("LDS")))
 
 
 if __name__ == "__main__":
