@@ -50,6 +50,9 @@ FRAME = 84 * 84 * 3
 # (Whole step incl. logic kernel state/action/reward traffic, SURVEY.md 8(d): MM-Grid 21,305 B.)
 STEP_BYTES = {"MortarMayhem-Grid-v0": 21305, "MortarMayhem-v0": 21309, "Endless-MortarMayhem-v0": 21821,
               "MysteryPath-v0": 21437, "Endless-SearingSpotlights-v0": 22205}
+# bytes of the frame descriptor the raster reads per frame
+DESC_BYTES = {"MortarMayhem-Grid-v0": 16, "MortarMayhem-v0": 16, "Endless-MortarMayhem-v0": 16, "MortarMayhemB-Grid-v0": 16, "MortarMayhemB-v0": 16,
+              "MysteryPath-v0": 64, "MysteryPath-Grid-v0": 64, "Endless-MysteryPath-v0": 64, "SearingSpotlights-v0": 128, "Endless-SearingSpotlights-v0": 128}
 DEFAULT_ENVS = {"MortarMayhem-Grid-v0": 65536, "MortarMayhem-v0": 65536, "MortarMayhemB-Grid-v0": 65536, "MortarMayhemB-v0": 65536, "Endless-MortarMayhem-v0": 32768,
                 "MysteryPath-v0": 32768, "MysteryPath-Grid-v0": 32768, "Endless-MysteryPath-v0": 32768, "SearingSpotlights-v0": 16384,
                 "Endless-SearingSpotlights-v0": 16384}
@@ -212,6 +215,12 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
         env.set_profiling(max(1, event_stride))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     done_sum = torch.zeros((), dtype=torch.int64, device=dev) if count_done else None
+    path0 = None
+    if count_done:  # C3: the library's own telemetry of the A* path generation inside the step's launches (wave-ticks, paths)
+        try:
+            path0 = (env.debug_counter("path_gen_ticks"), env.debug_counter("path_gen_paths"))
+        except Exception:
+            path0 = None
     fence()
     t0 = time.perf_counter()
     ev0.record()  # hipEventRecord on the launch stream (torch's current stream is the one mg_step is given)
@@ -223,6 +232,17 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     dt_event = ev0.elapsed_time(ev1) * 1e-3
     # everything of a step is enqueued on the launch stream unless a collective runs beside it: then the fences decide
     dt = dt_wall if (gather and dist_on) else dt_event
+    # spread of the headline: five more windows of K steps each, timed the same way right behind the timed region
+    windows = []
+    if not (gather and dist_on):
+        wev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        wev[0].record()
+        for w in range(5):
+            for k in range(K):
+                one_step(settle + W + K * (w + 1) + k)
+            wev[w + 1].record()
+        torch.cuda.synchronize()
+        windows = [n_total * K / (wev[w].elapsed_time(wev[w + 1]) * 1e-3) for w in range(5)]
     raster_ms = raster_n = logic_ms = logic_n = 0
     region = None
     if events:
@@ -231,8 +251,8 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
         else:  # short run: keep the timed region undisturbed, bracket every launch of the 32 steps after it
             env.set_profiling(1)
             for k in range(32):
-                one_step(settle + W + K + k)
-            region = "32 steps right after the timed region, every launch bracketed"
+                one_step(settle + W + 6 * K + k)
+            region = "32 steps right after the timed region and its five spread windows, every launch bracketed"
         raster_ms, raster_n = env.get_profile(1)
         logic_ms, logic_n = env.get_profile(0)
         env.set_profiling(False)
@@ -241,6 +261,13 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
     extra = {}
+    path_gen = None
+    if path0 is not None:  # (read right behind the timed region: it covers the K timed steps and the five spread windows)
+        ticks = env.debug_counter("path_gen_ticks") - path0[0]
+        paths = env.debug_counter("path_gen_paths") - path0[1]
+        steps_seen = K * (1 + len(windows)) + (32 if (events and not in_region) else 0)
+        path_gen = {"paths_per_step": paths / steps_seen, "wave_us_per_step": ticks / 100.0 / steps_seen,
+                    "wave_us_per_path": (ticks / 100.0 / paths) if paths else None, "steps": steps_seen}
     if count_done:  # after the timed region: how many instances finish per step, and what resetting that many costs
         for k in range(100):
             env.step(acts[k % n_act_bufs])
@@ -265,7 +292,7 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     out = {"env_id": env_id, "n_local": n_local, "n_total": n_total, "seconds": dt_max, "value": n_total * K / dt_max,
            "wall_ms_per_step": dt_wall / K * 1e3, "timing": ("host clock between the fences (a collective runs beside the launch stream)"
                                                                if (gather and dist_on) else "hipEvent pair on the launch stream around the K steps"),
-           "extra": extra,
+           "extra": extra, "value_windows": windows, "path_gen": path_gen,
            "ms_per_step": dt_max / K * 1e3, "raster_avg_ms": raster_ms / raster_n if raster_n else None, "raster_launches": raster_n,
            "logic_avg_ms": logic_ms / logic_n if logic_n else None, "event_region": region,
            "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if dist_on else None, "note": note}
@@ -278,7 +305,7 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     return out
 
 
-def secondary_workloads(primary, dev, settle):
+def secondary_workloads(primary, dev, settle, traffic=True):
     """The other single-GPU BASELINE configs (C3, C4, the per-GPU shard of C5), measured the same way after the headline
     run so that one bench line carries them; informational (the contract's `value` is the headline workload's)."""
     out = []
@@ -288,17 +315,40 @@ def secondary_workloads(primary, dev, settle):
         r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev, count_done=(label == "C3"))
         entry = {"config": label, "workload": "%s, %d envs" % (env_id, r["n_local"]), "value": r["value"], "unit": "env steps/s",
                  "ms_per_step": r["ms_per_step"], "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"],
-                 "raster_GBps": (FRAME + 16) * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 if r["raster_avg_ms"] else None,
+                 "raster_GBps": (FRAME + DESC_BYTES[env_id]) * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 if r["raster_avg_ms"] else None,
+                 "value_windows": r["value_windows"],
                  "obs_placement_zones": (r["obs_placement"] or {}).get("zones")}
+        # the same roofline figures as the headline's: SURVEY.md 8(d) bytes per instance-step over the whole step, the dominant
+        # launch's algorithmic bytes (frame + descriptor) over its own time, and its HBM traffic from two rocprofv3 child passes
+        rl = {"bytes_per_step": STEP_BYTES[env_id], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+              "frac_whole_step": STEP_BYTES[env_id] * r["n_local"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+              "dominant_kernel": "step + raster in one launch" if not r["logic_avg_ms"] else "raster",
+              "frac_dominant_kernel": (entry["raster_GBps"] / HBM_PEAK_GBPS) if entry["raster_GBps"] else None, "traffic": None}
+        if traffic:
+            tb, meta = measure_traffic(env_id, r["n_local"])
+            rl["traffic"], rl["traffic_source"] = tb, meta.get("source")
+            rl["traffic_over_bytes_per_launch"] = tb / ((FRAME + DESC_BYTES[env_id]) * r["n_local"]) if tb else None
+        entry["roofline"] = rl
         if label == "C3" and r["extra"]:
             # "report the reset (A* path-gen) kernel's share of time separately".  The path generation
             # of an auto-reset runs inside the step's logic kernel (served by the instance's wave), so its share is reported
             # as (instances that reset per step) x (cost of one reset, from a masked mg_reset of the whole batch: reset kernel
             # = mg_reset - raster) over the step time, next to the logic kernel's own time.
             x = r["extra"]
-            entry["reset_share"] = x["resets_per_step"] * x["reset_kernel_us_per_instance"] * 1e-3 / r["ms_per_step"]
-            entry["reset_share_detail"] = dict(x, method="resets per step x (masked full-batch mg_reset - mg_render) / instances, over ms_per_step",
+            est = x["resets_per_step"] * x["reset_kernel_us_per_instance"] * 1e-3 / r["ms_per_step"]
+            entry["reset_share_detail"] = dict(x, standalone_estimate=est, method="estimate: resets per step x (masked full-batch mg_reset - mg_render) / instances, over ms_per_step",
                                                logic_share=(r["logic_avg_ms"] / r["ms_per_step"]) if r["logic_avg_ms"] else None)
+            entry["reset_share"] = est
+            if r.get("path_gen"):
+                # MEASURED in the launches themselves: the path generator's waves stamp the real-time clock around every path
+                # (mg_debug_counter "path_gen_ticks" / "path_gen_paths"); share = wave-time spent generating paths over the
+                # wave-time the chip offers during a step (256 CUs x 7 workgroups x 4 waves resident)
+                pg = dict(r["path_gen"])
+                pg["chip_wave_us_per_step"] = r["ms_per_step"] * 1e3 * 256 * 7 * 4
+                pg["share_of_wave_time"] = pg["wave_us_per_step"] / pg["chip_wave_us_per_step"]
+                pg["method"] = "measured in the timed launches: per-wave real-time-clock stamps around every path generation"
+                entry["reset_share"] = pg["share_of_wave_time"]
+                entry["reset_share_measured"] = pg
         out.append(entry)
     return out
 
@@ -497,6 +547,9 @@ def main():
                        "parallelism": "env-sharded x%d, no data-path collective" % world if not r["gather"] else
                        "env-sharded x%d + %s(obs)->rank0" % (world, "peer-mapped stores" if r["gather"] == "peer" else "gather")},
             "per_gpu_value": r["value"] / world, "timing": r["timing"], "wall_ms_per_step": r["wall_ms_per_step"],
+            # five consecutive windows of K steps each right behind the timed one (this rank's share x N for N > 1): the spread a
+            # K-step headline carries
+            "value_windows": r["value_windows"],
         }
         if r["note"]:
             out["note"] = r["note"]
@@ -504,7 +557,7 @@ def main():
             out["gather_check"] = r["gather_check"]
         if r["raster_launches"]:
             avg_ms = r["raster_avg_ms"]
-            rb = (FRAME * obs_elem + 16) * n_local
+            rb = (FRAME * obs_elem + DESC_BYTES.get(env_id, 16)) * n_local
             achieved = rb / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source, traffic_meta = None, None, None
             if world == 1 and obs_elem == 1 and not args.no_traffic:
@@ -539,6 +592,7 @@ def main():
             try:
                 q = run_workload("Endless-MortarMayhem-v0", 32768, 100, 20, args.settle, world, rank, dev, "u8_xyc", gm, not args.no_events, args.event_stride)
                 c5[label] = {"value": q["value"], "unit": "env steps/s", "per_gpu_value": q["value"] / world, "ms_per_step": q["ms_per_step"],
+                             "timing": q["timing"], "wall_ms_per_step": q["wall_ms_per_step"],
                              "raster_avg_ms_rank0": q["raster_avg_ms"], "note": q["note"]}
             except Exception as e:  # keep the headline line alive
                 c5[label] = "failed: %s" % (str(e)[:200],)
@@ -560,7 +614,7 @@ def main():
                 out["c1"] = "failed: %s" % e
         if world == 1 and not args.no_secondary and args.obs_format == "u8_xyc":
             try:
-                out["secondary_workloads"] = secondary_workloads(env_id, dev, args.settle)
+                out["secondary_workloads"] = secondary_workloads(env_id, dev, args.settle, traffic=not args.no_traffic)
             except Exception as e:
                 out["secondary_workloads"] = "failed: %s" % e
         print(json.dumps(out), flush=True)

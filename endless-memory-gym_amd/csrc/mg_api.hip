@@ -26,7 +26,13 @@ struct mg_env {
     int variant = 0, family = 0;  // what make_* was called with
     bool started = false;         // a reset has happened: the grouping is fixed
     std::string id;
-    std::vector<std::pair<std::string, std::vector<double>>> options;  // every mg_set_option so far (replayed by mg_set_groups)
+    struct Opt {
+        int set;
+        std::string key;
+        std::vector<double> values;
+    };
+    std::vector<Opt> options;  // every mg_set_option / mg_set_option_set so far (replayed by mg_set_groups)
+    const int32_t* set_of_dev = nullptr;
     int obs_format = MG_OBS_U8_XYC;
     float* vec_dev = nullptr;
     int prof_stride = 0;
@@ -44,7 +50,10 @@ mg_info_buffers read_info(const mg_info_buffers* info) {
     memset(&ib, 0, sizeof(ib));
     if (!info) return ib;
     const size_t sz = info->struct_size;
-    if (sz < INFO_SIZE_MIN || sz % sizeof(void*) != 0)
+    // A caller built against the header of round 2 (no struct_size member) has a device POINTER in this place: 8-aligned and huge.
+    // Nothing larger than this build's struct plus room for a few future members is a layout of include/memgym.h.
+    constexpr size_t INFO_SIZE_MAX = sizeof(mg_info_buffers) + 16 * sizeof(void*);
+    if (sz < INFO_SIZE_MIN || sz > INFO_SIZE_MAX || sz % sizeof(void*) != 0)
         throw std::runtime_error("mg_step: mg_info_buffers.struct_size = " + std::to_string(sz) + " is not a layout of include/memgym.h (" +
                                  std::to_string(sizeof(mg_info_buffers)) + " in this build); set it to sizeof(mg_info_buffers)");
     memcpy(&ib, info, sz < sizeof(ib) ? sz : sizeof(ib));  // a shorter (older) struct: the fields it lacks stay NULL
@@ -127,7 +136,8 @@ void build_groups(mg_env* e, int groups) {
         e->fams.push_back(f);
         f->obs_format = e->obs_format;
         f->prof.stride = e->prof_stride;
-        for (auto& o : e->options) f->set_option(o.first, o.second.data(), (int)o.second.size());
+        for (auto& o : e->options) f->set_option_set(o.set, o.key, o.values.data(), (int)o.values.size());
+        if (e->set_of_dev) f->bind_option_sets(e->set_of_dev + e->base[g]);
         if (e->vec_dev && f->vec_dim()) f->bind_vector_obs(e->vec_dev + (size_t)e->base[g] * f->vec_dim());
     }
     e->fam = e->fams[0];
@@ -273,7 +283,23 @@ int mg_set_option(mg_env* env, const char* key, const double* values, int n) {
     return guarded(env, [&] {
         if (!key || !values || n < 1) throw mg::OptionError{-3, "mg_set_option: bad arguments"};
         for (auto* f : env->fams) f->set_option(key, values, n);
-        env->options.emplace_back(std::string(key), std::vector<double>(values, values + n));
+        env->options.push_back({0, std::string(key), std::vector<double>(values, values + n)});
+    });
+}
+
+int mg_set_option_set(mg_env* env, int set_id, const char* key, const double* values, int n) {
+    return guarded(env, [&] {
+        if (!key || !values || n < 1) throw mg::OptionError{-3, "mg_set_option_set: bad arguments"};
+        if (set_id < 0 || set_id >= MG_MAX_OPTION_SETS) throw mg::OptionError{-3, "mg_set_option_set: set index out of range"};
+        for (auto* f : env->fams) f->set_option_set(set_id, key, values, n);
+        env->options.push_back({set_id, std::string(key), std::vector<double>(values, values + n)});
+    });
+}
+
+int mg_bind_option_sets(mg_env* env, const int32_t* set_of_dev) {
+    return guarded(env, [&] {
+        for (int g = 0; g < env->groups(); ++g) env->fams[g]->bind_option_sets(off(set_of_dev, (size_t)env->base[g]));
+        env->set_of_dev = set_of_dev;
     });
 }
 

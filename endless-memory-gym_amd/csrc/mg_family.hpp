@@ -189,6 +189,14 @@ class Family {
     virtual void bind_vector_obs(float* /*dev*/) {}    // caller buffer [num_envs][vec_dim], written at every reset
     virtual const char* info_name(int k) const = 0;
     virtual void set_option(const std::string& key, const double* v, int n) = 0;  // throws OptionError
+    // per-instance option sets (include/memgym.h: mg_set_option_set / mg_bind_option_sets); families without them refuse sets > 0
+    virtual void set_option_set(int set, const std::string& key, const double* v, int n) {
+        if (set != 0) throw OptionError{-3, "this env id has no per-instance option sets in this build (use one handle per option set)"};
+        set_option(key, v, n);
+    }
+    virtual void bind_option_sets(const int32_t* set_of_dev) {
+        if (set_of_dev) throw OptionError{-3, "this env id has no per-instance option sets in this build (use one handle per option set)"};
+    }
     virtual void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) = 0;
     virtual void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt,
                       const mg_info_buffers* info, int autoreset, hipStream_t s) = 0;

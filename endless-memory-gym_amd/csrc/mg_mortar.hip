@@ -231,13 +231,20 @@ struct MortarIO {
     MortarDesc* desc;
     float* vec;  // [N][180] caller buffer bound with mg_bind_vector_obs (MortarMayhemB*), or NULL
     int* err;    // sticky error bits (mg_poll_errors / mg_peek_errors)
+    // per-instance option sets (mg_set_option_set / mg_bind_option_sets): instance i runs under sets[set_of[i]]; both NULL while
+    // the handle has ONE set -- the kernels then take the parameters from their arguments (scalar registers) as ever
+    const MortarParams* sets;
+    const int32_t* set_of;
 };
 constexpr int ERR_CMD_OVERFLOW = 32;  // include/memgym.h: Endless Mortar Mayhem command list longer than its capacity
 
-__global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P, int n, MortarIO io, const int64_t* seeds,
+// PS: per-instance option sets -- the parameters come from memory, io.sets[io.set_of[i]], instead of from the kernel arguments
+template <bool PS>
+__global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P0, int n, MortarIO io, const int64_t* seeds,
                                                            const uint8_t* mask, float* gt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const MortarParams& P = PS ? io.sets[io.set_of[i]] : P0;
     MortarDesc d;
     memset(&d, 0, sizeof(d));
     d.glyph_x0 = (int16_t)P.glyph_x0;
@@ -286,7 +293,7 @@ struct MortarStepArgs {
 // step's ticket into `claim_word` (see mortar_step_raster_kernel).  The exchange is ISSUED first and its answer awaited together
 // with the state record: as a round trip of its own in front of the loads it delayed every descriptor, i.e. the whole launch,
 // by 5-8 us (16,384 instances: 65 -> 73 us).
-template <bool FUSED, bool CLAIM = false>
+template <bool FUSED, bool CLAIM = false, bool PS = false>
 __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a, uint32_t epoch, uint32_t* claim_word = nullptr,
                                                  uint32_t ticket = 0u) {
     uint32_t claimed_by = 0u;
@@ -295,8 +302,8 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
         if ((threadIdx.x & 63) == 0) claimed_by = __hip_atomic_exchange(claim_word, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (the caller has dropped lanes with i >= n: the wave's first lane has its smallest i, so it is active whenever any lane is)
     }
-    const MortarParams& P = a.P;
     const MortarIO& io = a.io;
+    const MortarParams& P = PS ? io.sets[io.set_of[i]] : a.P;  // (PS: per-instance option sets)
     const int32_t* const actions = a.actions;
     float* const reward_out = a.reward_out;
     uint8_t* const done_out = a.done_out;
@@ -535,9 +542,10 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
     }
 }
 
+template <bool PS>
 __global__ __launch_bounds__(256) void mortar_step_kernel(MortarStepArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) mortar_step_body<false>(i, a, 0u);
+    if (i < a.n) mortar_step_body<false, false, PS>(i, a, 0u);
 }
 
 // ONE launch per step (uint8 observations).  `logic_wgs` workgroups of the grid run the step (one lane per instance), all others
@@ -654,9 +662,10 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
 // Debug view: the frame descriptors of the current frames with (a) the glyph the reference's CLONE of the display schedule
 // yields -- its next entry, popped (dbg_pops, the only state a debug render changes), only while the real schedule still
 // holds entries (oracle/mgo_mortar.c mm_debug) -- and (b) the ring around the target tile.
-__global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P, int n, MortarIO io, MortarDesc* out) {
+__global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P0, int n, MortarIO io, MortarDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const MortarParams& P = io.set_of ? io.sets[io.set_of[i]] : P0;
     const MortarState s = io.state[i];
     const uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     MortarDesc d = io.desc[i];
@@ -694,7 +703,7 @@ static const double SCALE = 0.25;  // the reference's module constant (e.g. mort
 class MortarFamily : public Family {
    public:
     // variant 3 / 4 = MortarMayhemB-Grid-v0 / MortarMayhemB-v0: the Grid / free machine with taskb set
-    MortarFamily(int variant_id, int n) : n_(n) {
+    MortarFamily(int variant_id, int n) : opt_(one_set()), P_(opt_[0]->P), n_(n) {
         memset(&P_, 0, sizeof(P_));
         const int variant = variant_id >= 3 ? variant_id - 3 : variant_id;
         P_.variant = variant;
@@ -711,11 +720,12 @@ class MortarFamily : public Family {
             const int cap = lab_int("MEMGYM_EMM_CMD_CAP", 0);
             if (cap >= 4 && cap <= 512) P_.cmd_cap = cap;
         }
-        st_command_count_.set(P_.command_count, {10});
-        st_show_dur_.set(P_.show_dur, {3});
-        st_show_delay_.set(P_.show_delay, {1});
-        st_expl_dur_.set(P_.expl_dur, {variant == V_GRID ? 2 : 6});
-        st_expl_delay_.set(P_.expl_delay, {variant == V_GRID ? 6 : 18});
+        MortarOpt& O = *opt_[0];
+        O.st_command_count.set(P_.command_count, {10});
+        O.st_show_dur.set(P_.show_dur, {3});
+        O.st_show_delay.set(P_.show_delay, {1});
+        O.st_expl_dur.set(P_.expl_dur, {variant == V_GRID ? 2 : 6});
+        O.st_expl_delay.set(P_.expl_delay, {variant == V_GRID ? 6 : 18});
         P_.r_fail = 0.0;
         P_.r_succ = 0.1;
         P_.r_ep_succ = 0.0;
@@ -727,9 +737,11 @@ class MortarFamily : public Family {
         err_.alloc();
         claims_.alloc((size_t)((n + 255) / 256) * 4);
         rescues_.alloc(1);
+        sets_dev_.alloc(MG_MAX_OPTION_SETS);
         hipLaunchKernelGGL(mortar_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, state_.p);
         MG_HIP(hipDeviceSynchronize());
         rebuild();
+        defaults_ = P_;  // (short lists only: no device arrays behind them)
     }
 
     int action_dim() const override { return P_.variant == V_GRID ? 1 : 2; }
@@ -741,8 +753,22 @@ class MortarFamily : public Family {
         return k == 0 ? "success" : (k == 1 ? "commands_completed" : nullptr);
     }
 
-    void set_option(const std::string& key, const double* v, int n) override {
+    // One key of the reset options, for option set `set` (0 = the handle-wide set of mg_set_option).  Sets > 0 hold everything
+    // that does not change the geometry (atlases and templates are shared by the handle's instances).
+    void set_option(const std::string& key, const double* v, int n) override { set_option_set(0, key, v, n); }
+    void set_option_set(int set, const std::string& key, const double* v, int n) override {
+        if (set < 0 || set >= MG_MAX_OPTION_SETS) throw OptionError{-3, "option set index out of range"};
+        while ((int)opt_.size() <= set) {  // a new set starts from the constructor's defaults (= the reference's), geometry from set 0
+            opt_.emplace_back(new MortarOpt());
+            opt_.back()->P = defaults_;
+            copy_geometry(opt_.back()->P, P_);
+        }
+        MortarOpt& O = *opt_[set];
+        MortarParams& P = O.P;
         const bool endless = P_.variant == V_ENDLESS;
+        auto geometry = [&]() {
+            if (set != 0) throw OptionError{-3, "reset parameter " + key + " changes the geometry shared by the handle's instances: it can only be set for all of them (option set 0)"};
+        };
         auto scalar_i = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
         // "sample one per episode" lists of any length (np_random.choice, e.g. mortar_mayhem_grid.py:181,253-254,268-269)
         auto list = [&](OptList& l, OptListStore& st, int lo, int hi) {
@@ -755,44 +781,54 @@ class MortarFamily : public Family {
             }
             st.set(l, vals);
         };
-        if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
+        // (a geometry option in a set > 0 is accepted when it says what the handle's geometry already is)
+        if (key == "agent_scale") { if (set != 0) { if (v[0] != agent_scale_) geometry(); } else { agent_scale_ = v[0]; dirty_ = true; } }
         else if (key == "allowed_commands") {
             int a = to_int_checked(v[0], key.c_str());
             if (a < 4 || a > 9) throw OptionError{-4, "assert 4 <= allowed_commands <= 9"};
-            P_.allowed = a;
+            P.allowed = a;
         }
-        else if (!P_.taskb && key == "command_show_duration") list(P_.show_dur, st_show_dur_, 1, 100);
-        else if (!P_.taskb && key == "command_show_delay") list(P_.show_delay, st_show_delay_, 0, 100);
-        else if (key == "explosion_duration") list(P_.expl_dur, st_expl_dur_, 1, 200);
-        else if (key == "explosion_delay") list(P_.expl_delay, st_expl_delay_, 1, 200);
-        else if (key == "visual_feedback") P_.visual_feedback = v[0] != 0.0;
-        else if (key == "reward_command_failure") P_.r_fail = v[0];
-        else if (key == "reward_command_success") P_.r_succ = v[0];
-        else if (endless && key == "max_steps") scalar_i(P_.max_steps);
+        else if (!P_.taskb && key == "command_show_duration") list(P.show_dur, O.st_show_dur, 1, 100);
+        else if (!P_.taskb && key == "command_show_delay") list(P.show_delay, O.st_show_delay, 0, 100);
+        else if (key == "explosion_duration") list(P.expl_dur, O.st_expl_dur, 1, 200);
+        else if (key == "explosion_delay") list(P.expl_delay, O.st_expl_delay, 1, 200);
+        else if (key == "visual_feedback") P.visual_feedback = v[0] != 0.0;
+        else if (key == "reward_command_failure") P.r_fail = v[0];
+        else if (key == "reward_command_success") P.r_succ = v[0];
+        else if (endless && key == "max_steps") scalar_i(P.max_steps);
         else if (endless && key == "initial_command_count") {
             int c = to_int_checked(v[0], key.c_str());
             if (c < 1 || c > P_.cmd_cap / 2) throw OptionError{-3, "initial_command_count out of the supported range"};
-            P_.initial_count = c;
+            P.initial_count = c;
         }
-        else if (endless && key == "reward_new_command_success") P_.r_new = v[0];
+        else if (endless && key == "reward_new_command_success") P.r_new = v[0];
         else if (!endless && key == "arena_size") {
             int a = to_int_checked(v[0], key.c_str());
             if (a < 2 || a > 6) throw OptionError{-4, "assert 2 <= arena_size <= 6"};
-            P_.N = a;
-            dirty_ = true;
+            if (set != 0 && a != P_.N) geometry();
+            if (set == 0 && a != P_.N) {
+                P_.N = a;
+                dirty_ = true;
+            }
         }
-        else if (!endless && key == "command_count") list(P_.command_count, st_command_count_, 1, P_.taskb ? VEC_DIM / 9 : P_.cmd_cap);
-        else if (!endless && key == "reward_episode_success") P_.r_ep_succ = v[0];
-        else if (P_.variant != V_GRID && key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
+        else if (!endless && key == "command_count") list(P.command_count, O.st_command_count, 1, P_.taskb ? VEC_DIM / 9 : P_.cmd_cap);
+        else if (!endless && key == "reward_episode_success") P.r_ep_succ = v[0];
+        else if (P_.variant != V_GRID && key == "agent_speed") { if (set != 0) { if (v[0] != agent_speed_) geometry(); } else { agent_speed_ = v[0]; dirty_ = true; } }
         else throw OptionError{-2, "unknown reset parameter " + key};
+        sets_dirty_ = true;
     }
+    // instance i runs under option set set_of_dev[i] (device array [num_envs], caller-owned; NULL: every instance under set 0)
+    void bind_option_sets(const int32_t* set_of_dev) override { set_of_ = set_of_dev; }
 
     void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) override {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;  // with a mask the caller is responsible for having seeded the other instances
-        hipLaunchKernelGGL(mortar_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), seeds, mask,
-                           gt_dim() ? gt : nullptr);
+        upload_sets(s);
+        if (per_set())
+            hipLaunchKernelGGL(mortar_reset_kernel<true>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), seeds, mask, gt_dim() ? gt : nullptr);
+        else
+            hipLaunchKernelGGL(mortar_reset_kernel<false>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), seeds, mask, gt_dim() ? gt : nullptr);
         raster(obs, s);
     }
 
@@ -802,8 +838,10 @@ class MortarFamily : public Family {
         mg_info_buffers ib;
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
+        upload_sets(s);
         const MortarStepArgs sa{P_, n_, io(), actions, reward, done, gt_dim() ? gt : nullptr, ib, autoreset};
-        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !logic_event && !capturing(s)) {  // one launch: mortar_step_raster_kernel
+        // one launch: mortar_step_raster_kernel (handles with ONE option set: the per-set step code reads its parameters from memory)
+        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !per_set() && !logic_event && !capturing(s)) {
             epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never the 0 a reset's (or the two-launch step's) descriptors carry
             ++ticket_;                    // claim words hold the ticket of the last one-launch step: never this one
             const int logic_wgs = (n_ + 255) / 256;
@@ -819,7 +857,8 @@ class MortarFamily : public Family {
         }
         prof.begin(0, s);
         const int sb = step_block(256);
-        hipLaunchKernelGGL(mortar_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, sa);
+        if (per_set()) hipLaunchKernelGGL(mortar_step_kernel<true>, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, sa);
+        else hipLaunchKernelGGL(mortar_step_kernel<false>, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, sa);
         end_logic(s);
         prof.begin(1, s);
         raster(obs, s);
@@ -866,6 +905,8 @@ class MortarFamily : public Family {
         o.desc = desc_.p;
         o.vec = vec_;
         o.err = err_.dev;
+        o.sets = per_set() ? sets_dev_.p : nullptr;
+        o.set_of = per_set() ? set_of_ : nullptr;
         return o;
     }
 
@@ -899,6 +940,36 @@ class MortarFamily : public Family {
         atlas_->upload();
         P_.glyph_x0 = (int)((SCREEN / 2) - std::floor(88 * SCALE / 2));
         dirty_ = false;
+        for (size_t k = 1; k < opt_.size(); ++k) copy_geometry(opt_[k]->P, P_);
+        copy_geometry(defaults_, P_);
+        sets_dirty_ = true;
+    }
+
+    // per-instance option sets
+    struct MortarOpt {
+        MortarParams P;
+        OptListStore st_command_count, st_show_dur, st_show_delay, st_expl_dur, st_expl_delay;
+    };
+    static std::vector<std::unique_ptr<MortarOpt>> one_set() {
+        std::vector<std::unique_ptr<MortarOpt>> v;
+        v.emplace_back(new MortarOpt());
+        return v;
+    }
+    // what the shared atlases and templates fix for every set of the handle
+    static void copy_geometry(MortarParams& d, const MortarParams& s) {
+        d.variant = s.variant; d.N = s.N; d.taskb = s.taskb; d.cmd_cap = s.cmd_cap; d.arena_x0 = s.arena_x0; d.tile = s.tile;
+        d.radius = s.radius; d.sprite_dim = s.sprite_dim; d.glyph_x0 = s.glyph_x0; d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i;
+        d.off_lo = s.off_lo; d.off_hi = s.off_hi; d.v_axis = s.v_axis; d.v_diag = s.v_diag;
+    }
+    bool per_set() const { return set_of_ != nullptr && opt_.size() > 1; }
+    // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)
+    void upload_sets(hipStream_t s) {
+        if (!per_set() || !sets_dirty_) return;
+        std::vector<MortarParams> host(MG_MAX_OPTION_SETS, P_);
+        for (size_t k = 0; k < opt_.size(); ++k) host[k] = opt_[k]->P;
+        MG_HIP(hipMemcpyAsync(sets_dev_.p, host.data(), sizeof(MortarParams) * host.size(), hipMemcpyHostToDevice, s));
+        MG_HIP(hipStreamSynchronize(s));  // (rare: only after an option of some set changed)
+        sets_dirty_ = false;
     }
 
     void raster_only(void* obs, const uint8_t* only, hipStream_t s) override {
@@ -924,8 +995,13 @@ class MortarFamily : public Family {
 
    private:
 
+    std::vector<std::unique_ptr<MortarOpt>> opt_;  // [0] = the handle-wide set (P_ below is its parameter block)
+    MortarParams& P_;
+    MortarParams defaults_;
+    const int32_t* set_of_ = nullptr;
+    bool sets_dirty_ = true;
+    DevArray<MortarParams> sets_dev_;
     int n_;
-    MortarParams P_;
     std::unique_ptr<Atlas> atlas_;
     double agent_scale_, agent_speed_;
     bool dirty_ = true, seeded_ = false;
@@ -941,7 +1017,6 @@ class MortarFamily : public Family {
     RngStore rng_;
     ErrorWord err_;
     DevArray<uint32_t> claims_, rescues_;  // one-launch step: one claim word per 64 instances; slots stepped by frame waves
-    OptListStore st_command_count_, st_show_dur_, st_show_delay_, st_expl_dur_, st_expl_delay_;
 };
 
 Family* make_mortar(int variant, int num_envs) { return new MortarFamily(variant, num_envs); }

@@ -194,6 +194,9 @@ struct MysteryIO {
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
     int* bgq;    // endless: instances that are owed a segment nobody waits for yet (QC_BG_COUNT entries; lane-per-path service)
     const uint4* jump;  // [64][2] PCG64 jump constants {A^(k+1), S_(k+1)} (WaveRng)
+    // telemetry of the finite variants' path generation inside the step's launches (bench.py: C3's measured reset share):
+    // [0] wave-ticks (real-time clock, 10 ns) spent generating paths, [1] paths generated; mg_debug_counter "path_gen_ticks" / "path_gen_paths"
+    unsigned long long* stats;
 };
 constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_BG_COUNT = 96, QC_BG_LEFT = 128, QC_WORDS = 160;  // one 128-byte line each
 // MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
@@ -235,6 +238,7 @@ constexpr int WS_BYTES = WS_STAGE + 4 * 64;
 struct PathWS {
     uint8_t* base;
     const uint4* jump;  // WaveRng's per-lane jump constants
+    unsigned long long* stats;  // MysteryIO::stats or NULL
     __device__ __forceinline__ double h(int d2) const { return reinterpret_cast<const double*>(base + WS_SQRT)[d2]; }
     __device__ __forceinline__ uint8_t* stage() const { return base + WS_STAGE + (threadIdx.x >> 6) * 64; }
 };
@@ -533,6 +537,8 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
     uint64_t todo = __ballot(req.need != 0);
     WaveRng wr;
     if (todo) wr.load_jump(W.jump);
+    const unsigned long long t_in = (todo && W.stats) ? wall_clock64() : 0ull;
+    const int n_paths = __popcll((unsigned long long)todo);
     while (todo) {
         const int L = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
@@ -554,6 +560,10 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
             pm_out = pm;
             if (walls) walls[inst] = wl;  // only the debug view reads them
         }
+    }
+    if (n_paths && W.stats && lane == 0) {  // (rare path: an instance of this wave finished)
+        atomicAdd(W.stats, wall_clock64() - t_in);
+        atomicAdd(W.stats + 1, (unsigned long long)n_paths);
     }
 }
 
@@ -1113,7 +1123,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
                                                             const uint8_t* mask, float* gt, int lpw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem, io.jump};
+    const PathWS W{smem, io.jump, io.stats};
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool in_range = worker && i < P.n;
@@ -1156,7 +1166,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
                                                            mg_info_buffers info, int autoreset, int lpw, int defer) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem, io.jump};
+    const PathWS W{smem, io.jump, io.stats};
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool active = worker && i < P.n;
@@ -1517,7 +1527,10 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
                 lane_ws_init(smem);
                 if (threadIdx.x < 64) {
                     const LaneWS LW{smem, (int)threadIdx.x};
+                    const unsigned long long t_in = io.stats ? wall_clock64() : 0ull;
+                    int mine = 0;
                     for (int idx = blockIdx.x * 64 + threadIdx.x; idx < count; idx += busy * 64) {
+                        ++mine;
                         const int i = io.queue[idx];
                         Pcg g;
                         g.load(io.rng, i);
@@ -1534,11 +1547,20 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
                         if (io.walls) io.walls[i] = wl;
                         g.store(io.rng, i);
                     }
+                    if (io.stats) {  // one wave's time for up to 64 paths side by side
+                        const unsigned long long n_here = (unsigned long long)__popcll(__ballot(mine > 0)) ;
+                        int total = mine;
+                        for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o);
+                        if (threadIdx.x == 0 && n_here) {
+                            atomicAdd(io.stats, wall_clock64() - t_in);
+                            atomicAdd(io.stats + 1, (unsigned long long)total);
+                        }
+                    }
                 }
             } else if (count > 0) {
                 if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
                 path_ws_init(smem);
-                const PathWS W{smem, io.jump};
+                const PathWS W{smem, io.jump, io.stats};
                 const bool me = (threadIdx.x & 63) == 0;
                 const int waves = busy * 4;
                 for (int idx = bcast((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), 0); idx < count; idx += waves) {
@@ -1656,7 +1678,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
-    const PathWS W{smem, io.jump};
+    const PathWS W{smem, io.jump, io.stats};
     const bool me = (threadIdx.x & 63) == 0;
     const int count = all ? P.n : queue_count(&io.qctr[QC_COUNT], P.n);
     // the first entry of wave w is entry w (no atomic: with thousands of idle waves the same-address atomics of their
@@ -1702,6 +1724,9 @@ static __device__ unsigned long long g_lab_emp_clock[3 * 16384];
 #endif
 constexpr int EMP_BG_WGS = 512;  // frame workgroups that may carry background jobs (64 each: all 32,768 instances at once)
 static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
+// (Round 4 tried the service and background workgroups as a launch of their own on a side stream beside a plain raster launch:
+// bit-exact, 185 M env-steps/s against 189-192 M for this fused launch -- the raster alone takes 110 us, beside the service
+// 136-144 us, and the fork / join costs ~10 us of stream time: profiles/r04_emp.md.  Taken out again.)
 template <int FMT>
 __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
                                                                   MysteryParams P, MysteryIO io, float* reward_out, uint8_t* done_out,
@@ -1722,7 +1747,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
         if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
         uint8_t* ws = smem + FRAME_BYTES;  // the path workspace lives in the (unused) mask words behind the frame
         path_ws_init(ws);
-        const PathWS W{ws, io.jump};
+        const PathWS W{ws, io.jump, io.stats};
         const int wv = tid >> 6;
         const bool me = (tid & 63) == 0;
         const int count = queue_count(&io.qctr[QC_COUNT], n);
@@ -1841,6 +1866,7 @@ class MysteryFamily : public Family {
                 jt[2 * k + 1] = make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(q >> 64), (uint32_t)(q >> 96));
             }
             jump_.upload(jt);
+            stats_.alloc(4);
         }
         if (endless) {
             segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
@@ -1981,6 +2007,14 @@ class MysteryFamily : public Family {
         return err_.take();
     }
     int peek_errors() override { return err_.peek(); }
+    bool debug_counter(const std::string& name, int64_t* out) override {
+        const int k = name == "path_gen_ticks" ? 0 : (name == "path_gen_paths" ? 1 : -1);
+        if (k < 0 || !stats_.p) return false;
+        unsigned long long v = 0;
+        MG_HIP(hipMemcpy(&v, stats_.p + k, sizeof v, hipMemcpyDeviceToHost));
+        *out = (int64_t)v;
+        return true;
+    }
 
    private:
     // instance-carrying lanes per wave (see instance_of_lane); MEMGYM_MYSTERY_LPW overrides for tuning
@@ -2059,6 +2093,7 @@ class MysteryFamily : public Family {
         o.qctr = queue_.p + ((n_ + 31) & ~31);
         o.bgq = bgq_.p;
         o.jump = jump_.p;
+        o.stats = stats_.p;
         return o;
     }
 
@@ -2144,6 +2179,7 @@ class MysteryFamily : public Family {
     DevArray<int> bgq_;    // endless: background jobs (owed segments)
     bool lazy_wanted_ = false, owed_possible_ = false;
     DevArray<uint4> jump_;  // WaveRng jump constants
+    DevArray<unsigned long long> stats_;  // MysteryIO::stats
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)
     ErrorWord err_;
     RngStore rng_;

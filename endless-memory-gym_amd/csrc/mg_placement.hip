@@ -36,26 +36,40 @@ constexpr int FILL_STEP = 32;               // filler handles per step of the wa
 constexpr int PROBE_GRID = 14336;
 // Classification of a probed pair of pieces.  Pairs in one zone measured 4.9-5.5 TB/s, pairs across zones 6.1-6.5
 // (profiles/r02_zones.md) -- on THESE boxes.  Those absolute figures are only the PRIOR (round 2 classified by them alone):
-// every probe of two distinct pieces feeds the per-device extremes (Calib), and as soon as they are 15 % apart -- more than
-// pairs of one kind differ among themselves (4.9-5.5: 12 %), so both kinds have been seen in this process -- the thresholds
-// become relative: the geometric mean of the extremes -/+ 3 %.  A
+// every probe of two distinct pieces feeds the per-device calibration (Calib), and once the samples show two clusters the
+// thresholds become relative: the geometric mean across the gap between the clusters -/+ 1.5 %.  A
 // search whose earlier decisions the calibrated thresholds would change starts over once.  (A piece paired with ITSELF is no
 // calibration: both windows then hit the same cache lines, 11.6 TB/s.)  MEMGYM_OBS_SAME_TBPS / MEMGYM_OBS_CROSS_TBPS set the prior.
 static const double PRIOR_SAME_TBPS = lab_env("MEMGYM_OBS_SAME_TBPS") ? atof(lab_env("MEMGYM_OBS_SAME_TBPS")) : 5.35;
 static const double PRIOR_CROSS_TBPS = lab_env("MEMGYM_OBS_CROSS_TBPS") ? atof(lab_env("MEMGYM_OBS_CROSS_TBPS")) : 5.85;
 struct Calib {
-    double lo = 1e30, hi = 0;
+    // Round 4: the thresholds turn relative only on evidence of TWO clusters -- at least two probes on either side of the
+    // widest gap between neighbouring samples, that gap >= 7 % and the whole spread >= 15 %.  The first version switched as soon as
+    // the fastest probe was 15 % above the slowest: pairs of ONE zone differ by up to 12 % among themselves and a single noisy
+    // probe did the rest, after which same-zone pairs at 5.5 TB/s were classed "other zone" for the rest of the process.
+    std::vector<double> seen;  // every probe of two distinct pieces so far (bounded)
     bool relative = false;
     double same_t = PRIOR_SAME_TBPS, cross_t = PRIOR_CROSS_TBPS;
     void observe(double t) {
-        lo = std::min(lo, t);
-        hi = std::max(hi, t);
-        if (hi >= 1.15 * lo) {
-            const double mid = std::sqrt(lo * hi);
-            relative = true;
-            same_t = 0.97 * mid;
-            cross_t = 1.03 * mid;
-        }
+        if (seen.size() < 256) seen.push_back(t);
+        std::vector<double> v(seen);
+        std::sort(v.begin(), v.end());
+        relative = false;
+        same_t = PRIOR_SAME_TBPS;
+        cross_t = PRIOR_CROSS_TBPS;
+        if (v.size() < 4 || v.back() < 1.15 * v.front()) return;
+        size_t cut = 0;
+        double gap = 0;
+        for (size_t k = 2; k + 2 <= v.size(); ++k)  // two samples at least on either side
+            if (v[k] / v[k - 1] > gap) {
+                gap = v[k] / v[k - 1];
+                cut = k;
+            }
+        if (cut == 0 || gap < 1.07) return;
+        const double mid = std::sqrt(v[cut - 1] * v[cut]);
+        relative = true;
+        same_t = std::max(v[cut - 1] * 1.005, 0.985 * mid);  // (never below the fastest sample of the slow cluster)
+        cross_t = std::min(v[cut] * 0.995, 1.015 * mid);
     }
     int classify(double t) const { return t < same_t ? 0 : (t <= cross_t ? 1 : 2); }  // 0 same zone, 1 unclear, 2 other zone
 };

@@ -41,6 +41,7 @@ struct SpotParams {
     int ordered_holes;              // a spotlight with a border has been possible: hole words in LIST order, border composer
     int layer_flags;                // LAYER_EXIT_ABOVE (exit_visible) | LAYER_AGENT_TOP (agent_visible), OR-ed into SpotDesc::coin_above
     int coin_enabled, coin_show_duration, coins_visible, sample_agent_position, show_last_action, show_last_positive_reward;
+    int use_exit;                   // finite variant; 0: no exit is spawned, the instance's EARLIER exit stays in the frame (spot_reset)
     int r_lo, r_hi;                 // radius = integers(r_lo, r_hi)
     int agent_radius, sprite_half, coin_radius;
     int v_axis_i, v_diag_i;
@@ -69,17 +70,13 @@ struct __attribute__((aligned(16))) SpotCore {
 };
 static_assert(sizeof(SpotCore) == 80, "SpotCore must be 80 bytes");
 
-// The frame descriptor: 32 dwords = ONE 128-byte line, two 64-byte halves with an epoch word each (the one-launch step,
-// spot_step_raster_kernel, hands descriptors from its step waves to its frame waves inside the launch; a reader that finds this
-// launch's epoch in BOTH halves of one load holds a consistent record).
+// The frame descriptor: 32 dwords = ONE 128-byte line (round 4; it was 160 bytes over two or three lines).
 //   w0  valid | bg << 8 | sprite << 16 | alpha << 24          w1  sx | sy << 16 (int16 each)
 //   w2  n_holes | n_coins << 8 | coin_above << 16 | red_w << 24
 //   w3  c_base | c_act0 << 8 | c_act1 << 16 | c_bar << 24      w4  bar_x | bar_w << 8 | quarter << 16 | exit_stamp << 24
-//   w5  exit_x | exit_y << 16                                  w6  holes[15]        w7  epoch (first half)
-//   w8 .. w15  coins: (x + 128) | (y + 128) << 16, top-left of the coin stamp
-//   w16 .. w30 holes[0 .. 14]                                  w31 epoch (second half)
-// Readers address it by WORD (SpotView below), through scalar loads (a pointer in the constant address space) or through lane
-// reads of a register that holds word k in lane k.
+//   w5  exit_x | exit_y << 16                                  w6, w7  unused
+//   w8 .. w15  coins: (x + 128) | (y + 128) << 16, top-left of the coin stamp        w16 .. w31 holes
+// The composers address it by WORD through scalar loads (SpotView over a pointer in the constant address space).
 struct __attribute__((aligned(128))) SpotDesc {
     uint32_t valid : 8, bg : 8, sprite : 8, alpha : 8;
     int32_t sx : 16, sy : 16;
@@ -87,23 +84,16 @@ struct __attribute__((aligned(128))) SpotDesc {
     uint32_t c_base : 8, c_act0 : 8, c_act1 : 8, c_bar : 8;
     uint32_t bar_x : 8, bar_w : 8, quarter : 8, exit_stamp : 8;
     int32_t exit_x : 16, exit_y : 16;
-    uint32_t hole15;
-    uint32_t epoch_a;
+    uint32_t pad[2];
     uint32_t coins[MAX_COINS];
-    uint32_t holes[MAX_HOLES - 1];
-    uint32_t epoch_b;
+    uint32_t holes[MAX_HOLES];
 };
 static_assert(sizeof(SpotDesc) == 128 && MAX_HOLES == 16 && MAX_COINS == 8, "SpotDesc is one 128-byte line");
-constexpr int DW_HOLE15 = 6, DW_EPOCH_A = 7, DW_COINS = 8, DW_HOLES = 16, DW_EPOCH_B = 31, DESC_WORDS = 32;
-__device__ __forceinline__ int hole_word(int h) { return h < MAX_HOLES - 1 ? DW_HOLES + h : DW_HOLE15; }
+constexpr int DW_COINS = 8, DW_HOLES = 16;
 
 struct DescWordsMem {  // the descriptor in memory, written by an EARLIER launch: scalar loads
     cptr<uint32_t> p;
     __device__ __forceinline__ uint32_t w(int k) const { return p[k]; }
-};
-struct DescWordsReg {  // word k in lane k (k < 32) of one vector register: v_readlane, the result is a scalar like a scalar load's
-    uint32_t v;
-    __device__ __forceinline__ uint32_t w(int k) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); }
 };
 template <class W>
 struct SpotView {
@@ -130,10 +120,9 @@ struct SpotView {
     __device__ __forceinline__ int exit_y() const { return (int)s.w(5) >> 16; }
     __device__ __forceinline__ int coin_x(int k) const { return (int)(s.w(DW_COINS + k) & 0xFFFFu) - 128; }
     __device__ __forceinline__ int coin_y(int k) const { return (int)(s.w(DW_COINS + k) >> 16) - 128; }
-    __device__ __forceinline__ uint32_t hole(int h) const { return s.w(hole_word(h)); }
+    __device__ __forceinline__ uint32_t hole(int h) const { return s.w(DW_HOLES + h); }
 };
 typedef SpotView<DescWordsMem> SpotViewMem;
-typedef SpotView<DescWordsReg> SpotViewReg;
 __device__ __forceinline__ SpotViewMem view_of(cptr<SpotDesc> dp) { return SpotViewMem{DescWordsMem{(cptr<uint32_t>)dp}}; }
 
 constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
@@ -141,6 +130,9 @@ constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
 // (searing_spotlights.py:349-351, 234-235, 420-421; endless :313-315, 223-224, 376-377): per instance, sticky across
 // episodes and option changes.  Templates: 0 blue board, 1 red board, 2 white, 3 black.
 constexpr uint32_t BG_CHESS = 0, BG_WHITE = 1, BG_BLACK = 2, BG_MODE_SHIFT = 20, BG_MODE_MASK = 0xFu << BG_MODE_SHIFT;
+// SpotCore::pad bit 24: the instance has had an exit (searing_spotlights.py: self.exit exists); sticky like the board modes
+constexpr uint32_t PAD_HAS_EXIT = 1u << 24, PAD_STICKY = BG_MODE_MASK | PAD_HAS_EXIT;
+constexpr int ERR_NO_EXIT = 256;  // include/memgym.h: use_exit = False for an instance that never had an exit
 __device__ __forceinline__ uint32_t bg_mode(uint32_t pad, int red) { return (pad >> (BG_MODE_SHIFT + 2 * red)) & 3u; }
 __device__ __forceinline__ uint32_t bg_set(uint32_t pad, int red, uint32_t m) {
     return (pad & ~(3u << (BG_MODE_SHIFT + 2 * red))) | (m << (BG_MODE_SHIFT + 2 * red));
@@ -409,6 +401,10 @@ struct SpotIO {
     // resets put off by the step kernel and served inside the raster launch (spot_raster_serve_kernel)
     int* queue;  // [N] instances
     int* qctr;   // SQ_COUNT entries, SQ_LEFT service workgroups that have finished (the last one clears both)
+    // per-instance option sets (mg_set_option_set / mg_bind_option_sets): instance i runs under sets[set_of[i]]; both NULL while
+    // the handle has ONE set -- the kernels then take the parameters from their arguments
+    const SpotParams* sets;
+    const int32_t* set_of;
 };
 constexpr int SQ_COUNT = 0, SQ_LEFT = 32, SQ_WORDS = 64;  // one 128-byte line each
 // SpotDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = a reset is queued, 3 = reset and drawn by a service
@@ -447,9 +443,7 @@ struct Discs {
 // the slot of the calling lane's group inside an array of (workgroup size / 16) * DISC_INTS ints
 __device__ __forceinline__ int* disc_slot(int* lds, int grp) { return lds + grp * DISC_INTS; }
 // Where a lane sits: its slot id, the group (= instance) of 16 lanes it belongs to within the workgroup, and that group's bit
-// position in a wave ballot.  Handed down instead of being derived from threadIdx in place: inside the one-launch step's loop
-// (spot_step_raster_kernel) everything derived from threadIdx is a loop invariant that the compiler keeps in a register for the
-// whole kernel -- twenty of them, in a kernel without a register to spare; that kernel derives the context from an opaque copy.
+// position in a wave ballot.
 struct LaneCtx {
     int ls, grp, gshift;
 };
@@ -655,7 +649,6 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.coins_collected = 0;
     s.n_coins = 0;
     s.has_coin = 0;
-    s.exit_open = 0;
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
     int* const coin_pos = slot + 3 * MAX_DISCS;  // the coins as placed (finite variant), next to the disc list
     if constexpr (EN) {
@@ -685,13 +678,22 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
             coin_pos[k] = (int)w;
             s.n_coins++;
         }
-        int ex, ey;
-        sample_cell(g, D, L, &ex, &ey);
-        ex += g.integers(2, 4);
-        ey += g.integers(2, 4);
-        clamp_spawn(P, ex, ey);
-        s.exit_x = (int16_t)ex;
-        s.exit_y = (int16_t)ey;
+        if (P.use_exit) {  // _spawn_exit (searing_spotlights.py:280-286)
+            int ex, ey;
+            sample_cell(g, D, L, &ex, &ey);
+            ex += g.integers(2, 4);
+            ey += g.integers(2, 4);
+            clamp_spawn(P, ex, ey);
+            s.exit_x = (int16_t)ex;
+            s.exit_y = (int16_t)ey;
+            s.exit_open = 0;
+            s.pad |= PAD_HAS_EXIT;
+        } else if (!(s.pad & PAD_HAS_EXIT)) {
+            // use_exit == False: nothing is spawned, sampled or drawn (:413-416) and the frame keeps blitting self.exit -- the Exit
+            // of an earlier episode, where it was and as it was last drawn (open / closed).  Without one the reference raises
+            // AttributeError at this reset (:431-435); here the bit is raised and no exit is drawn.
+            raise_error(io.err, ERR_NO_EXIT);
+        }
     }
     s.bg_red = 0;
     if (P.hide_chessboard) s.pad = bg_set(bg_set(s.pad, 0, BG_WHITE), 1, BG_WHITE);  // (the reference does this first thing: no draw depends on it)
@@ -723,7 +725,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
                 d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
             }
         }
-        d.exit_stamp = ST_EXIT_CLOSED;
+        d.exit_stamp = (s.pad & PAD_HAS_EXIT) ? (s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED) : 0xFF;
         d.exit_x = (int16_t)(s.exit_x - P.exit_half);
         d.exit_y = (int16_t)(s.exit_y - P.exit_half);
     }
@@ -746,7 +748,6 @@ __global__ __launch_bounds__(256) void spot_init_kernel(int n, SpotCore* core) {
 
 // the leader stores the descriptor's header + coin positions (words 0..5 and 8..15); hole words are written by the slot
 // lanes.  Packed field by field (the layout of the bit-fields above) so that `d` never has to exist in memory.
-template <bool COHERENT = false>  // COHERENT: agent-scope (write-through) stores, for readers inside the same launch
 __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d) {
     uint4* out = reinterpret_cast<uint4*>(dst);
     const uint32_t w0 = (uint32_t)d.valid | ((uint32_t)d.bg << 8) | ((uint32_t)d.sprite << 16) | ((uint32_t)d.alpha << 24);
@@ -755,33 +756,22 @@ __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d
     const uint32_t w3 = (uint32_t)d.c_base | ((uint32_t)d.c_act0 << 8) | ((uint32_t)d.c_act1 << 16) | ((uint32_t)d.c_bar << 24);
     const uint32_t w4 = (uint32_t)d.bar_x | ((uint32_t)d.bar_w << 8) | ((uint32_t)d.quarter << 16) | ((uint32_t)d.exit_stamp << 24);
     const uint32_t w5 = ((uint32_t)d.exit_x & 0xFFFFu) | ((uint32_t)d.exit_y << 16);
-    if constexpr (COHERENT) {  // (dword stores: 64-bit ones need aligned register pairs, which cost this tight kernel its last free registers)
-        uint32_t* o = reinterpret_cast<uint32_t*>(dst);
-        auto put = [&](int q, uint32_t w) { __hip_atomic_store(o + q, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        put(0, w0);
-        put(1, w1);
-        put(2, w2);
-        put(3, w3);
-        put(4, w4);
-        put(5, w5);
-#pragma unroll
-        for (int c = 0; c < MAX_COINS; ++c) put(DW_COINS + c, d.coins[c]);
-        return;
-    }
     out[0] = make_uint4(w0, w1, w2, w3);
-    reinterpret_cast<uint2*>(dst)[2] = make_uint2(w4, w5);  // (w6 is holes[15], a slot lane's; w7 the one-launch step's epoch)
+    reinterpret_cast<uint2*>(dst)[2] = make_uint2(w4, w5);
     out[2] = make_uint4(d.coins[0], d.coins[1], d.coins[2], d.coins[3]);
     out[3] = make_uint4(d.coins[4], d.coins[5], d.coins[6], d.coins[7]);
 }
 static_assert(MAX_COINS == 8, "store_desc_head packs eight coin words");
 
-template <bool EN>
-__global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P, SpotIO io, const int64_t* seeds, const uint8_t* mask,
+// PS: per-instance option sets -- the parameters come from memory, io.sets[io.set_of[i]], instead of from the kernel arguments
+template <bool EN, bool PS>
+__global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P0, SpotIO io, const int64_t* seeds, const uint8_t* mask,
                                                          float* gt) {
     __shared__ int disc_lds[(256 / 16) * DISC_INTS];
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int i = gid >> 4, ls = gid & 15;
-    if (i >= P.n) return;
+    if (i >= P0.n) return;
+    const SpotParams& P = PS ? io.sets[io.set_of[i]] : P0;
     if (mask && !mask[i]) {
         if (ls == 0) io.desc[i].valid = 0;
         return;
@@ -813,32 +803,22 @@ struct SpotStepArgs {
     int autoreset, defer;
 };
 
-// The step of instance i as its 16 lanes execute it (lane ls owns spotlight slot ls).  FUSED (spot_step_raster_kernel): the
-// descriptor is handed to the frame waves of the SAME launch -- every word written with agent-scope (write-through) stores, the
-// two epoch words last (SpotDesc).  The body is written to need few registers at once, because in that launch it shares a
-// kernel with the raster (80 VGPRs at six workgroups per CU): the RNG stream is read where the first draw happens (spawns, coin
-// re-sampling and resets are rare), the slot record after the spawn, and a newborn spotlight is read back from memory.
-// CLAIM with a claim word (a step workgroup's wave of that launch): the wave steps its four instances only if it is the first to
-// exchange this step's ticket into the word; the exchange is issued first and awaited together with the state record.  Without
-// a word (a frame wave that has won the claim already) the step is unconditional.
-template <bool EN, bool FUSED, bool CLAIM = false>
-__device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const SpotStepArgs& a, int* disc_lds, SpotCore* core_lds, uint32_t epoch,
-                                               uint32_t* claim_word = nullptr, uint32_t ticket = 0u) {
+// The step of instance i as its 16 lanes execute it (lane ls owns spotlight slot ls).  Written to need few registers at once
+// (round 4: 123 -> 65-78 VGPRs; it was written for a one-launch step that measured slower and is gone, profiles/r04_spot_one_launch.md,
+// and the two-launch step kept what it gained at large launches): the RNG stream is read where the first draw happens (spawns,
+// coin re-sampling and resets are rare), the slot record after the spawn, a newborn spotlight is read back from memory, and the
+// core record lives in LDS.
+template <bool EN, bool PS>
+__device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const SpotStepArgs& a, int* disc_lds, SpotCore* core_lds) {
     const int ls = L.ls;
-    uint32_t claimed_by = 0u;
-    if constexpr (CLAIM) {
-        claimed_by = ticket + 1u;  // lanes other than the wave's first: any value but the ticket
-        // (the caller has dropped lanes with i >= n; the wave's first lane has its smallest i, so it is active whenever any lane is)
-        if (claim_word && (L.ls | L.gshift) == 0) claimed_by = __hip_atomic_exchange(claim_word, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const SpotParams& P = a.P;
     const SpotIO& io = a.io;
+    const SpotParams& P = PS ? io.sets[io.set_of[i]] : a.P;  // (PS: per-instance option sets)
     const int32_t* const actions = a.actions;
     float* const reward_out = a.reward_out;
     uint8_t* const done_out = a.done_out;
     float* const gt = a.gt;
     const mg_info_buffers& info = a.info;
-    const int autoreset = a.autoreset, defer = FUSED ? 0 : a.defer;
+    const int autoreset = a.autoreset, defer = a.defer;
     const int group_shift = L.gshift;  // bit position of this instance's 16 lanes in a wave ballot
     const bool leader = ls == 0;
     // The instance's core record lives in LDS for the length of the step (its 16 lanes write the same values to the same words):
@@ -846,10 +826,6 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     // 89 -> 65-73 VGPRs for this body), for a handful of LDS round trips on its critical path.
     SpotCore& s = core_lds[L.grp];
     s = io.core[i];
-    if constexpr (CLAIM) {
-        asm volatile("" : "+v"(claimed_by));
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)claimed_by) == ticket) return;  // a frame wave has stepped this slot already
-    }
     Pcg g;
     bool rng_loaded = false;
     auto need_rng = [&]() {  // (all 16 lanes of the instance take the same branch: they hold the same state)
@@ -947,12 +923,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
                 rank += (int)((processed >> slot) & 1u);
             }
         }
-        {
-            uint32_t* const hw = reinterpret_cast<uint32_t*>(&io.desc[i]) + hole_word(rank);
-            const uint32_t hv = pack_hole((int)cx, (int)cy, radius) | ((uint32_t)(p_r >> 7) << 31);
-            if constexpr (FUSED) __hip_atomic_store(hw, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *hw = hv;
-        }
+        io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius) | ((uint32_t)(p_r >> 7) << 31);
         t += p_speed;
         if (t >= 1.0) {
             t = 1.0;
@@ -1044,7 +1015,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
         }
         bool exit_done = false;
         double er = 0.0;
-        if (coins_done) {
+        if (coins_done && P.use_exit) {  // _step_exit_task (:313-330)
             s.exit_open = 1;
             double ddx = (double)ax - (double)s.exit_x, ddy = (double)ay - (double)s.exit_y;
             if (sqrt(ddx * ddx + ddy * ddy) <= P.exit_radius + (double)P.agent_radius) {
@@ -1054,7 +1025,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
         }
         reward += er;
         if (spot_done) done = true;
-        else if (coins_done && exit_done) { done = true; success = 1; }
+        else if (coins_done && (P.use_exit ? exit_done : s.num_coins > 0)) { done = true; success = 1; }  // (:499-511)
         s.t++;
         if (s.t == P.max_steps) done = true;
     }
@@ -1082,7 +1053,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
 
     // debug view only: the (rotated_agent_surface, rotated_agent_rect) pair of this step -- a reset leaves it alone, and the
     // reference's debug render shows that stale pair until the first step of the next episode
-    s.pad = (s.pad & BG_MODE_MASK) | 0x80000000u | ((uint32_t)s.rot8 << 16) | (uint32_t)((ax + 128) & 0xFF) | ((uint32_t)((ay + 128) & 0xFF) << 8);
+    s.pad = (s.pad & PAD_STICKY) | 0x80000000u | ((uint32_t)s.rot8 << 16) | (uint32_t)((ax + 128) & 0xFF) | ((uint32_t)((ay + 128) & 0xFF) << 8);
     // defer: the reset (position sampling on 84x84 masks: ~30 us for the 16 lanes of the instance, the tail of this launch
     // whenever any instance finishes) is queued and done by a service workgroup of the raster launch, which also draws the
     // frame; state, stream and the descriptor head (its n_holes are the reset frame's stale holes) are stored as after
@@ -1118,7 +1089,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
                 reinterpret_cast<uint4*>(coins)[0] = make_uint4(coin_pos[0], coin_pos[1], coin_pos[2], coin_pos[3]);
                 reinterpret_cast<uint4*>(coins)[1] = make_uint4(coin_pos[4], coin_pos[5], coin_pos[6], coin_pos[7]);
             }
-            d.exit_stamp = s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED;
+            d.exit_stamp = (s.pad & PAD_HAS_EXIT) ? (s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED) : 0xFF;
             d.exit_x = (int16_t)(s.exit_x - P.exit_half);
             d.exit_y = (int16_t)(s.exit_y - P.exit_half);
         }
@@ -1136,182 +1107,17 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     if (leader) {
         if (rng_loaded) g.store(io.rng, i);
         io.core[i] = s;
-        store_desc_head<FUSED>(&io.desc[i], d);
-    }
-    if constexpr (FUSED) {
-        // every word of the descriptor (this wave's hole and head stores) has reached the coherence point before the epochs leave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (leader) {
-            uint32_t* const dw = reinterpret_cast<uint32_t*>(&io.desc[i]);
-            __hip_atomic_store(dw + DW_EPOCH_A, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dw + DW_EPOCH_B, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        store_desc_head(&io.desc[i], d);
     }
 }
 
-#ifndef MG_SPOT_OCC
-#define MG_SPOT_OCC 1
-#endif
-template <bool EN>
-__global__ __launch_bounds__(256, MG_SPOT_OCC) void spot_step_kernel(SpotStepArgs a) {
+template <bool EN, bool PS>
+__global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
     __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
     __shared__ SpotCore core_lds[256 / 16];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gid >> 4;
-    if (i < a.P.n) spot_step_body<EN, false, false>(i, lane_ctx((int)threadIdx.x), a, disc_lds, core_lds, 0u);
-}
-
-// ONE launch per step (uint8 observations; round 4).  Like the mortar family's (mg_mortar.hip mortar_step_raster_kernel): the
-// first `logic_wgs` workgroups run the step -- sixteen lanes per instance, resets included: their 30-us tail now runs beside the
-// frames of the other instances instead of in front of all of them -- every other workgroup is one of the raster's persistent
-// workgroups and waits, per frame, for the descriptor a step wave of the SAME launch publishes (both epoch words of the
-// 128-byte record, SpotDesc).  The two kernels it replaces sat one behind the other: the step kernel 17-21 us (its slowest wave)
-// + a launch gap + the raster 58-61 us.  The step's code needs more registers than the raster's (123 as it stood; written for
-// the purpose, spot_step_body: 80 without scratch), so this launch runs six workgroups per CU where the raster alone runs seven.
-// A frame wave reads its descriptor with ONE vector load (lane k <- word k, agent scope: past the caches) and picks the fields
-// with v_readlane (SpotViewReg): scalars, like the scalar loads of the two-launch raster; the NEXT frame's descriptor is
-// requested together with this frame's template and stamps, so that only a workgroup's first frame pays a round trip for it.
-// Liveness does not rest on dispatch order: claim words per wave-slot (four instances), a frame wave that has polled
-// 200 us steps the slot itself if nobody has claimed it (see the mortar kernel for the argument).
-// LDS: a step workgroup keeps the disc lists and core records of its 16 instances where a frame workgroup keeps its frame.  A
-// frame workgroup needs room for FOUR instances behind the frame and the hole mask: its four waves wait for the same frame, so at
-// most one of them wins that frame's claim and steps a wave-slot at a time.
-constexpr int SPOT_STEP_LDS_PER_INSTANCE = DISC_INTS * 4 + (int)sizeof(SpotCore);
-constexpr int SPOT_FUSED_RESCUE_OFF = (RASTER_LDS + 15) / 16 * 16;
-constexpr int SPOT_FUSED_LDS = SPOT_FUSED_RESCUE_OFF + 4 * SPOT_STEP_LDS_PER_INSTANCE;
-static_assert(16 * SPOT_STEP_LDS_PER_INSTANCE <= RASTER_LDS && SPOT_FUSED_LDS % 16 == 0 && SPOT_FUSED_LDS * 7 <= 160 * 1024, "seven workgroups of the one-launch step per CU");
-// Workgroups per CU: the endless variant's kernel needs 72 VGPRs (seven), the finite one's 80 (six: its reset places up to ten objects).
-// Both only without LLVM's machine-level loop-invariant code motion (this file is compiled with -mllvm -disable-machine-licm,
-// __graft_entry__.py): it hoisted a dozen constants and lane offsets of the step's code out of the kernel's loop and held them in
-// registers across the raster's code, 12-36 B of scratch per lane at 80 VGPRs.
-template <bool EN>
-constexpr int spot_fused_occ() { return EN ? 7 : 6; }
-constexpr unsigned long long SPOT_RESCUE_AFTER_TICKS = 20000;  // 200 us on the 100-MHz real-time clock (see RESCUE_AFTER_TICKS, mg_mortar.hip)
-#define MG_KERNARG_AS __attribute__((address_space(4)))
-// ALL arguments of the launch in one struct = the kernel-argument segment: every iteration of the kernel's loop reads what it needs
-// from the segment through a pointer the compiler cannot see through.  Passed and used the ordinary way, ~50 scalar and ~20
-// vector registers of loop invariants (pointers, the epoch, strides, lane offsets) stayed live across the step's code in the
-// middle of the loop, which needs every register the kernel has: 80 B of scratch per lane, paid at every wave launch.
-struct SpotFusedArgs {
-    SpotStepArgs step;
-    int logic_wgs, logic_base;
-    uint32_t epoch, ticket;
-    uint32_t* claims;
-    uint32_t* rescues;
-    RasterAtlas A;
-    void* obs;
-};
-#ifdef MG_LAB_SPOT_CLOCK  // measurement builds only (tools/spot_timeline.py): four stamps per workgroup, constant-rate clock (10 ns)
-static __device__ unsigned long long g_lab_spot_clock[4 * 16384];
-#define SPOT_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_spot_clock[4 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
-#else
-#define SPOT_CLOCK(slot) do { } while (0)
-#endif
-template <bool EN, bool BORDER, bool NT>
-__global__ __launch_bounds__(256, spot_fused_occ<EN>()) void spot_step_raster_kernel(SpotFusedArgs args) {
-    typedef SpotComposerT<BORDER> Composer;
-    SPOT_CLOCK(0);
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool is_logic = (int)blockIdx.x >= args.logic_base && (int)blockIdx.x < args.logic_base + args.logic_wgs;
-    // the wave-slot (four instances) this wave steps next: a step workgroup's wave starts with its own; a frame wave gets one only
-    // by winning a claim below
-    int slot = is_logic ? ((int)blockIdx.x - args.logic_base) * 4 + wave : -1;
-    int env = is_logic ? args.step.P.n : ((int)blockIdx.x < args.logic_base ? (int)blockIdx.x : (int)blockIdx.x - args.logic_wgs);
-    if (!is_logic) {
-        RasterCtx R0;
-        R0.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
-        R0.tid = threadIdx.x;
-        Composer::recycle(R0);
-        __syncthreads();
-    }
-    uint32_t v = 0u;
-    bool have = false;  // v holds (a snapshot of) descriptor `env`
-    for (;;) {
-        const SpotFusedArgs MG_KERNARG_AS* ka = (const SpotFusedArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane));  // (opaque per iteration: nothing derived from it is kept across the step code, see LaneCtx)
-        const int n = ka->step.P.n;
-        if (slot >= 0) {  // ONE copy of the step's code for both kinds of wave
-            int i = slot * 4 + (lane >> 4);
-            asm volatile("" : "+v"(i));
-            bool mine = true;  // (a frame wave has won the claim already)
-            if (is_logic) {    // a step wave steps its slot unless a frame wave got there first
-                uint32_t old = 0u;
-                if (lane == 0) old = __hip_atomic_exchange(ka->claims + slot, ka->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ka->ticket;
-            }
-            // (group index within the LDS area: a step workgroup's 16 instances in the frame area, a frame wave's four behind it)
-            uint8_t* const area = is_logic ? smem : smem + SPOT_FUSED_RESCUE_OFF;
-            const int groups = is_logic ? 16 : 4;
-            const LaneCtx L{lane & 15, (is_logic ? wave * 4 : 0) + (lane >> 4), (lane >> 4) * 16};
-            if (mine && i < n)
-                spot_step_body<EN, true, false>(i, L, *(const SpotStepArgs*)&ka->step, reinterpret_cast<int*>(area),
-                                                reinterpret_cast<SpotCore*>(area + groups * DISC_INTS * 4), ka->epoch);
-            SPOT_CLOCK(is_logic ? 3 : 2);
-            if (is_logic) return;
-            if (lane == 0) atomicAdd(ka->rescues, 1u);
-            slot = -1;
-            have = false;
-            continue;
-        }
-        if (env >= n) return;
-        const uint32_t epoch = ka->epoch;
-        const int stride = (int)gridDim.x - ka->logic_wgs;
-        const uint32_t* const words = reinterpret_cast<const uint32_t*>(ka->step.io.desc);
-        auto fetch = [&](int e) -> uint32_t {  // lanes 0..31 (and 32..63 again) <- words 0..31 of descriptor e
-            return __hip_atomic_load(words + (size_t)e * DESC_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        if (!have) v = fetch(env);
-        have = true;
-        bool tried = false;
-        unsigned long long t0 = 0;
-        for (int polls = 0;; ++polls) {  // (readlane results are scalars: the wait loop's control is scalar)
-            const DescWordsReg dr{v};
-            if (dr.w(DW_EPOCH_A) == epoch && dr.w(DW_EPOCH_B) == epoch) break;
-            if (polls == 0) t0 = wall_clock64();
-            if (!tried && (polls & 15) == 15 && wall_clock64() - t0 >= SPOT_RESCUE_AFTER_TICKS) {
-                tried = true;  // (a lost claim is not retried: its owner is running)
-                uint32_t old = 0u;
-                if (lane == 0) old = __hip_atomic_exchange(ka->claims + (env >> 2), ka->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != ka->ticket) {
-                    slot = env >> 2;  // nobody has: step the four instances around this frame here
-                    break;
-                }
-            }
-            __builtin_amdgcn_s_sleep(4);
-            v = fetch(env);
-        }
-        if (slot >= 0) continue;
-#ifdef MG_LAB_SPOT_CLOCK
-        if (threadIdx.x == 0 && blockIdx.x < 16384 && g_lab_spot_clock[4 * blockIdx.x + 1] == 0) g_lab_spot_clock[4 * blockIdx.x + 1] = wall_clock64();
-#endif
-        const SpotViewReg d{DescWordsReg{v}};
-        const int next = env + stride;
-        const uint32_t vn = next < n ? fetch(next) : 0u;  // leaves with this frame's loads
-        if (d.valid() == 1u) {
-            RasterCtx R;
-            R.frame = smem;
-            R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
-            R.A.templates = ka->A.templates;
-            R.A.stamp_data = ka->A.stamp_data;
-            R.A.disc_span = ka->A.disc_span;
-            R.A.tables = ka->A.tables;
-            R.T = as_const(ka->A.tables);
-            R.tid = wave * 64 + lane;
-            typename Composer::Pre P;
-            Composer::prefetch_v(d, R, P);
-            Composer::compose_v(d, P, R);
-            __syncthreads();
-            Composer::recycle(R);
-            store_frame<MG_OBS_U8_XYC, NT, true>(smem, ka->obs, env, R.tid);
-            __syncthreads();
-        }
-        v = vn;
-        env = next;
-        SPOT_CLOCK(3);
-    }
+    if (i < a.P.n) spot_step_body<EN, PS>(i, lane_ctx((int)threadIdx.x), a, disc_lds, core_lds);
 }
 
 // The step's raster launch with the put-off resets served inside it: the first workgroups take the queue entries, eight
@@ -1394,9 +1200,10 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
 
 // Debug view: the current descriptors with the agent the reference's debug render shows -- the stored (sprite, rect) pair of
 // the last STEP (stale right after a reset; oracle/mgo_spot.c sp_debug), sprite 0 at the agent's rect before any step.
-__global__ __launch_bounds__(256) void spot_debug_desc_kernel(SpotParams P, SpotIO io, SpotDesc* out) {
+__global__ __launch_bounds__(256) void spot_debug_desc_kernel(SpotParams P0, SpotIO io, SpotDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
+    if (i >= P0.n) return;
+    const SpotParams& P = io.set_of ? io.sets[io.set_of[i]] : P0;
     SpotDesc d = io.desc[i];
     const SpotCore s = io.core[i];
     d.valid = 1;
@@ -1417,13 +1224,12 @@ static __attribute__((noinline)) double cos_only(double x) { volatile double v =
 
 class SpotFamily : public Family {
    public:
-    SpotFamily(int endless, int n) : n_(n) {
+    SpotFamily(int endless, int n) : opt_(one_set()), P_(opt_[0]->P), n_(n) {
         memset(&P_, 0, sizeof(P_));
         P_.endless = endless;
         P_.n = n;
-        spot_min_radius_ = 30.0 * SCALE; spot_max_radius_ = 55.0 * SCALE;
         P_.speed_lo = 0.0025; P_.speed_hi = 0.0075; P_.damage = 1.0;
-        P_.visual_feedback = 1; dim_duration_ = 6; P_.light_threshold = 255;
+        P_.visual_feedback = 1; P_.light_threshold = 255;
         coin_scale_ = 1.5 * SCALE; agent_speed_ = 12.0 * SCALE; agent_scale_ = 1.0 * SCALE; exit_scale_ = 2.0 * SCALE;
         P_.sample_agent_position = 1; P_.show_last_action = 1; P_.show_last_positive_reward = 1;
         P_.r_coin = 0.25;
@@ -1433,7 +1239,7 @@ class SpotFamily : public Family {
         } else {
             P_.max_steps = 256; P_.initial_spawns = 4; P_.num_spawns = 30;
             initial_spawn_interval_ = 30; spawn_interval_threshold_ = 10;
-            st_num_coins_.set(P_.num_coins, {1}); P_.agent_health = 5; P_.r_exit = 1.0;
+            opt_[0]->st_num_coins.set(P_.num_coins, {1}); P_.agent_health = 5; P_.r_exit = 1.0; P_.use_exit = 1;
         }
         core_.alloc(n);
         for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) a->alloc((size_t)SLOTS * n);
@@ -1441,8 +1247,6 @@ class SpotFamily : public Family {
         sp_done_.alloc((size_t)SLOTS * n);
         flags_.alloc(4);
         queue_.alloc((size_t)n + SQ_WORDS);
-        claims_.alloc((size_t)(n + 3) / 4);
-        rescues_.alloc(1);
 
         coins_.alloc((size_t)MAX_COINS * n);
         desc_.alloc(n);
@@ -1462,9 +1266,11 @@ class SpotFamily : public Family {
         }
         cos_.upload(ct);
         sin_.upload(st);
+        sets_dev_.alloc(MG_MAX_OPTION_SETS);
         hipLaunchKernelGGL(spot_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, core_.p);
         MG_HIP(hipDeviceSynchronize());
         rebuild();
+        defaults_ = P_;  // (short lists only: no device arrays behind them)
     }
 
     int action_dim() const override { return 2; }
@@ -1476,56 +1282,80 @@ class SpotFamily : public Family {
         return nullptr;
     }
 
-    void set_option(const std::string& key, const double* v, int n) override {
+    // One key of the reset options, for option set `set` (0 = the handle-wide set of mg_set_option).  Sets > 0 hold everything
+    // that does not change the geometry (atlases, tables and derived constants are shared by the handle's instances); a geometry
+    // option is accepted there when it says what the handle's geometry already is.
+    void set_option(const std::string& key, const double* v, int n) override { set_option_set(0, key, v, n); }
+    void set_option_set(int set, const std::string& key, const double* v, int n) override {
+        if (set < 0 || set >= MG_MAX_OPTION_SETS) throw OptionError{-3, "option set index out of range"};
+        while ((int)opt_.size() <= set) {  // a new set starts from the constructor's defaults (= the reference's), geometry from set 0
+            opt_.emplace_back(new SpotOpt());
+            opt_.back()->P = defaults_;
+            copy_geometry(opt_.back()->P, P_);
+            derive(*opt_.back());
+        }
+        SpotOpt& O = *opt_[set];
+        SpotParams& P = O.P;
         const bool e = P_.endless;
+        // handle-wide values (members of the family) that fix geometry: `member = value` in set 0, "must already be so" elsewhere
+        auto G = [&](double& member, double value) {
+            if (set == 0) { member = value; dirty_ = true; }
+            else if (member != value) throw OptionError{-3, "reset parameter " + key + " changes the geometry shared by the handle's instances: it can only be set for all of them (option set 0)"};
+        };
+        auto GI = [&](int& member, int value) {
+            double m = member;
+            G(m, (double)value);
+            member = (int)m;
+        };
+        sets_dirty_ = true;
         auto I = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
         auto B = [&](int& dst) { dst = v[0] != 0.0; };
         auto must_be = [&](bool ok) { if (!ok) throw OptionError{-3, "reset parameter " + key + ": this value is not supported by the MI355X build"}; };
-        if (key == "max_steps") I(P_.max_steps);
-        else if (key == "initial_spawns") { I(P_.initial_spawns); must_be(P_.initial_spawns >= 0 && P_.initial_spawns <= SLOTS); }
-        else if (key == "spot_min_radius") { spot_min_radius_ = v[0]; dirty_ = true; }
-        else if (key == "spot_max_radius") { spot_max_radius_ = v[0]; dirty_ = true; }
-        else if (key == "spot_min_speed") P_.speed_lo = v[0];
-        else if (key == "spot_max_speed") P_.speed_hi = v[0];
-        else if (key == "spot_damage") P_.damage = v[0];
-        else if (key == "visual_feedback") B(P_.visual_feedback);
+        if (key == "max_steps") I(P.max_steps);
+        else if (key == "initial_spawns") { I(P.initial_spawns); must_be(P.initial_spawns >= 0 && P.initial_spawns <= SLOTS); }
+        else if (key == "spot_min_radius") { O.min_radius = v[0]; derive(O); }
+        else if (key == "spot_max_radius") { O.max_radius = v[0]; derive(O); }
+        else if (key == "spot_min_speed") P.speed_lo = v[0];
+        else if (key == "spot_max_speed") P.speed_hi = v[0];
+        else if (key == "spot_damage") P.damage = v[0];
+        else if (key == "visual_feedback") B(P.visual_feedback);
         else if (key == "black_background") {
-            B(P_.black_background);
-            if (P_.black_background && !P_.ordered_holes) {  // from now on spotlights may carry a border (sticky, kept in the state)
+            B(P.black_background);
+            if (P.black_background && !P_.ordered_holes) {  // from now on spotlights may carry a border (sticky, kept in the state)
                 P_.ordered_holes = 1;
                 const int one = 1;
                 MG_HIP(hipMemcpy(flags_.p, &one, sizeof(int), hipMemcpyHostToDevice));
             }
         }
-        else if (key == "hide_chessboard") B(P_.hide_chessboard);
-        else if (key == "light_dim_off_duration") { I(dim_duration_); dirty_ = true; }
-        else if (key == "light_threshold") I(P_.light_threshold);
-        else if (key == "coin_scale") { coin_scale_ = v[0]; dirty_ = true; }
-        else if (key == "coins_visible") B(P_.coins_visible);
-        else if (key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
-        else if (key == "agent_health") P_.agent_health = v[0];
-        else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
-        else if (key == "agent_visible") P_.layer_flags = (P_.layer_flags & ~LAYER_AGENT_TOP) | (v[0] != 0.0 ? LAYER_AGENT_TOP : 0);
-        else if (key == "sample_agent_position") B(P_.sample_agent_position);
+        else if (key == "hide_chessboard") B(P.hide_chessboard);
+        else if (key == "light_dim_off_duration") { O.dim_duration = to_int_checked(v[0], key.c_str()); derive(O); }
+        else if (key == "light_threshold") I(P.light_threshold);
+        else if (key == "coin_scale") G(coin_scale_, v[0]);
+        else if (key == "coins_visible") B(P.coins_visible);
+        else if (key == "agent_speed") G(agent_speed_, v[0]);
+        else if (key == "agent_health") P.agent_health = v[0];
+        else if (key == "agent_scale") G(agent_scale_, v[0]);
+        else if (key == "agent_visible") P.layer_flags = (P.layer_flags & ~LAYER_AGENT_TOP) | (v[0] != 0.0 ? LAYER_AGENT_TOP : 0);
+        else if (key == "sample_agent_position") B(P.sample_agent_position);
         else if (key == "show_last_action") {
-            B(P_.show_last_action);
-            dirty_ = true;  // the last-reward bar's position and width depend on it (searing_spotlights.py:385-390)
+            // (the last-reward bar's position and width depend on it, searing_spotlights.py:385-390: geometry)
+            GI(P_.show_last_action, v[0] != 0.0 ? 1 : 0);
             // False crashes the ENDLESS reference at its first step (endless_searing_spotlights.py:422 reads action_colors,
             // which :343 only creates when the flag is set); the finite env guards the use (searing_spotlights.py:465)
-            if (e) must_be(P_.show_last_action != 0);
+            if (e) must_be(v[0] != 0.0);
         }
-        else if (key == "show_last_positive_reward") B(P_.show_last_positive_reward);
-        else if (key == "reward_inside_spotlight") P_.r_inside = v[0];
-        else if (key == "reward_outside_spotlight") P_.r_outside = v[0];
-        else if (key == "reward_death") P_.r_death = v[0];
-        else if (key == "reward_coin") P_.r_coin = v[0];
-        else if (e && key == "steps_per_coin") I(P_.steps_per_coin);
-        else if (e && key == "spawn_interval") I(P_.spawn_interval);
-        else if (e && key == "coin_enabled") B(P_.coin_enabled);
-        else if (e && key == "coin_show_duration") I(P_.coin_show_duration);
-        else if (!e && key == "num_spawns") { I(P_.num_spawns); must_be(P_.num_spawns >= 0 && P_.num_spawns <= 255); }
-        else if (!e && key == "initial_spawn_interval") { initial_spawn_interval_ = v[0]; dirty_ = true; }
-        else if (!e && key == "spawn_interval_threshold") { spawn_interval_threshold_ = v[0]; dirty_ = true; }
+        else if (key == "show_last_positive_reward") B(P.show_last_positive_reward);
+        else if (key == "reward_inside_spotlight") P.r_inside = v[0];
+        else if (key == "reward_outside_spotlight") P.r_outside = v[0];
+        else if (key == "reward_death") P.r_death = v[0];
+        else if (key == "reward_coin") P.r_coin = v[0];
+        else if (e && key == "steps_per_coin") I(P.steps_per_coin);
+        else if (e && key == "spawn_interval") I(P.spawn_interval);
+        else if (e && key == "coin_enabled") B(P.coin_enabled);
+        else if (e && key == "coin_show_duration") I(P.coin_show_duration);
+        else if (!e && key == "num_spawns") { I(P.num_spawns); must_be(P.num_spawns >= 0 && P.num_spawns <= 255); }
+        else if (!e && key == "initial_spawn_interval") G(initial_spawn_interval_, v[0]);
+        else if (!e && key == "spawn_interval_threshold") G(spawn_interval_threshold_, v[0]);
         else if (!e && key == "spawn_interval_decay") { /* only intervals[0] is ever read (pop() takes the last) */ }
         else if (!e && key == "num_coins") {
             // any length (searing_spotlights.py:408); the empty list is refused by mg_set_option: the reference ends every such
@@ -1535,34 +1365,47 @@ class SpotFamily : public Family {
                 vals[k] = to_int_checked(v[k], key.c_str());
                 must_be(vals[k] >= 1 && vals[k] <= MAX_COINS);
             }
-            st_num_coins_.set(P_.num_coins, vals);
+            O.st_num_coins.set(P.num_coins, vals);
         }
-        else if (!e && key == "use_exit") must_be(v[0] != 0.0);  // use_exit=False crashes the reference itself
-        else if (!e && key == "exit_scale") { exit_scale_ = v[0]; dirty_ = true; }
-        else if (!e && key == "exit_visible") P_.layer_flags = (P_.layer_flags & ~LAYER_EXIT_ABOVE) | (v[0] != 0.0 ? LAYER_EXIT_ABOVE : 0);
-        else if (!e && key == "reward_exit") P_.r_exit = v[0];
+        // False: legal once the instance has had an exit (its stale one is drawn, spot_reset); before that the reference raises
+        // AttributeError and the reset raises error bit 256
+        else if (!e && key == "use_exit") B(P.use_exit);
+        else if (!e && key == "exit_scale") G(exit_scale_, v[0]);
+        else if (!e && key == "exit_visible") P.layer_flags = (P.layer_flags & ~LAYER_EXIT_ABOVE) | (v[0] != 0.0 ? LAYER_EXIT_ABOVE : 0);
+        else if (!e && key == "reward_exit") P.r_exit = v[0];
         else if (!e && key == "reward_max_steps") {}
         else throw OptionError{-2, "unknown reset parameter " + key};
     }
+    // instance i runs under option set set_of_dev[i] (device array [num_envs], caller-owned; NULL: every instance under set 0)
+    void bind_option_sets(const int32_t* set_of_dev) override { set_of_ = set_of_dev; }
 
     void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) override {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
-        {   // 16 spotlight slots per instance.  Refuse option sets that overflow them in ANY episode that lasts as long
+        for (auto& O : opt_) {   // 16 spotlight slots per instance.  Refuse option sets that overflow them in ANY episode that lasts as long
             // as the fastest spotlight lives (t reaches 1 after ceil(1 / speed) steps, the slot is freed one step later);
             // rarer overflows raise error bit 1, which mg_peek_errors shows without a synchronisation.
-            const int life_min = (int)std::ceil(1.0 / P_.speed_hi) + 1;
-            const int interval = P_.endless ? P_.spawn_interval : P_.interval0;
+            const SpotParams& Q = O->P;
+            if (Q.r_hi <= Q.r_lo) throw OptionError{-3, "spot radius range not supported"};
+            const int life_min = (int)std::ceil(1.0 / Q.speed_hi) + 1;
+            const int interval = P_.endless ? Q.spawn_interval : P_.interval0;
             int later = interval > 0 ? (life_min - 1) / interval : 1 << 20;
-            if (!P_.endless && later > P_.num_spawns) later = P_.num_spawns;
-            if (P_.initial_spawns + later > SLOTS)
-                throw std::runtime_error("these options keep " + std::to_string(P_.initial_spawns + later) +
+            if (!P_.endless && later > Q.num_spawns) later = Q.num_spawns;
+            if (Q.initial_spawns + later > SLOTS)
+                throw std::runtime_error("these options keep " + std::to_string(Q.initial_spawns + later) +
                                          " spotlights alive at once; this build holds " + std::to_string(SLOTS) +
                                          " per instance (raise spawn_interval / spot_max_speed or lower initial_spawns)");
         }
         if (seeds) seeded_ = true;
-        if (P_.endless) hipLaunchKernelGGL(spot_reset_kernel<true>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
-        else hipLaunchKernelGGL(spot_reset_kernel<false>, dim3((n_ * SLOTS + 255) / 256), dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        upload_sets(s);
+        const dim3 rg((n_ * SLOTS + 255) / 256);
+        if (P_.endless) {
+            if (per_set()) hipLaunchKernelGGL((spot_reset_kernel<true, true>), rg, dim3(256), 0, s, P_, io(), seeds, mask, gt);
+            else hipLaunchKernelGGL((spot_reset_kernel<true, false>), rg, dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        } else {
+            if (per_set()) hipLaunchKernelGGL((spot_reset_kernel<false, true>), rg, dim3(256), 0, s, P_, io(), seeds, mask, gt);
+            else hipLaunchKernelGGL((spot_reset_kernel<false, false>), rg, dim3(256), 0, s, P_, io(), seeds, mask, gt);
+        }
         raster(obs, s);
     }
 
@@ -1572,39 +1415,20 @@ class SpotFamily : public Family {
         mg_info_buffers ib;
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
-        if (obs_format == MG_OBS_U8_XYC && one_launch(n_) && !logic_event && !capturing(s)) {  // spot_step_raster_kernel
-            epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never what a reset's or a two-launch step's descriptors carry in their epoch words
-            ++ticket_;
-            SpotFusedArgs fa;
-            fa.step = SpotStepArgs{P_, io(), actions, reward, done, gt, ib, autoreset, 0};
-            fa.logic_wgs = (n_ + 15) / 16;
-            const int frames = n_ < raster_grid(n_) ? n_ : raster_grid(n_);
-            static const bool logic_last = lab_int("MEMGYM_LAB_LOGIC_LAST", 0) != 0;  // lab build: the dispatch order the design must survive
-            fa.logic_base = logic_last ? frames : 0;
-            fa.epoch = epoch_;
-            fa.ticket = ticket_;
-            fa.claims = claims_.p;
-            fa.rescues = rescues_.p;
-            fa.A = atlas_->dev();
-            fa.obs = obs;
-            const dim3 grid(fa.logic_wgs + frames);
-            const bool nt = raster_nt(n_);
-            prof.begin(1, s);
-#define SPOT_ONE(EN, BO) do { if (nt) hipLaunchKernelGGL((spot_step_raster_kernel<EN, BO, true>), grid, dim3(256), SPOT_FUSED_LDS, s, fa); \
-                              else hipLaunchKernelGGL((spot_step_raster_kernel<EN, BO, false>), grid, dim3(256), SPOT_FUSED_LDS, s, fa); } while (0)
-            if (P_.endless) { if (P_.ordered_holes) SPOT_ONE(true, true); else SPOT_ONE(true, false); }
-            else { if (P_.ordered_holes) SPOT_ONE(false, true); else SPOT_ONE(false, false); }
-#undef SPOT_ONE
-            MG_HIP(hipGetLastError());
-            prof.end(1, s);
-            return;
-        }
+        upload_sets(s);
         prof.begin(0, s);
-        const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets()) ? 1 : 0;
+        // (resets served inside the raster launch: handles with ONE option set -- the service code takes its parameters from the launch's arguments)
+        const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets() && !per_set()) ? 1 : 0;
         const int sb = step_block(256);
         const SpotStepArgs sa{P_, io(), actions, reward, done, gt, ib, autoreset, defer};
-        if (P_.endless) hipLaunchKernelGGL(spot_step_kernel<true>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, sa);
-        else hipLaunchKernelGGL(spot_step_kernel<false>, dim3((n_ * SLOTS + sb - 1) / sb), dim3(sb), 0, s, sa);
+        const dim3 sg((n_ * SLOTS + sb - 1) / sb);
+        if (P_.endless) {
+            if (per_set()) hipLaunchKernelGGL((spot_step_kernel<true, true>), sg, dim3(sb), 0, s, sa);
+            else hipLaunchKernelGGL((spot_step_kernel<true, false>), sg, dim3(sb), 0, s, sa);
+        } else {
+            if (per_set()) hipLaunchKernelGGL((spot_step_kernel<false, true>), sg, dim3(sb), 0, s, sa);
+            else hipLaunchKernelGGL((spot_step_kernel<false, false>), sg, dim3(sb), 0, s, sa);
+        }
         end_logic(s);
         prof.begin(1, s);
         if (defer) {
@@ -1636,26 +1460,8 @@ class SpotFamily : public Family {
         return err_.take();
     }
     int peek_errors() override { return err_.peek(); }
-    bool debug_counter(const std::string& name, int64_t* out) override {
-        if (name != "one_launch_rescues") return false;  // wave-slots (four instances) stepped by a frame wave since the handle was created
-        uint32_t v = 0;
-        MG_HIP(hipMemcpy(&v, rescues_.p, sizeof v, hipMemcpyDeviceToHost));
-        *out = (int64_t)v;
-        return true;
-    }
 
    private:
-    uint32_t epoch_ = 0, ticket_ = 0;  // the one-launch step's descriptor epoch (1 .. 255) and claim ticket (the step's number)
-    // The one-launch step by launch size (first measurement, profiles/r04_spot_one_launch.md: 65,536 instances 228 vs 215-222 M
-    // env-steps/s, 16,384 instances 199-201 vs 208-210 M).  Lab build: MEMGYM_SPOT_ONE_LAUNCH=0 / 1 forces it off / on.
-    static bool one_launch(int n) {
-        static const int forced = lab_int("MEMGYM_SPOT_ONE_LAUNCH", -1);
-        return forced >= 0 ? forced != 0 : n >= 32768;
-    }
-    static bool capturing(hipStream_t s) {  // (epoch and ticket are launch arguments: a replayed graph would find them satisfied)
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
-    }
     SpotIO io() {
         SpotIO o;
         o.core = core_.p;
@@ -1668,6 +1474,8 @@ class SpotFamily : public Family {
         o.err = err_.dev;
         o.queue = queue_.p + SQ_WORDS;
         o.qctr = queue_.p;
+        o.sets = per_set() ? sets_dev_.p : nullptr;
+        o.set_of = per_set() ? set_of_ : nullptr;
         return o;
     }
 
@@ -1682,11 +1490,10 @@ class SpotFamily : public Family {
         double inv = 1.0 / std::sqrt(2.0);
         P_.v_axis_i = (int)((1.0 / 1.0) * agent_speed_);
         P_.v_diag_i = (int)(inv * agent_speed_);
-        P_.r_lo = (int)spot_min_radius_;
-        P_.r_hi = (int)(spot_max_radius_ + 1);
-        if (P_.r_hi - 1 > DISC_RMAX || P_.r_lo < 1 || P_.r_hi <= P_.r_lo) throw OptionError{-3, "spot radius range not supported"};
-        P_.dim_duration = dim_duration_;
-        P_.dim_step = dim_duration_ > 0 ? (int)(255.0 / dim_duration_) : 0;
+        for (auto& O : opt_) {
+            derive(*O);
+            if (O->P.r_hi <= O->P.r_lo) throw OptionError{-3, "spot radius range not supported"};
+        }
         P_.coin_radius = (int)(10 * coin_scale_);
         P_.spawn_clamp = (int)(30 * SCALE);
         P_.quarter = (int)(SCREEN / 4);
@@ -1710,6 +1517,59 @@ class SpotFamily : public Family {
         atlas_->set_templates(build_chessboards(SCALE, SCREEN));
         atlas_->upload();
         dirty_ = false;
+        for (size_t k = 1; k < opt_.size(); ++k) copy_geometry(opt_[k]->P, P_);
+        copy_geometry(defaults_, P_);
+        {   // (the defaults' own radius / dim values, whatever set 0 holds by now)
+            SpotOpt D;
+            D.P = defaults_;
+            derive(D);
+            defaults_ = D.P;
+        }
+        sets_dirty_ = true;
+    }
+
+    // per-instance option sets
+    struct SpotOpt {
+        SpotParams P;
+        OptListStore st_num_coins;
+        double min_radius = 30.0 * 0.25, max_radius = 55.0 * 0.25;  // spot_min_radius / spot_max_radius (defaults x SCALE)
+        int dim_duration = 6;                                      // light_dim_off_duration
+    };
+    // what a set's radius and dim options mean for the kernels (pure logic: the disc span table covers every radius up to DISC_RMAX)
+    static void derive(SpotOpt& O) {
+        const int r_lo = (int)O.min_radius, r_hi = (int)(O.max_radius + 1);
+        // (both bounds travel through set_option one at a time: only a pair that is complete nonsense is refused here, the range
+        // as a whole again by rebuild() / the reset that uses it)
+        if (r_hi - 1 > DISC_RMAX || r_lo < 1) throw OptionError{-3, "spot radius range not supported"};
+        O.P.r_lo = r_lo;
+        O.P.r_hi = r_hi;
+        O.P.dim_duration = O.dim_duration;
+        O.P.dim_step = O.dim_duration > 0 ? (int)(255.0 / O.dim_duration) : 0;
+    }
+    static std::vector<std::unique_ptr<SpotOpt>> one_set() {
+        std::vector<std::unique_ptr<SpotOpt>> v;
+        v.emplace_back(new SpotOpt());
+        return v;
+    }
+    // what the shared atlases, tables and derived constants fix for every set of the handle
+    static void copy_geometry(SpotParams& d, const SpotParams& s) {
+        d.endless = s.endless; d.n = s.n; d.ordered_holes = s.ordered_holes;
+        d.show_last_action = s.show_last_action; d.agent_radius = s.agent_radius; d.sprite_half = s.sprite_half;
+        d.coin_radius = s.coin_radius; d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.spawn_clamp = s.spawn_clamp; d.bar_x = s.bar_x;
+        d.bar_w = s.bar_w; d.quarter = s.quarter; d.bar_h = s.bar_h; d.exit_half = s.exit_half; d.half_diag = s.half_diag;
+        d.exit_radius = s.exit_radius; d.interval0 = s.interval0; d.cos_tab = s.cos_tab; d.sin_tab = s.sin_tab;
+    }
+    bool per_set() const { return set_of_ != nullptr && opt_.size() > 1; }
+    void upload_sets(hipStream_t s) {
+        if (!per_set() || !sets_dirty_) return;
+        std::vector<SpotParams> host(MG_MAX_OPTION_SETS, P_);
+        for (size_t k = 0; k < opt_.size(); ++k) {
+            copy_geometry(opt_[k]->P, P_);  // (ordered_holes may have been switched on since the last rebuild)
+            host[k] = opt_[k]->P;
+        }
+        MG_HIP(hipMemcpyAsync(sets_dev_.p, host.data(), sizeof(SpotParams) * host.size(), hipMemcpyHostToDevice, s));
+        MG_HIP(hipStreamSynchronize(s));  // (rare: only after an option of some set changed)
+        sets_dirty_ = false;
     }
 
     void raster_only(void* obs, const uint8_t* only, hipStream_t s) override {
@@ -1744,11 +1604,15 @@ class SpotFamily : public Family {
         return forced >= 0 ? forced != 0 : (!P_.endless && n_ <= FUSE_MAX);
     }
 
+    std::vector<std::unique_ptr<SpotOpt>> opt_;  // [0] = the handle-wide set (P_ below is its parameter block)
+    SpotParams& P_;
+    SpotParams defaults_;
+    const int32_t* set_of_ = nullptr;
+    bool sets_dirty_ = true;
+    DevArray<SpotParams> sets_dev_;
     int n_;
-    SpotParams P_;
-    double spot_min_radius_, spot_max_radius_, coin_scale_, agent_speed_, agent_scale_, exit_scale_;
+    double coin_scale_, agent_speed_, agent_scale_, exit_scale_;
     double initial_spawn_interval_ = 30, spawn_interval_threshold_ = 10;
-    int dim_duration_;
     bool dirty_ = true, seeded_ = false;
 
    public:
@@ -1757,6 +1621,7 @@ class SpotFamily : public Family {
         int f = 0;
         MG_HIP(hipMemcpy(&f, flags_.p, sizeof(int), hipMemcpyDeviceToHost));
         if (f) P_.ordered_holes = 1;
+        sets_dirty_ = true;
     }
     void raster_debug(void* frames, hipStream_t s) override;
 
@@ -1765,14 +1630,12 @@ class SpotFamily : public Family {
     DevArray<SpotCore> core_;
     DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;
     DevArray<uint8_t> sp_r_, sp_done_;
-    DevArray<uint32_t> claims_, rescues_;  // one-launch step: one claim word per wave-slot (four instances); slots stepped by frame waves
     DevArray<int> queue_;  // deferred resets: the counters + n entries
     DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)
     DevArray<uint32_t> coins_;
     DevArray<SpotDesc> desc_;
     ErrorWord err_;
     RngStore rng_;
-    OptListStore st_num_coins_;
 };
 
 void SpotFamily::raster_debug(void* frames, hipStream_t s) {
@@ -1789,14 +1652,3 @@ void SpotFamily::raster_debug(void* frames, hipStream_t s) {
 Family* make_spot(int endless, int num_envs) { return new SpotFamily(endless, num_envs); }
 
 }  // namespace mg
-
-#ifdef MG_LAB_SPOT_CLOCK
-extern "C" int mg_lab_spot_clock(unsigned long long* host, int n_wgs, int clear) {
-    if (clear) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mg::g_lab_spot_clock)) != hipSuccess) return -1;
-        return hipMemset(p, 0, sizeof(unsigned long long) * 4 * 16384) == hipSuccess ? 0 : -1;
-    }
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_spot_clock), sizeof(unsigned long long) * 4 * (size_t)n_wgs) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -14,6 +14,7 @@ PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("MEMGYM_HIP_LIB", os.path.join(PKG_ROOT, "lib", "libmemgym_hip.so"))
 
 MG_INFO_SLOTS = 8
+MG_MAX_OPTION_SETS = 8
 
 
 class InfoBuffers(C.Structure):
@@ -72,6 +73,9 @@ def _load():
     L.mg_obs_debug_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.mg_enable_peer_access.argtypes = [C.c_int, C.c_int]
     L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    if hasattr(L, "mg_set_option_set"):
+        L.mg_set_option_set.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_int]
+        L.mg_bind_option_sets.argtypes = [C.c_void_p, C.c_void_p]
     if hasattr(L, "mg_debug_counter"):  # (absent from builds of earlier rounds that tools/ A/B against through MEMGYM_HIP_LIB)
         L.mg_debug_counter.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     return L

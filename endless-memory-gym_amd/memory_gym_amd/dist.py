@@ -147,6 +147,7 @@ class PeerObsBuffer:
         payload = [None]
         if self.rank == dst:
             self.full = torch.empty((int(n_total),) + tuple(frame_shape), dtype=dtype, device=self.device)
+            self._check_exportable(self.full)
             payload[0] = reduce_tensor(self.full)  # (rebuild function, picklable arguments incl. the IPC handle)
         dist.broadcast_object_list(payload, src=dst, group=group)
         if self.rank != dst:
@@ -155,6 +156,16 @@ class PeerObsBuffer:
         lo, hi = shard_range(n_total, self.rank, self.world)
         self.local = self.full[lo:hi]
         self._token = torch.zeros(1, device=self.device)
+
+    @staticmethod
+    def _check_exportable(tensor):
+        """hipIpcGetMemHandle works on hipMalloc allocations only; a zone-balanced buffer (mg_obs_alloc: hipMemCreate pieces in a
+        reserved virtual range) would fail late and cryptically inside torch's reduce_tensor.  Refuse it here, by name."""
+        from .vec_env import is_balanced_buffer
+        if is_balanced_buffer(tensor):
+            raise ValueError("PeerObsBuffer: a buffer from mg_obs_alloc (obs_placement='balanced') cannot be exported through HIP IPC; "
+                             "share an ordinary allocation (torch.empty) -- its rows are filled over xGMI at a fifth of one memory "
+                             "zone's rate, placement does not matter for it (DESIGN.md section 6)")
 
     def fence(self):
         """Stream-ordered on the nccl backend (a 4-byte all-reduce enqueued behind this rank's kernels); on gloo the

@@ -15,6 +15,7 @@ stream and return torch tensors that alias the kernels' output buffers (no copie
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -55,11 +56,24 @@ def _spaces(action_dim, gt_dim, vec_dim=0):
     return act, obs, gt
 
 
+_BALANCED = weakref.WeakSet()  # live mg_obs_alloc buffers of this process
+
+
+def is_balanced_buffer(tensor):
+    """True if `tensor` lies in memory obtained from mg_obs_alloc (HIP virtual memory: physical pieces mapped into a reserved
+    range).  Such memory has no IPC handle (hipIpcGetMemHandle needs a hipMalloc allocation): memory_gym_amd.dist.PeerObsBuffer
+    refuses to export it; collectives (RCCL) and peer access work on it like on any device memory."""
+    p = tensor.data_ptr()
+    return any(o.ptr is not None and o.ptr <= p < o.ptr + o.nbytes for o in _BALANCED)
+
+
 class _ObsMemory:
     """Owner of a device buffer obtained from mg_obs_alloc; tensors made from it keep it alive (CUDA array interface)."""
 
     def __init__(self, ptr, shape, typestr, info):
         self.ptr, self.info = ptr, info
+        self.nbytes = int(np.prod(shape))
+        _BALANCED.add(self)
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
 
     def __del__(self):
@@ -188,30 +202,72 @@ class VecMemoryGym:
         self._info.reward64_dev = self.reward64.data_ptr()
         self.reset_params = process_reset_params(env_id, None)
         self._applied = dict(DEFAULTS[env_id])
+        self._set_params = [self._applied]  # what each option set of the handle holds (set 0 = the handle-wide one)
+        self._set_of = None                 # int32 [N]: the set instance i runs under, once a masked reset has used other options
         self.max_episode_steps = None
         self.autoreset = True
         self._seeded = False  # no instance has an RNG stream before the first reset (or load_state_dict)
+        self._swapped = False  # use_obs_buffer() since the last call that wrote every row
         self._truncated = torch.zeros(N, dtype=torch.bool, device=dev)  # `truncation` is always False in the reference
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _apply_options(self, options):
-        params = process_reset_params(self.env_id, options)
+    def _write_set(self, set_id, params):
+        """Bring option set `set_id` of the handle to `params` (only the keys that differ from what it holds are sent)."""
+        have = self._set_params[set_id]
         for k, v in params.items():
-            if self._applied.get(k, None) == v and k in self._applied:
+            if k in have and have[k] == v:
                 continue
             vals = [float(x) for x in v] if isinstance(v, (list, tuple, np.ndarray)) else [float(v)]
             arr = (C.c_double * len(vals))(*vals)
-            rc = _native.LIB.mg_set_option(self._h, k.encode(), arr, len(vals))
+            if set_id == 0:
+                rc = _native.LIB.mg_set_option(self._h, k.encode(), arr, len(vals))
+            else:
+                rc = _native.LIB.mg_set_option_set(self._h, set_id, k.encode(), arr, len(vals))
             if rc == -2:
                 raise AssertionError("Provided reset parameter (" + str(k) + ") is not valid. Check spelling.")
             if rc == -4:
                 raise AssertionError(_native.last_error())
             if rc != 0:
-                raise NotImplementedError("reset parameter %s=%r: %s" % (k, v, _native.last_error()))
-            self._applied[k] = v
+                raise NotImplementedError("reset parameter %s=%r%s: %s" % (k, v, "" if set_id == 0 else " for a subset of the instances", _native.last_error()))
+            have[k] = v
+
+    def _apply_options_masked(self, options, mask):
+        """reset(options=..., mask=...): like the reference's reset(seed, options) of ONE instance (mortar_mayhem_grid.py:213-236),
+        the options belong to the instances that are being reset and to nobody else.  The handle keeps up to
+        MG_MAX_OPTION_SETS parameter sets (include/memgym.h: mg_set_option_set); the masked instances are moved to the set that
+        holds these options (a free one is filled if none does).  options=None keeps every masked instance under the options it
+        has (a masked reset is this library's extension -- the re-start of finished instances; it is reset(mask=None, options=None)
+        that means "the defaults for everybody", like the reference's)."""
+        if options is None:
+            return
+        params = process_reset_params(self.env_id, options)
+        k = next((j for j, p in enumerate(self._set_params) if p == params), None)
+        if k == 0 and self._set_of is None:
+            return  # everybody runs under these options already
+        if k is None:
+            used = set([0])
+            if self._set_of is not None:
+                used |= set(torch.unique(self._set_of).cpu().tolist())  # (synchronises: only when a new set is needed)
+            free = [j for j in range(1, _native.MG_MAX_OPTION_SETS) if j not in used]
+            if not free:
+                raise NotImplementedError("more than %d different option sets alive in one handle" % _native.MG_MAX_OPTION_SETS)
+            k = free[0]
+            while len(self._set_params) <= k:
+                self._set_params.append(dict(DEFAULTS[self.env_id]))
+            self._write_set(k, params)
+        if self._set_of is None:
+            self._set_of = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            _native.check(_native.LIB.mg_bind_option_sets(self._h, self._set_of.data_ptr()), "mg_bind_option_sets")
+        self._set_of[mask.to(device=self.device, dtype=torch.bool)] = k
+
+    def _apply_options(self, options):
+        params = process_reset_params(self.env_id, options)
+        self._write_set(0, params)
+        if self._set_of is not None:
+            self._set_of.zero_()  # a reset of every instance: all of them run under these options
         self.reset_params = params
         if self.env_id in ("MortarMayhemB-Grid-v0", "MortarMayhemB-v0"):  # mortar_mayhem_b_grid.py:149-153
             self.max_episode_steps = calc_max_episode_steps(
@@ -242,13 +298,24 @@ class VecMemoryGym:
 
     # ------------------------------------------------------------------ API
     def reset(self, seed=None, return_info=True, options=None, mask=None):
-        """Env.reset(seed, options) for all instances (or those selected by the bool/uint8 tensor `mask`)."""
+        """Env.reset(seed, options) for all instances, or for those selected by the bool/uint8 tensor `mask`: the options then belong
+        to those instances only (per-instance option sets, include/memgym.h: mg_set_option_set); mask with options=None re-starts
+        them under the options each of them has."""
         with torch.cuda.device(self.device):
-            self._apply_options(options)
+            if mask is None:
+                self._apply_options(options)
+            else:
+                self._apply_options_masked(options, mask)
             if mask is not None and seed is None and not self._seeded:
                 raise RuntimeError("a masked reset(seed=None) needs an earlier full reset: the other instances have no RNG stream yet")
             s = self._seed_tensor(seed)
             m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if m is not None and self._swapped:
+                # a masked reset writes the rows of the masked instances only; after use_obs_buffer() the other rows of the new
+                # buffer hold whatever was there: draw every instance's CURRENT frame into it first (one raster launch, this
+                # sequence only).  (Rows a masked reset had left untouched right before the swap stay as they are: mg_render.)
+                _native.check(_native.LIB.mg_render(self._h, self.obs.data_ptr(), self._stream()), "mg_render")
+            self._swapped = False
             _native.check(_native.LIB.mg_reset(self._h, None if s is None else s.data_ptr(),
                                                None if m is None else m.data_ptr(), self.obs.data_ptr(),
                                                self.gt.data_ptr() if self.gt_dim else None, self._stream()), "mg_reset")
@@ -264,6 +331,7 @@ class VecMemoryGym:
             _native.check(_native.LIB.mg_step(self._h, a.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
                                               self.done_u8.data_ptr(), self.gt.data_ptr() if self.gt_dim else None,
                                               C.byref(self._info), int(self.autoreset), self._stream()), "mg_step")
+            self._swapped = False  # a step writes every row
         _native.LIB.mg_peek_errors(self._h, C.byref(self._err))  # host-mapped word: no synchronisation
         if self._err.value:
             self.check_errors()
@@ -291,10 +359,13 @@ class VecMemoryGym:
     def use_obs_buffer(self, tensor):
         """Make `tensor` (same shape / dtype / device as `obs`) the buffer the NEXT reset / step writes its observations to
         (mg_step takes the buffer per call).  A consumer that still reads the previous buffer -- e.g. a gather to another
-        rank running beside the next step (memory_gym_amd.dist.ObsGatherer) -- alternates between two buffers this way."""
+        rank running beside the next step (memory_gym_amd.dist.ObsGatherer) -- alternates between two buffers this way.
+        A step() or a full reset() writes every row of the new buffer; a MASKED reset right after a swap first draws the
+        current frame of every instance into it (the rows it does not reset would otherwise be stale)."""
         if tuple(tensor.shape) != tuple(self.obs.shape) or tensor.dtype != self.obs.dtype or tensor.device != self.obs.device or not tensor.is_contiguous():
             raise ValueError("use_obs_buffer: need a contiguous tensor like env.obs")
         self.obs = tensor
+        self._swapped = True
 
     def _obs(self):
         if self.vector_obs is None:
@@ -323,7 +394,11 @@ class VecMemoryGym:
         with torch.cuda.device(self.device):
             _native.check(_native.LIB.mg_get_state(self._h, buf.ctypes.data, n), "mg_get_state")
         # the reset options in force belong to the state: geometry, schedules and limits are derived from them
-        return {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf, "options": dict(self._applied), "seeded": self._seeded}
+        sd = {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf, "options": dict(self._applied), "seeded": self._seeded}
+        if self._set_of is not None:  # per-instance option sets in use
+            sd["option_sets"] = [dict(p) for p in self._set_params]
+            sd["set_of"] = self._set_of.cpu().numpy()
+        return sd
 
     def load_state_dict(self, sd):
         """Restore a checkpoint, also into a handle that was never reset: the options in force when it was taken are
@@ -334,6 +409,18 @@ class VecMemoryGym:
             if opts is not None and any(self._applied.get(k) != v for k, v in opts.items()):
                 # options only take effect at a reset: do one (its frames and RNG consumption are overwritten right below)
                 self.reset(seed=0, options={k: v for k, v in opts.items() if k in DEFAULTS[self.env_id]})
+            if sd.get("option_sets") is not None:
+                for k, p in enumerate(sd["option_sets"]):
+                    while len(self._set_params) <= k:
+                        self._set_params.append(dict(DEFAULTS[self.env_id]))
+                    if k > 0:
+                        self._write_set(k, {kk: vv for kk, vv in p.items() if kk in DEFAULTS[self.env_id]})
+                if self._set_of is None:
+                    self._set_of = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+                    _native.check(_native.LIB.mg_bind_option_sets(self._h, self._set_of.data_ptr()), "mg_bind_option_sets")
+                self._set_of.copy_(torch.as_tensor(np.asarray(sd["set_of"], dtype=np.int32), device=self.device))
+            elif self._set_of is not None:
+                self._set_of.zero_()
             buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
             _native.check(_native.LIB.mg_set_state(self._h, buf.ctypes.data, buf.size), "mg_set_state")
             self._seeded = bool(sd.get("seeded", True))  # (env.obs shows the restored episodes from the next step on)
@@ -353,7 +440,8 @@ class VecMemoryGym:
                   4: "endless path longer than 128 segments", 8: "more than 128 distinct fall-off cells",
                   16: "past-path window wider than 16 columns",
                   32: "Endless Mortar Mayhem command list reached its 512-entry capacity (the episode was ended)",
-                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)"}
+                  64: "a deferred-reset queue overflowed (a previous fused launch did not drain it)",
+                  256: "use_exit=False for an instance that never had an exit (the reference raises AttributeError at this reset)"}
 
     def check_errors(self):
         """Raise if a kernel flagged a capacity/failure condition since the last call (synchronises the device).

@@ -33,8 +33,9 @@ typedef struct mg_env mg_env;
  * all arrays [num_envs]; any pointer may be NULL.  `aux[k]` meaning per env id: see mg_info_name(). */
 typedef struct mg_info_buffers {
     /* Versioning: set to sizeof(mg_info_buffers) of the header the caller was built against.  The library reads that many
-     * bytes (never more than it knows) and treats the fields a shorter, older struct lacks as NULL; 0 or any size that
-     * cannot be a layout of this header is refused (-1) instead of the struct being read past its end. */
+     * bytes (never more than it knows) and treats the fields a shorter, older struct lacks as NULL; 0, a size that is not a
+     * multiple of the pointer size, or one larger than this build's struct plus 16 pointers (e.g. the device pointer a
+     * caller built against the round-2 header -- which had no such member -- passes in this place) is refused (-1). */
     size_t struct_size;
     double* ep_reward_dev;         /* "reward": Python sum() of the step rewards, in double        */
     int32_t* ep_length_dev;        /* "length"                                                      */
@@ -59,8 +60,9 @@ const char* mg_last_error(void);
 /* Instance groups (optional; the reference has no counterpart: it steps one instance at a time).  A handle's instances can
  * be split into `groups` contiguous, equally treated blocks (1, 2, 4 or 8; num_envs must be divisible).  mg_reset / mg_step
  * then launch each block's kernels on a stream of its own, staggered: block g's logic kernel waits for block g - 1's, so it
- * runs UNDER block g - 1's raster launch (the logic kernels are latency-bound, the raster kernels HBM-bound; measured
- * x1.08-1.35 per step: profiles/r03_groups.md), and the caller's stream waits for all blocks at the end of the call
+ * runs UNDER block g - 1's raster launch (the logic kernels are latency-bound, the raster kernels HBM-bound).  MEASURED SLOWER
+ * than one block on ROCm 7.2 -- x0.8 for two blocks, every cross-stream event dependency costs ~10-25 us of stream time
+ * (profiles/r03_groups.md) -- so it stays an opt-in; the caller's stream waits for all blocks at the end of the call
  * (stream-ordered: no host synchronisation).  Results are bit-identical to groups = 1: instance i is the same instance with
  * the same RNG stream whatever the grouping (tests/test_gpu_groups.py).  All buffers keep their [num_envs] layout.  Must be
  * called before the first mg_reset; option calls made earlier are replayed.  Checkpoints record the grouping. */
@@ -89,8 +91,27 @@ const char* mg_info_name(const mg_env* env, int k);
  * mortar_mayhem_grid.py:36-53).  `values`/`n`: scalars are n == 1, "sample one per episode" lists
  * have n >= 1.  Unknown key -> error -2 (the Python layer turns it into the reference's
  * AssertionError text); unsupported value -> error -3.  Takes effect at the next reset (also
- * auto-resets), for every instance of the handle. */
+ * auto-resets), for every instance of the handle that runs under option set 0 (all of them unless
+ * mg_bind_option_sets says otherwise, below). */
 int mg_set_option(mg_env* env, const char* key, const double* values, int n);
+
+/* Per-instance reset options.  In the reference reset(seed, options) belongs to ONE environment instance (e.g.
+ * mortar_mayhem_grid.py:213-236): a pool of workers runs different curricula side by side.  Here a handle holds up to
+ * MG_MAX_OPTION_SETS option sets; set 0 is the one mg_set_option writes.  mg_set_option_set writes one key of set
+ * `set_id` (a set that has never been written starts from the reference's defaults); mg_bind_option_sets registers the
+ * caller's device array int32 [num_envs]: instance i runs under set set_of_dev[i] -- for its resets, auto-resets AND its steps
+ * (rewards, limits and display options are read at step time, like the reference's self.reset_params) -- read by every
+ * following mg_reset / mg_step; the caller changes an instance's entry when that instance is reset with other options
+ * (stream-ordered, e.g. a tensor assignment on the launch stream).  NULL unbinds (every instance under set 0).
+ * Options that change the geometry shared by the handle's instances (the *_scale, agent_speed, arena_size, radius and dim /
+ * interval options that rebuild atlases, templates or tables) can only be set in set 0, i.e. for all instances: -3 otherwise.
+ * A geometry option is accepted in a set > 0 when it says what the handle's geometry already is.
+ * Families: Mortar Mayhem (all five ids) and Searing Spotlights (both ids) in this build; the Mystery Path family refuses sets
+ * > 0 with -3 (one handle per set).  With more than one set in use the per-set kernels read their parameters from memory: a
+ * mortar-family handle then steps with two launches, a SearingSpotlights handle resets inside its step kernel. */
+#define MG_MAX_OPTION_SETS 8
+int mg_set_option_set(mg_env* env, int set_id, const char* key, const double* values, int n);
+int mg_bind_option_sets(mg_env* env, const int32_t* set_of_dev);
 
 /* Observation format written to obs_dev by mg_reset / mg_step (default MG_OBS_U8_XYC).
  *   MG_OBS_U8_XYC   uint8   [num_envs][84 x][84 y][3]  -- the reference's observation: pygame.surfarray.array3d order
@@ -169,6 +190,9 @@ int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches);
  *      endless_mortar_mayhem.py:316-318); the episode of that instance was ended
  *  64  a deferred-reset queue was found over-full (an earlier fused launch failed before draining it); the excess
  *      entries were dropped
+ * 256  SearingSpotlights-v0: use_exit = False at the reset of an instance that has never had an exit (the reference raises
+ *      AttributeError there, searing_spotlights.py:431-435; with an earlier exit it keeps drawing that one, and so does this
+ *      library); no exit was drawn
  * 128  reserved (rounds <= 3: a frame workgroup of the mortar family's one-launch step gave up waiting for its descriptor.
  *      Since round 4 that launch cannot time out -- a frame wave that waits too long steps the instances itself,
  *      mg_mortar.hip mortar_step_raster_kernel -- and the bit is never raised) */

@@ -272,11 +272,11 @@ static void sp_compose(mgo_env* e, sp_t* p, mgo_surf* agent_surf) {
     int have_coin_surf = p->endless ? p->coin_enabled : (p->num_coins > 0);
     mgo_blit(e->screen, bg, 0, 0);
     if (!coin_above && have_coin_surf) mgo_blit(e->screen, p->coin_surf, 0, 0);
-    if (!p->endless && !p->exit_visible) mgo_blit(e->screen, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
+    if (!p->endless && !p->exit_visible && p->exit_surf) mgo_blit(e->screen, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
     if (!p->agent_visible) mgo_blit(e->screen, agent_surf, p->agent.rect.x, p->agent.rect.y);
     mgo_blit(e->screen, p->spot_surf, 0, 0);
     if (coin_above && have_coin_surf) mgo_blit(e->screen, p->coin_surf, 0, 0);
-    if (!p->endless && p->exit_visible) mgo_blit(e->screen, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
+    if (!p->endless && p->exit_visible && p->exit_surf) mgo_blit(e->screen, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
     /* NOTE: with agent_visible the reference's insert index (spot_surface_id + 3) can exceed the list length and
      * lands the agent on top of the top bar; list.insert clamps, so "append" is the faithful reading. */
     mgo_blit(e->screen, p->top_bar, 0, 0);
@@ -299,7 +299,7 @@ static void sp_debug(mgo_env* e, mgo_surf* dst) {
     mgo_fill(dst, 0);
     mgo_blit(dst, p->bg_is_red ? p->bg_red : p->bg_blue, 0, 0);
     mgo_blit(dst, p->spot_surf, 0, 0);
-    if (!p->endless) mgo_blit(dst, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
+    if (!p->endless && p->exit_surf) mgo_blit(dst, p->exit_surf, p->exit_rect.x, p->exit_rect.y);
     mgo_blit(dst, coin, 0, 0);
     if (p->have_disp) {
         const mgo_surf* sp = p->agent.sprites[p->disp_sprite];
@@ -450,6 +450,10 @@ static void sp_reset(mgo_env* e) {
                 p->coin_y[p->n_coins++] = y;
             }
         }
+        /* use_exit == False (searing_spotlights.py:413-416): no exit is spawned -- and no position sampled, no number drawn -- but the
+           frame still blits self.exit (:431-435): the Exit object of an EARLIER episode, at its place and in the state (open / closed)
+           it was last drawn in.  Without an earlier exit the reference raises AttributeError there; here nothing is drawn. */
+        if (p->use_exit) {
         /* _spawn_exit (:280-286) */
         int x, y;
         sp_sample(e, p, 21, &x, &y);
@@ -466,6 +470,7 @@ static void sp_reset(mgo_env* e) {
         p->exit_radius = 20.0 / 2 * p->exit_scale;
         p->exit_open = 1;
         sp_exit_draw(e, p, 0);
+        }
     }
     p->bg_is_red = 0;
     if (p->black_background) mgo_fill(p->bg_blue, 0);
@@ -605,7 +610,7 @@ static void sp_step(mgo_env* e, const int action[2]) {
             coins_done = 1;
         }
         int exit_done = 0;
-        { /* _step_exit_task (:313-330); use_exit=False crashes the reference at reset, so it is always on */
+        if (p->use_exit) { /* _step_exit_task (:313-330) */
             double er = 0.0;
             if (coins_done) {
                 sp_exit_draw(e, p, 1);
@@ -617,7 +622,14 @@ static void sp_step(mgo_env* e, const int action[2]) {
             reward += er;
         }
         if (spot_done) done = 1;
-        else if (coins_done && exit_done) { done = 1; success = 1; }
+        else if (coins_done) { /* (:499-511) */
+            if (p->use_exit) {
+                if (exit_done) { done = 1; success = 1; }
+            } else if (p->num_coins > 0) {
+                done = 1;
+                success = 1;
+            }
+        }
         p->t += 1;
         if (p->t == p->max_steps) done = 1;
     }
@@ -670,7 +682,7 @@ static int sp_set_option(mgo_env* e, const char* k, const double* v, int n) {
         I("num_spawns", num_spawns) D("initial_spawn_interval", initial_spawn_interval)
         D("spawn_interval_threshold", spawn_interval_threshold) D("spawn_interval_decay", spawn_interval_decay)
         if (!strcmp(k, "num_coins")) return mgo_opt_list(p->num_coins_list, &p->n_num_coins_list, SP_MAXLIST, v, n);
-        if (!strcmp(k, "use_exit")) return v[0] != 0.0 ? 0 : -3; /* use_exit=False crashes the reference */
+        I("use_exit", use_exit) /* False: legal once the object has had an exit (its stale one is drawn), see sp_reset */
         D("exit_scale", exit_scale) I("exit_visible", exit_visible)
         D("reward_exit", reward_exit) D("reward_max_steps", reward_max_steps)
     }

@@ -97,6 +97,11 @@ int main(int argc, char** argv) {
         printf("a mg_info_buffers without struct_size was accepted\n");
         return 1;
     }
+    info.struct_size = (size_t)(uintptr_t)rew64_d;  // what a caller built against the round-2 header (no struct_size) has here: a pointer
+    if (mg_step(env, act_d, obs_d, rew_d, done_d, nullptr, &info, 1, stream) == 0) {
+        printf("a device pointer in the place of struct_size was accepted\n");
+        return 1;
+    }
     info.struct_size = sizeof(info);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     long episodes = 0;

@@ -107,3 +107,21 @@ print("NO_VMM_OK")
 def test_runtime_without_the_virtual_memory_api_gets_a_plain_buffer():
     out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=dict(os.environ, MEMGYM_OBS_NO_VMM="1", MEMGYM_HIP_LIB=LAB_LIB), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "NO_VMM_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_a_balanced_buffer_is_never_exported_through_hip_ipc():
+    """mg_obs_alloc memory (hipMemCreate pieces in a reserved range) has no IPC handle; PeerObsBuffer refuses it by name instead
+    of failing inside torch's reduce_tensor (multi-GPU readiness)."""
+    import torch
+    from memory_gym_amd.dist import PeerObsBuffer
+    from memory_gym_amd.vec_env import alloc_obs_buffer, is_balanced_buffer
+
+    t, info = alloc_obs_buffer((20000, 84, 84, 3), torch.uint8, "cuda:0")
+    plain = torch.empty((16, 84, 84, 3), dtype=torch.uint8, device="cuda:0")
+    assert not is_balanced_buffer(plain)
+    PeerObsBuffer._check_exportable(plain)
+    if info["pieces"] > 0:
+        assert is_balanced_buffer(t) and is_balanced_buffer(t[100:200])
+        with pytest.raises(ValueError):
+            PeerObsBuffer._check_exportable(t)
+    del t

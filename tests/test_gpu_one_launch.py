@@ -1,5 +1,4 @@
-"""GPU (-m gpu): the one-launch step of the mortar and spotlight families (csrc/mg_mortar.hip mortar_step_raster_kernel,
-csrc/mg_spot.hip spot_step_raster_kernel) never shows a stale frame.
+"""GPU (-m gpu): the mortar family's one-launch step (csrc/mg_mortar.hip mortar_step_raster_kernel) never shows a stale frame.
 
 The reference's step() returns the frame of THIS step, always (mortar_mayhem_grid.py:280-375).  In the one launch a frame's
 workgroup waits for the descriptor the step's workgroups of the same launch publish; since round 4 a frame wave that waits
@@ -47,10 +46,9 @@ print("ok:", env_id, n, steps, done)
 '''
 
 
-@pytest.mark.parametrize("env_id,n,steps", [("MortarMayhem-Grid-v0", 4096, 40), ("Endless-MortarMayhem-v0", 4133, 30), ("MortarMayhem-v0", 2500, 30),
-                                              ("Endless-SearingSpotlights-v0", 2501, 40), ("SearingSpotlights-v0", 2048, 60)])
+@pytest.mark.parametrize("env_id,n,steps", [("MortarMayhem-Grid-v0", 4096, 40), ("Endless-MortarMayhem-v0", 4133, 30), ("MortarMayhem-v0", 2500, 30)])
 def test_step_workgroups_dispatched_last(env_id, n, steps):
-    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB, MEMGYM_LAB_LOGIC_LAST="1", MEMGYM_SPOT_ONE_LAUNCH="1")
+    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB, MEMGYM_LAB_LOGIC_LAST="1")
     r = subprocess.run([sys.executable, "-c", WORKER % {"here": HERE, "pkg": os.path.join(ROOT, "endless-memory-gym_amd")}, env_id, str(n), str(steps)],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok:" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -57,6 +57,46 @@ print("RCCL_WORLD1_OK")
 '''
 
 
+# RCCL reading an mg_obs_alloc range (HIP virtual memory: hipMemCreate pieces mapped into one reserved range): BASELINE config 5's
+# per-GPU shard, 32,768 Endless-MortarMayhem instances = 694 MB of observations, the size at which the Python mirror takes its
+# buffers from mg_obs_alloc (the 8-GPU run must not be the first time RCCL sees such memory)
+WORKER_VMM = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "endless-memory-gym_amd"))
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import memory_gym_amd
+from memory_gym_amd.dist import gather_to_rank0, ObsGatherer
+from memory_gym_amd.vec_env import is_balanced_buffer
+n = 32768
+env = memory_gym_amd.make("Endless-MortarMayhem-v0", num_envs=n, device=0)
+info = env.obs_placement_info
+print("PLACEMENT", info)
+if info is None or info["pieces"] == 0:
+    print("PLAIN_ALLOCATION")   # one zone only within reach on this box: nothing to test
+    sys.exit(0)
+assert is_balanced_buffer(env.obs)
+obs, _ = env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda"))
+g = gather_to_rank0(obs)
+torch.cuda.synchronize()
+assert torch.equal(g, obs), "gather_to_rank0 of a balanced (virtual-memory) buffer differs from the local observations"
+gen = torch.Generator(device="cuda").manual_seed(3)
+gat = ObsGatherer(env)
+assert is_balanced_buffer(gat.bufs[1]), "the second buffer of the gatherer is balanced like the first"
+for t in range(12):
+    a = torch.randint(0, 3, (n, 2), device="cuda", generator=gen, dtype=torch.int32)
+    o = gat.step(a)[0]
+    got = gat.gathered()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], o), "gathered frames of step %%d differ from the step's observation buffer" %% t
+gat.drain()
+env.check_errors()
+dist.destroy_process_group()
+print("RCCL_VMM_OK")
+'''
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -72,6 +112,13 @@ def _env():
 def test_gather_through_rccl_equals_local_observations():
     out = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=_env(), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_WORLD1_OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_rccl_reads_a_balanced_virtual_memory_buffer():
+    out = subprocess.run([sys.executable, "-c", WORKER_VMM % {"root": ROOT}], env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and ("RCCL_VMM_OK" in out.stdout or "PLAIN_ALLOCATION" in out.stdout), out.stdout[-1500:] + out.stderr[-3000:]
+    if "PLAIN_ALLOCATION" in out.stdout:
+        pytest.skip("mg_obs_alloc found one memory zone only on this box: " + out.stdout[-300:])
 
 
 def test_bench_gather_rccl_one_rank():

@@ -71,3 +71,29 @@ def test_obs_alloc_small_and_no_search():
         assert p.value and info.zones == 0 and info.searched_bytes == 0
         assert _native.LIB.mg_obs_free(p) == 0
     assert _native.LIB.mg_obs_free(C.c_void_p(12345)) != 0
+
+
+@pytest.mark.parametrize("env_id,adim,n_act", [("MortarMayhem-Grid-v0", 1, 4), ("SearingSpotlights-v0", 2, 3)])
+def test_masked_reset_after_a_buffer_swap_leaves_no_stale_rows(env_id, adim, n_act):
+    """use_obs_buffer() then reset(mask=...): the rows of the instances that are NOT reset must show their current frames in
+    the new buffer, not whatever the buffer held (a gatherer that double-buffers would ship them)."""
+    import memory_gym_amd
+    import torch
+
+    n = 512
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    env.reset(seed=9)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(25):
+        obs = env.step(torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32))[0]
+    before = obs.clone()
+    other = torch.full_like(obs, 0xAB)
+    env.use_obs_buffer(other)
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+    mask[::3] = True
+    obs2, _ = env.reset(mask=mask)
+    assert obs2.data_ptr() == other.data_ptr()
+    assert torch.equal(obs2[~mask], before[~mask]), "rows of instances that were not reset are stale in the new buffer"
+    assert not torch.equal(obs2[mask], before[mask])
+    env.check_errors()
+    env.close()

@@ -18,10 +18,8 @@ CASES = [
     ("MEMGYM_EMP_RESET_LANES", "0", "Endless-MysteryPath-v0", 1024, 30),    # full reset one wave per instance (lanes: n >= 1,024)
     ("MEMGYM_MYSTERY_DEFER", "1", "MysteryPath-v0", 160, 150),              # reset paths inside the raster launch
     ("MEMGYM_MYSTERY_DEFER", "0", "MysteryPath-Grid-v0", 160, 150),         # ... and not, for the grid variant
-    ("MEMGYM_SPOT_ONE_LAUNCH", "0", "Endless-SearingSpotlights-v0", 160, 200),  # step and raster as two launches
-    ("MEMGYM_SPOT_ONE_LAUNCH", "0", "SearingSpotlights-v0", 160, 200),         # ... (the finite variant: resets served inside the raster launch)
-    ("MEMGYM_SPOT_ONE_LAUNCH=0 MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 200),  # two launches, resets inside the raster launch
-    ("MEMGYM_SPOT_ONE_LAUNCH=0 MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 200),          # ... and not, for the finite variant
+    ("MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 200),    # resets inside the raster launch
+    ("MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 200),            # ... and not, for the finite variant
     ("MEMGYM_MORTAR_FUSE", "0", "MortarMayhem-Grid-v0", 300, 150),          # step and raster as two launches
     ("MEMGYM_MORTAR_FUSE", "0", "Endless-MortarMayhem-v0", 300, 150),
     ("MEMGYM_LAB_NONE", "1", "MortarMayhem-Grid-v0", 300, 60),             # the lab build itself, no switch set
