@@ -53,7 +53,6 @@ constexpr int RASTER_GRID_SMALL = 256 * 38;   // ... over 24,576 frames or fewer
 constexpr int RASTER_PLAIN_MAX = 16384;       // launches up to this many frames use plain stores, larger ones non-temporal: raster_nt()
 constexpr int RASTER_LDS = FRAME_BYTES + SCREEN * MASK_WORDS * 4;
 constexpr int RASTER_LDS_REQUEST = 25 * 1024;  // non-temporal uint8 stream: six workgroups per CU, see launch_raster
-constexpr int RASTER_LDS_FUSED = 28 * 1024;    // spot_raster_serve_kernel: five per CU (its reset code needs the 96 VGPRs)
 
 struct StampInfo {
     uint32_t off;  // pixel offset into the stamp data, pixels stored [x][y] (column-major like the frame)

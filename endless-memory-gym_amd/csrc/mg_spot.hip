@@ -546,7 +546,14 @@ struct SlotRec {
 // Spotlight.__init__ for the slot the free mask hands out; the owning lane stores the record AND returns it in `rec` (the step
 // kernel used to read it back from memory: store, wait, load, wait -- two round trips in every wave in which any instance
 // spawned, i.e. in every launch).
-__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SlotRec* rec = nullptr) {
+// cos / sin of integer degrees (host-built tables, see SpotFamily): in global memory, or the step kernel's copy in LDS -- a spawn
+// reads six entries at addresses that depend on its draws, i.e. a memory round trip of its own in the step kernel's longest chains
+// (a reset spawns three or four spotlights one after another)
+struct Trig {
+    const double* c;
+    const double* s;
+};
+__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, const Trig& T, SlotRec* rec = nullptr) {
     int radius = g.integers(P.r_lo, P.r_hi);
     double speed = g.uniform(P.speed_lo, P.speed_hi);
     int start = g.integers(0, 360);
@@ -568,12 +575,12 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, S
     n.done = false;
     n.t = 0.0;
     n.speed = speed;
-    n.sx = c + P.cos_tab[start % 360] * R;
-    n.sy = c + P.sin_tab[start % 360] * R;
-    n.tx = c + P.cos_tab[target % 360] * R;
-    n.ty = c + P.sin_tab[target % 360] * R;
-    n.ox = c + P.cos_tab[offset % 360] * R;
-    n.oy = c + P.sin_tab[offset % 360] * R;
+    n.sx = c + T.c[start % 360] * R;
+    n.sy = c + T.s[start % 360] * R;
+    n.tx = c + T.c[target % 360] * R;
+    n.ty = c + T.s[target % 360] * R;
+    n.ox = c + T.c[offset % 360] * R;
+    n.oy = c + T.s[offset % 360] * R;
     n.mine = true;
     io.sp_r[k] = (uint8_t)n.r;
     io.sp_done[k] = 0;
@@ -611,7 +618,7 @@ __device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore&
 // 0 at reset, i.e. with light_dim_off_duration == 0.  The hole words themselves are still in the descriptor.
 template <bool EN>
 __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, const LaneCtx& L, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
-                                           int stale_holes, int* slot) {  // slot: disc_slot() of the calling kernel's LDS array
+                                           int stale_holes, int* slot, const Trig& T) {  // slot: disc_slot() of the calling kernel's LDS array
     const int ls = L.ls;
     s.t = 0;
     s.coin_t = 0;
@@ -645,7 +652,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.free_mask = 0xFFFFu;
     s.spawn_timer = 0;
     s.n_intervals = (uint8_t)P.num_spawns;
-    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g);
+    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g, T);
     s.coins_collected = 0;
     s.n_coins = 0;
     s.has_coin = 0;
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P0, SpotIO i
     SpotDesc d;
     const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);  // n_holes of the frame drawn last
     const LaneCtx L = lane_ctx((int)threadIdx.x);
-    spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds, L.grp));
+    spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds, L.grp), Trig{P.cos_tab, P.sin_tab});
     if (ls == 0) {
         io.core[i] = s;
         g.store(io.rng, i);
@@ -809,7 +816,7 @@ struct SpotStepArgs {
 // coin re-sampling and resets are rare), the slot record after the spawn, a newborn spotlight is read back from memory, and the
 // core record lives in LDS.
 template <bool EN, bool PS>
-__device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const SpotStepArgs& a, int* disc_lds, SpotCore* core_lds) {
+__device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const SpotStepArgs& a, int* disc_lds, SpotCore* core_lds, const Trig& T) {
     const int ls = L.ls;
     const SpotIO& io = a.io;
     const SpotParams& P = PS ? io.sets[io.set_of[i]] : a.P;  // (PS: per-instance option sets)
@@ -865,13 +872,13 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     if constexpr (EN) {
         if (__builtin_expect(s.spawn_timer >= P.spawn_interval, 0)) {
             need_rng();
-            new_spot(P, io, i, ls, s, g);
+            new_spot(P, io, i, ls, s, g, T);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
         if (__builtin_expect(s.spawn_timer >= P.interval0, 0)) {
             need_rng();
-            new_spot(P, io, i, ls, s, g);
+            new_spot(P, io, i, ls, s, g, T);
             s.n_intervals--;
             s.spawn_timer = 0;
         }
@@ -1062,7 +1069,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     if (defer && reset_me && leader) queue_push(io.queue, &io.qctr[SQ_COUNT], P.n, i, io.err);
     if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
         need_rng();
-        spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds, L.grp));
+        spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds, L.grp), T);
     } else {
         d.bg = bg_template(s.pad, s.bg_red);
         d.sprite = s.rot8;
@@ -1115,9 +1122,12 @@ template <bool EN, bool PS>
 __global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
     __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
     __shared__ SpotCore core_lds[256 / 16];
+    __shared__ double trig_lds[720];  // cos[360], sin[360]: the workgroup's copy (5.8 KB, requested with the step's first loads)
+    for (int k = threadIdx.x; k < 720; k += blockDim.x) trig_lds[k] = k < 360 ? a.P.cos_tab[k] : a.P.sin_tab[k - 360];
+    __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gid >> 4;
-    if (i < a.P.n) spot_step_body<EN, PS>(i, lane_ctx((int)threadIdx.x), a, disc_lds, core_lds);
+    if (i < a.P.n) spot_step_body<EN, PS>(i, lane_ctx((int)threadIdx.x), a, disc_lds, core_lds, Trig{trig_lds, trig_lds + 360});
 }
 
 // The step's raster launch with the put-off resets served inside it: the first workgroups take the queue entries, eight
@@ -1128,24 +1138,41 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
 // one address: 22 ns each, in series).  What bounds the launch is a reset's latency next to the raster's waves (~45-80 us)
 // plus the frames that follow it in the same workgroup; variants measured: profiles/r02_spot_resets.md.
 constexpr int SPOT_SVC_WGS = 512, SPOT_SVC_BATCH = 8;
-constexpr int FUSED_DISC_OFF = 24 * 1024;  // past the frame and the hole mask (RASTER_LDS = 22,176 B)
-static_assert(FUSED_DISC_OFF + SPOT_SVC_BATCH * DISC_INTS * 4 <= RASTER_LDS_FUSED, "disc lists fit into the fused launch's LDS request");
-// (five workgroups per CU: what the 28-KiB LDS request of the uint8 raster allows anyway -- and the reset code needs the 96 VGPRs)
+static_assert(SPOT_SVC_BATCH * (DISC_INTS * 4 + (int)sizeof(SpotCore)) <= FRAME_BYTES, "a service batch's disc lists and core records fit into the frame area");
+// Workgroups per CU of the fused launch (round 4, profiles/r04_spot_serve.md): SIX, non-temporal stores.  Rounds 2-3 ran it at five (96
+// VGPRs and 104-124 B of scratch, 28 KiB of LDS): with the core record of a reset in LDS and the arguments of the service loop
+// read where they are used, the endless variant needs 80 VGPRs and no scratch, the finite one 80 + 88-100 B.
+#ifndef MG_SPOT_SERVE_OCC
+#define MG_SPOT_SERVE_OCC 6
+#endif
+#define MG_KERNARG_AS __attribute__((address_space(4)))
+// all arguments in one struct = the kernel-argument segment: the service workgroups read theirs through a pointer the compiler cannot
+// see through, where they are used (held in scalar registers for the length of the service loop they spilled into vector lanes)
+struct SpotServeArgs {
+    const SpotDesc* descs;
+    RasterAtlas A;
+    void* obs;
+    int n;
+    SpotParams P;
+    SpotIO io;
+    float* gt;
+};
 template <bool EN, bool BORDER, bool NT>
-__global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
-                                                                   SpotParams P, SpotIO io, float* gt) {
+__global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kernel(SpotServeArgs a) {
     typedef SpotComposerT<BORDER> Composer;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     RasterCtx R;
     R.frame = smem;
     R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
-    R.A = A;
-    R.T = as_const(A.tables);
+    R.A = a.A;
+    R.T = as_const(a.A.tables);
     R.tid = threadIdx.x;
     const int tid = threadIdx.x;
-    const cptr<SpotDesc> cdescs = as_const(descs);
+    const int n = a.n;
+    void* const obs = a.obs;
+    const cptr<SpotDesc> cdescs = as_const(a.descs);
     const bool service = (int)blockIdx.x < SPOT_SVC_WGS;
-    const int count = service ? queue_count(&io.qctr[SQ_COUNT], n) : 0;
+    const int count = service ? queue_count(&a.io.qctr[SQ_COUNT], n) : 0;
     if (service && (int)blockIdx.x * SPOT_SVC_BATCH >= count) return;
     Composer::recycle(R);
     __syncthreads();
@@ -1160,18 +1187,26 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
     };
     if (service) {
         for (int base = blockIdx.x * SPOT_SVC_BATCH; base < count; base += SPOT_SVC_WGS * SPOT_SVC_BATCH) {
+            const SpotServeArgs MG_KERNARG_AS* ka = (const SpotServeArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const SpotParams& P = *(const SpotParams*)&ka->P;
+            const SpotIO& io = *(const SpotIO*)&ka->io;
+            float* const gt = ka->gt;
             const int e = base + (tid >> 4), ls = tid & 15;
             if (tid < 16 * SPOT_SVC_BATCH && e < count) {
                 const int i = io.queue[e];
                 Pcg g;
                 g.load(io.rng, i);
-                SpotCore s = io.core[i];
+                // disc lists and core records of the batch: in the FRAME area -- nothing of this workgroup is being composed while it
+                // resets (the barriers around draw() separate the two uses) -- so the launch asks for no more LDS than the raster alone;
+                // the core record in LDS instead of registers is what lets this kernel run at the raster's occupancy (round 4)
+                const LaneCtx L = lane_ctx(tid);
+                SpotCore& s = reinterpret_cast<SpotCore*>(smem + SPOT_SVC_BATCH * DISC_INTS * 4)[L.grp];
+                s = io.core[i];
                 SpotDesc d;
                 const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);
-                // disc lists: behind the frame and the hole mask, in the part of the 28-KiB request the composer does not use
-                const LaneCtx L = lane_ctx(tid);
                 spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes,
-                               disc_slot(reinterpret_cast<int*>(smem + FUSED_DISC_OFF), L.grp));
+                               disc_slot(reinterpret_cast<int*>(smem), L.grp), Trig{P.cos_tab, P.sin_tab});
                 d.valid = DESC_SERVED;
                 if (ls == 0) {
                     io.core[i] = s;
@@ -1185,9 +1220,9 @@ __global__ __launch_bounds__(256, 5) void spot_raster_serve_kernel(const SpotDes
             for (int k = 0; k < SPOT_SVC_BATCH && base + k < count; ++k) draw(io.queue[base + k]);
         }
         const int busy = (count + SPOT_SVC_BATCH - 1) / SPOT_SVC_BATCH < SPOT_SVC_WGS ? (count + SPOT_SVC_BATCH - 1) / SPOT_SVC_BATCH : SPOT_SVC_WGS;
-        if (tid == 0 && atomicAdd(&io.qctr[SQ_LEFT], 1) == busy - 1) {  // last service workgroup out
-            io.qctr[SQ_COUNT] = 0;
-            io.qctr[SQ_LEFT] = 0;
+        if (tid == 0 && atomicAdd(&a.io.qctr[SQ_LEFT], 1) == busy - 1) {  // last service workgroup out
+            a.io.qctr[SQ_COUNT] = 0;
+            a.io.qctr[SQ_LEFT] = 0;
         }
         return;
     }
@@ -1433,8 +1468,11 @@ class SpotFamily : public Family {
         prof.begin(1, s);
         if (defer) {
             const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + SPOT_SVC_WGS;
-#define SPOT_FUSED2(EN, BO, NT) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT>), dim3(grid), dim3(256), RASTER_LDS_FUSED, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), gt)
-#define SPOT_FUSED(EN, BO) do { if (fused_nt()) SPOT_FUSED2(EN, BO, true); else SPOT_FUSED2(EN, BO, false); } while (0)
+            const SpotServeArgs va{desc_.p, atlas_->dev(), obs, n_, P_, io(), gt};
+            const bool nt = fused_nt();                // non-temporal: with plain stores the fused launch loses 5-15 us at every occupancy
+            const int serve_lds = RASTER_LDS_REQUEST;  // 25 KiB: six per CU
+#define SPOT_FUSED2(EN, BO, NT) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT>), dim3(grid), dim3(256), serve_lds, s, va)
+#define SPOT_FUSED(EN, BO) do { if (nt) SPOT_FUSED2(EN, BO, true); else SPOT_FUSED2(EN, BO, false); } while (0)
             if (P_.endless) { if (P_.ordered_holes) SPOT_FUSED(true, true); else SPOT_FUSED(true, false); }
             else { if (P_.ordered_holes) SPOT_FUSED(false, true); else SPOT_FUSED(false, false); }
 #undef SPOT_FUSED
