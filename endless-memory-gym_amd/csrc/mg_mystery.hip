@@ -1726,35 +1726,14 @@ constexpr int EMP_BG_WGS = 512;  // frame workgroups that may carry background j
 static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
 // (Round 4 tried the service and background workgroups as a launch of their own on a side stream beside a plain raster launch:
 // bit-exact, 185 M env-steps/s against 189-192 M for this fused launch -- the raster alone takes 110 us, beside the service
-// 136-144 us, and the fork / join costs ~10 us of stream time: profiles/r04_emp.md.  Taken out again.)
-// All arguments in ONE struct = the kernel-argument segment (round 4): the service and background workgroups read theirs through a
-// pointer the compiler cannot see through, inside their loops, where they are used -- held in scalar registers for the length
-// of the service loop they were ~300 scalar spills into vector lanes and, from there, scratch.
-#define MG_KERNARG_AS __attribute__((address_space(4)))
-struct EmpFusedArgs {
-    const MysteryDesc* descs;
-    RasterAtlas A;
-    void* obs;
-    int n;
-    MysteryParams P;
-    MysteryIO io;
-    float* reward_out;
-    uint8_t* done_out;
-    float* gt;
-    mg_info_buffers info;
-    int autoreset, svc;
-};
-__device__ __forceinline__ const EmpFusedArgs& emp_args_again() {
-    const EmpFusedArgs MG_KERNARG_AS* ka = (const EmpFusedArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    return *(const EmpFusedArgs*)ka;
-}
+// 136-144 us, and the fork / join costs ~10 us of stream time: profiles/r04_emp.md.  Taken out again.  So was the arguments-as-one-
+// struct form that helped the spotlight family's fused kernel (service loop reading them through an opaque pointer where it uses
+// them): scratch 672 -> 624 B only -- the path generator wants ~200 VGPRs whatever the scalar side does -- and the launch got
+// SLOWER, 149-151 -> 156-164 us.)
 template <int FMT>
-__global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(EmpFusedArgs args) {
-    const MysteryDesc* const descs = args.descs;
-    const RasterAtlas A = args.A;
-    void* const obs = args.obs;
-    const int n = args.n, svc = args.svc;
+__global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
+                                                                  MysteryParams P, MysteryIO io, float* reward_out, uint8_t* done_out,
+                                                                  float* gt, mg_info_buffers info, int autoreset, int svc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ MysteryDesc sdesc[4];
     __shared__ int served[4];
@@ -1768,22 +1747,20 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(Em
     LAB_CLOCK(0);
     if ((int)blockIdx.x < svc) {
         // the service waves run a long dependent instruction chain next to memory-bound raster waves: let them issue first
-        if (args.P.svc_prio) __builtin_amdgcn_s_setprio(3);
+        if (P.svc_prio) __builtin_amdgcn_s_setprio(3);
         uint8_t* ws = smem + FRAME_BYTES;  // the path workspace lives in the (unused) mask words behind the frame
         path_ws_init(ws);
+        const PathWS W{ws, io.jump, io.stats};
         const int wv = tid >> 6;
         const bool me = (tid & 63) == 0;
-        const int count = queue_count(&args.io.qctr[QC_COUNT], n);
+        const int count = queue_count(&io.qctr[QC_COUNT], n);
         const int waves = svc * 4;
         int idx = bcast((int)(blockIdx.x * 4 + wv), 0);
         for (;;) {
-            const EmpFusedArgs& a = emp_args_again();
-            const MysteryIO& io = a.io;
-            const PathWS W{ws, io.jump, io.stats};
             int inst = -1;
             if (idx < count) {
                 const int entry = bcast(io.queue[idx], 0);
-                emp_serve_entry(a.P, io, W, entry, nullptr, a.reward_out, a.done_out, a.gt, a.info, a.autoreset, &sdesc[wv]);
+                emp_serve_entry(P, io, W, entry, nullptr, reward_out, done_out, gt, info, autoreset, &sdesc[wv]);
                 inst = entry & (EMP_Q_SEGMENT - 1);
                 if (me) idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
                 idx = bcast(idx, 0);
@@ -1804,10 +1781,10 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(Em
             if (!any) break;
             __syncthreads();  // served[] / sdesc[] are rewritten by the next round: every wave has finished reading them
         }
-        if (tid == 0 && atomicAdd(&args.io.qctr[QC_LEFT], 1) == svc - 1) {  // last service workgroup out
-            args.io.qctr[QC_COUNT] = 0;
-            args.io.qctr[QC_HEAD] = 0;
-            args.io.qctr[QC_LEFT] = 0;
+        if (tid == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == svc - 1) {  // last service workgroup out
+            io.qctr[QC_COUNT] = 0;
+            io.qctr[QC_HEAD] = 0;
+            io.qctr[QC_LEFT] = 0;
         }
         LAB_CLOCK(2);
         return;
@@ -1817,7 +1794,6 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(Em
     // its frames; ~105 us that run beside the other workgroups' frames, and nothing of this launch depends on them.  The
     // last participant clears the counter (participants read it before that can happen, see mystery_raster_paths_kernel).
     if ((int)blockIdx.x - svc < EMP_BG_WGS) {
-        const MysteryIO& io = emp_args_again().io;
         const int bg = queue_count(&io.qctr[QC_BG_COUNT], n);
         const int busy = min(EMP_BG_WGS, (bg + 63) / 64);
         const int b = (int)blockIdx.x - svc;
@@ -1992,8 +1968,8 @@ class MysteryFamily : public Family {
                 prof.begin(1, s);
                 const int svc = EMP_SVC_WGS;
                 const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + svc;
-                const EmpFusedArgs fa{desc_.p, atlas_->dev(), obs, n_, P_, io(), reward, done, gt, ib, autoreset, svc};
-                hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, fa);
+                hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                   P_, io(), reward, done, gt, ib, autoreset, svc);
                 MG_HIP(hipGetLastError());
                 prof.end(1, s);
 #ifdef MG_LAB_EMP_CLOCK  // diagnosis: is the next logic kernel slow because the L2 is full of dirty observation lines?
