@@ -392,8 +392,15 @@ typedef SpotDebugComposerT<true> SpotBorderDebugComposer;
 
 struct SpotIO {
     SpotCore* core;
-    double *sp_t, *sp_speed, *sp_sx, *sp_sy, *sp_tx, *sp_ty, *sp_ox, *sp_oy;  // [N][16]
-    uint8_t *sp_r, *sp_done;                                                    // [N][16]
+    // A spotlight's slot record, [N][16] each: where it is on its way (t, f64), how fast (f64), its three angles in degrees (u32:
+    // start | target << 9 | offset << 18, each already % 360) and its radius (u8, bit 7: has_border).  The six end points of
+    // Spotlight.__init__ are c + cos/sin(angle) * (half_diag + radius): the same expression gives the same doubles at every step, so
+    // they are recomputed from the (cache-resident) trig tables instead of stored -- round 3 kept them (six f64 arrays): 1,312 B of
+    // slot state per instance, read by a step kernel that is a burst of cold loads (profiles/r04_spot_step.md); now 336 B.
+    // `done` is t == 1.0 (the step clamps t to exactly 1.0 when it raises it, and nothing else writes either).
+    double *sp_t, *sp_speed;
+    uint32_t* sp_ang;
+    uint8_t* sp_r;
     uint32_t* coins;  // [N][MAX_COINS] (x | y<<16), finite variant
     RngSoA rng;
     SpotDesc* desc;
@@ -411,12 +418,17 @@ constexpr int SQ_COUNT = 0, SQ_LEFT = 32, SQ_WORDS = 64;  // one 128-byte line e
 // workgroup.  The frame workgroups of the fused launch draw 1 only, everything else (raster_only, debug view) draws != 0.
 constexpr uint32_t DESC_QUEUED = 2, DESC_SERVED = 3;
 
+// floor(sqrt(v)), v < 2^24: single-precision estimate (a double-precision square root is ~20 dependent f64 instructions on this
+// chip), made exact by the two integer corrections.
 __device__ __forceinline__ int isqrt_floor(int v) {
-    int r = (int)sqrt((double)v);
+    int r = (int)__fsqrt_rn((float)v);
     while (r * r > v) --r;
     while ((r + 1) * (r + 1) <= v) ++r;
     return r;
 }
+// sqrt(dx^2 + dy^2) <= R for integers (Coin / agent distance tests of the reference, computed there in doubles): the square root is
+// correctly rounded and monotonic and sqrt(R^2) == R exactly, so the test is d2 <= R^2 -- without the f64 square root.
+__device__ __forceinline__ bool within(int dx, int dy, int R) { return dx * dx + dy * dy <= R * R; }
 
 // GridPositionSampler.sample: k-th un-blocked cell (row-major) of the 84x84 grid; discs: (x, y, r) with strict <.
 // Each row's blocked set is a union of intervals [cx - hw, cx + hw] with hw = isqrt(r^2 - dy^2 - 1); rows are
@@ -481,9 +493,30 @@ __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx
         return SCREEN * SCREEN;
     }
     const int y0 = ls * ROWS_PER_LANE;
+    // One disc (the endless variant's coin re-sampling: only the collected coin is blocked): a row's blocked cells are ONE interval
+    // [lo, hi] -- no masks; the lane holding the k-th free cell finds it with two comparisons.
+    const bool one = D.n == 1;
+    int lo[ROWS_PER_LANE], len[ROWS_PER_LANE];
     int local_free = 0;
     if (ls < 14) {
-        for (int j = 0; j < ROWS_PER_LANE; ++j) local_free += SCREEN - popc128(row_mask(D, y0 + j));
+        if (one) {
+            const int dx = D.p[0], dy = D.p[MAX_DISCS], dr = D.p[2 * MAX_DISCS];
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_LANE; ++j) {
+                const int ddy = y0 + j - dy, rem = dr * dr - ddy * ddy - 1;
+                int a = 0, b = -1;
+                if (rem >= 0) {
+                    const int hw = isqrt_floor(rem);
+                    a = dx - hw < 0 ? 0 : dx - hw;
+                    b = dx + hw > SCREEN - 1 ? SCREEN - 1 : dx + hw;
+                }
+                lo[j] = a;
+                len[j] = b >= a ? b - a + 1 : 0;
+                local_free += SCREEN - len[j];
+            }
+        } else {
+            for (int j = 0; j < ROWS_PER_LANE; ++j) local_free += SCREEN - popc128(row_mask(D, y0 + j));
+        }
     }
     // inclusive scan over the 16 lanes of the group (width-16 shuffles stay inside the instance's lanes)
     int incl = local_free;
@@ -495,7 +528,18 @@ __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx
     int k = g.integers(0, free_total);  // identical in all 16 lanes
     const int excl = incl - local_free;
     int fx = -1, fy = -1;
-    if (k >= excl && k < incl) {  // exactly one lane
+    if (one && k >= excl && k < incl) {
+        int kk = k - excl;
+#pragma unroll
+        for (int j = 0; j < ROWS_PER_LANE; ++j) {
+            const int fr = SCREEN - len[j];
+            if (fy < 0 && kk < fr) {
+                fx = kk < lo[j] ? kk : kk + len[j];
+                fy = y0 + j;
+            }
+            if (fy < 0) kk -= fr;
+        }
+    } else if (k >= excl && k < incl) {  // exactly one lane
         int kk = k - excl;
         for (int j = 0; j < ROWS_PER_LANE; ++j) {
             u128m m = row_mask(D, y0 + j);
@@ -538,20 +582,22 @@ __device__ __forceinline__ void clamp_spawn(const SpotParams& P, int& x, int& y)
 // `ls` = this lane's slot id: every lane of the instance draws the same numbers, the owner of the chosen slot stores them
 // The record of a spotlight as the lane owning its slot holds it in registers.
 struct SlotRec {
-    double t, speed, sx, sy, tx, ty, ox, oy;
-    int r;        // bit 7: has_border
-    bool done;
-    bool mine;    // new_spot: this lane's slot was taken by the new spotlight and the fields above are its record
+    double t, speed;
+    uint32_t ang;  // start | target << 9 | offset << 18 (degrees, % 360)
+    int r;         // bit 7: has_border
 };
-// Spotlight.__init__ for the slot the free mask hands out; the owning lane stores the record AND returns it in `rec` (the step
-// kernel used to read it back from memory: store, wait, load, wait -- two round trips in every wave in which any instance
-// spawned, i.e. in every launch).
+__device__ __forceinline__ uint32_t pack_angles(int start, int target, int offset) {
+    return (uint32_t)(start % 360) | ((uint32_t)(target % 360) << 9) | ((uint32_t)(offset % 360) << 18);
+}
 // cos / sin of integer degrees (host-built tables in global memory, see SpotFamily)
 struct Trig {
     const double* c;
     const double* s;
 };
-__device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, const Trig& T, SlotRec* rec = nullptr) {
+// Spotlight.__init__: 5 draws (radius, speed, start angle, target delta, offset delta).  `ls` = this lane's slot id: every lane of
+// the instance draws the same numbers; the lane owning the slot the free mask hands out stores the record AND gets it back in
+// `rec` (reading it back from memory is two round trips in every wave in which any instance spawned, i.e. in every launch).
+__device__ __forceinline__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SlotRec* rec = nullptr) {
     int radius = g.integers(P.r_lo, P.r_hi);
     double speed = g.uniform(P.speed_lo, P.speed_hi);
     int start = g.integers(0, 360);
@@ -567,29 +613,15 @@ __device__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, S
     s.n_spots++;
     if (slot != ls) return;
     size_t k = (size_t)i * SLOTS + slot;
-    double R = P.half_diag + (double)radius, c = SCREEN / 2;
     SlotRec n;
     n.r = radius | (P.black_background ? 0x80 : 0);  // bit 7: Spotlight.has_border
-    n.done = false;
     n.t = 0.0;
     n.speed = speed;
-    n.sx = c + T.c[start % 360] * R;
-    n.sy = c + T.s[start % 360] * R;
-    n.tx = c + T.c[target % 360] * R;
-    n.ty = c + T.s[target % 360] * R;
-    n.ox = c + T.c[offset % 360] * R;
-    n.oy = c + T.s[offset % 360] * R;
-    n.mine = true;
+    n.ang = pack_angles(start, target, offset);
     io.sp_r[k] = (uint8_t)n.r;
-    io.sp_done[k] = 0;
     io.sp_t[k] = n.t;
     io.sp_speed[k] = n.speed;
-    io.sp_sx[k] = n.sx;
-    io.sp_sy[k] = n.sy;
-    io.sp_tx[k] = n.tx;
-    io.sp_ty[k] = n.ty;
-    io.sp_ox[k] = n.ox;
-    io.sp_oy[k] = n.oy;
+    io.sp_ang[k] = n.ang;
     if (rec) *rec = n;
 }
 
@@ -616,7 +648,7 @@ __device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore&
 // 0 at reset, i.e. with light_dim_off_duration == 0.  The hole words themselves are still in the descriptor.
 template <bool EN>
 __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, const LaneCtx& L, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
-                                           int stale_holes, int* slot, const Trig& T) {  // slot: disc_slot() of the calling kernel's LDS array
+                                           int stale_holes, int* slot) {  // slot: disc_slot() of the calling kernel's LDS array
     const int ls = L.ls;
     s.t = 0;
     s.coin_t = 0;
@@ -650,7 +682,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.free_mask = 0xFFFFu;
     s.spawn_timer = 0;
     s.n_intervals = (uint8_t)P.num_spawns;
-    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g, T);
+    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g);
     s.coins_collected = 0;
     s.n_coins = 0;
     s.has_coin = 0;
@@ -788,7 +820,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P0, SpotIO i
     SpotDesc d;
     const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);  // n_holes of the frame drawn last
     const LaneCtx L = lane_ctx((int)threadIdx.x);
-    spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds, L.grp), Trig{P.cos_tab, P.sin_tab});
+    spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes, disc_slot(disc_lds, L.grp));
     if (ls == 0) {
         io.core[i] = s;
         g.store(io.rng, i);
@@ -813,9 +845,21 @@ struct SpotStepArgs {
 // and the two-launch step kept what it gained at large launches): the RNG stream is read where the first draw happens (spawns,
 // coin re-sampling and resets are rare), the slot record after the spawn, a newborn spotlight is read back from memory, and the
 // core record lives in LDS.
+#ifdef MG_LAB_SPOT_CLOCK  // measurement builds only (tools/spot_step_timeline.py): eight stamps + flags per wave of the step kernel
+static __device__ unsigned long long g_lab_spot_clock[10 * 65536];
+#define SPOT_CLOCK(slot) do { clk[slot] = (unsigned long long)clock64(); } while (0)
+#else
+#define SPOT_CLOCK(slot) do { } while (0)
+#endif
 template <bool EN, bool PS>
 __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const SpotStepArgs& a, int* disc_lds, SpotCore* core_lds, const Trig& T) {
     const int ls = L.ls;
+#ifdef MG_LAB_SPOT_CLOCK
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long wall0 = wall_clock64();
+    bool f_spawn = false, f_coin = false;
+#endif
+    SPOT_CLOCK(0);
     const SpotIO& io = a.io;
     const SpotParams& P = PS ? io.sets[io.set_of[i]] : a.P;  // (PS: per-instance option sets)
     const int32_t* const actions = a.actions;
@@ -831,15 +875,20 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     // 89 -> 65-73 VGPRs for this body), for a handful of LDS round trips on its critical path.
     SpotCore& s = core_lds[L.grp];
     s = io.core[i];
+    // Everything the step may need is requested HERE, together: the generator's stream (spawns, coin re-sampling and resets are
+    // rare, but each used to start with a memory round trip of its own, and a wave with two of them is what the launch waits
+    // for) and this lane's slot record (16 bytes + a byte now).  Timeline per wave: profiles/r04_spot_step.md.
     Pcg g;
-    bool rng_loaded = false;
-    auto need_rng = [&]() {  // (all 16 lanes of the instance take the same branch: they hold the same state)
-        if (!rng_loaded) g.load(io.rng, i);
-        rng_loaded = true;
-    };
-
+    g.load(io.rng, i);
+    bool rng_used = false;  // (all 16 lanes of the instance take the same branches: they hold the same state)
     uint32_t* coins = io.coins + (size_t)i * MAX_COINS;
     const size_t k = (size_t)i * SLOTS + ls;  // lane ls looks after slot ls
+    SlotRec mine;
+    mine.t = io.sp_t[k];
+    mine.speed = io.sp_speed[k];
+    mine.ang = io.sp_ang[k];
+    mine.r = io.sp_r[k];
+    g.pin();
 
     // CharacterController.step(action, walkable_rect = (0, 4, 84, 80))
     int a0 = actions[2 * i], a1 = actions[2 * i + 1];
@@ -848,6 +897,10 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
               SCREEN - P.agent_radius);
     s.ax = (int16_t)ax;
     s.ay = (int16_t)ay;
+#ifdef MG_LAB_SPOT_CLOCK
+    asm volatile("" ::"v"(ax), "v"(ay));
+#endif
+    SPOT_CLOCK(1);
     // the top bar shows the PREVIOUS action
     int shown0 = s.la0, shown1 = s.la1;
     if (EN || P.show_last_action) {
@@ -870,23 +923,24 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     s.spawn_timer++;
     if constexpr (EN) {
         if (__builtin_expect(s.spawn_timer >= P.spawn_interval, 0)) {
-            need_rng();
-            new_spot(P, io, i, ls, s, g, T);
+#ifdef MG_LAB_SPOT_CLOCK
+            f_spawn = true;
+#endif
+            rng_used = true;
+            new_spot(P, io, i, ls, s, g, &mine);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
         if (__builtin_expect(s.spawn_timer >= P.interval0, 0)) {
-            need_rng();
-            new_spot(P, io, i, ls, s, g, T);
+            rng_used = true;
+            new_spot(P, io, i, ls, s, g, &mine);
             s.n_intervals--;
             s.spawn_timer = 0;
         }
     }
-    // the slot record, AFTER the spawn (a spotlight born into this lane's slot just now is read back: the lane wrote it itself)
-    double p_t = io.sp_t[k], p_speed = io.sp_speed[k];
-    double p_sx = io.sp_sx[k], p_sy = io.sp_sy[k], p_tx = io.sp_tx[k], p_ty = io.sp_ty[k], p_ox = io.sp_ox[k], p_oy = io.sp_oy[k];
-    int p_r = io.sp_r[k];  // bit 7: has_border
-    bool p_done = io.sp_done[k] != 0;
+    SPOT_CLOCK(2);
+    const int p_r = mine.r;  // bit 7: has_border
+    const bool p_done = mine.t >= 1.0;
     const bool used = !((s.free_mask >> ls) & 1u);
     const bool my_done = used && p_done;
     const uint32_t done_mask = (uint32_t)(__ballot(my_done) >> group_shift) & 0xFFFFu;
@@ -916,7 +970,12 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     }
     bool my_hit = false;
     if ((processed >> ls) & 1u) {
-        double t = p_t;
+        const int radius0 = p_r & 127;
+        const double R = P.half_diag + (double)radius0, c = SCREEN / 2;  // Spotlight.__init__'s end points (see SpotIO)
+        const int a_s = (int)(mine.ang & 511u), a_t = (int)((mine.ang >> 9) & 511u), a_o = (int)(mine.ang >> 18);
+        const double p_sx = c + T.c[a_s] * R, p_sy = c + T.s[a_s] * R, p_tx = c + T.c[a_t] * R, p_ty = c + T.s[a_t] * R;
+        const double p_ox = c + T.c[a_o] * R, p_oy = c + T.s[a_o] * R;
+        double t = mine.t;
         double lx = p_tx * (1 - t) + p_ox * t, ly = p_ty * (1 - t) + p_oy * t;
         double cx = p_sx * (1 - t) + lx * t, cy = p_sy * (1 - t) + ly * t;
         const int radius = p_r & 127;
@@ -930,17 +989,18 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
             }
         }
         io.desc[i].holes[rank] = pack_hole((int)cx, (int)cy, radius) | ((uint32_t)(p_r >> 7) << 31);
-        t += p_speed;
-        if (t >= 1.0) {
-            t = 1.0;
-            io.sp_done[k] = 1;
-        }
+        t += mine.speed;
+        if (t >= 1.0) t = 1.0;  // = done: removed from the list by the next step
         io.sp_t[k] = t;
         double ddx = (double)ax - cx, ddy = (double)ay - cy;
         my_hit = sqrt(ddx * ddx + ddy * ddy) <= (double)(radius + P.agent_radius);
     }
     const int hit = __popc((uint32_t)(__ballot(my_hit) >> group_shift) & 0xFFFFu);
     const int nh = __popc(processed);
+#ifdef MG_LAB_SPOT_CLOCK
+    asm volatile("" ::"v"(hit));
+#endif
+    SPOT_CLOCK(3);
     if (hit > 0) {
         s.health -= P.damage;
         r += P.r_inside;
@@ -964,13 +1024,15 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     if constexpr (EN) {
         if (P.coin_enabled) {
             double cr = 0.0;
-            double ddx = (double)ax - (double)s.coin_x, ddy = (double)ay - (double)s.coin_y;
-            if (__builtin_expect(sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius), 0)) {
+            if (__builtin_expect(within(ax - (int)s.coin_x, ay - (int)s.coin_y, P.coin_radius + P.agent_radius), 0)) {
                 cr += P.r_coin;
                 s.coins_collected++;
                 s.coin_t = 0;
                 // _spawn_coin: sampler reset, previous coin blocked with r = 28
-                need_rng();
+#ifdef MG_LAB_SPOT_CLOCK
+                f_coin = true;
+#endif
+                rng_used = true;
                 Discs D;
                 D.p = disc_slot(disc_lds, L.grp);
                 D.n = 0;
@@ -1004,8 +1066,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
             for (int q = 0; q < MAX_COINS; ++q) {  // remove-while-iterating: the coin after a collected one is skipped
                 if (q >= s.n_coins) break;
                 int cx = (int)(int16_t)(coin_pos[q] & 0xFFFF), cy = (int)(coin_pos[q] >> 16);
-                double ddx = (double)ax - cx, ddy = (double)ay - cy;
-                if (sqrt(ddx * ddx + ddy * ddy) <= (double)(P.coin_radius + P.agent_radius)) {
+                if (within(ax - cx, ay - cy, P.coin_radius + P.agent_radius)) {
 #pragma unroll
                     for (int j = q; j < MAX_COINS - 1; ++j)
                         if (j < s.n_coins - 1) coin_pos[j] = coin_pos[j + 1];
@@ -1035,6 +1096,10 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
         s.t++;
         if (s.t == P.max_steps) done = true;
     }
+#ifdef MG_LAB_SPOT_CLOCK
+    asm volatile("" ::"v"(done));
+#endif
+    SPOT_CLOCK(4);
     bool shown_last_pos = s.last_pos;
     if (P.show_last_positive_reward) s.last_pos = reward > 0 ? 1 : 0;
     s.ep_sum += reward;
@@ -1065,10 +1130,11 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
     // frame; state, stream and the descriptor head (its n_holes are the reset frame's stale holes) are stored as after
     // any other step, exactly what a masked mg_reset(seed = None) would find.
     const bool reset_me = done && autoreset;
+    SPOT_CLOCK(5);
     if (defer && reset_me && leader) queue_push(io.queue, &io.qctr[SQ_COUNT], P.n, i, io.err);
     if (__builtin_expect(reset_me && !defer, 0)) {  // cold: keep the reset code out of the hot instruction stream
-        need_rng();
-        spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds, L.grp), T);
+        rng_used = true;
+        spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && leader) ? gt + 4 * i : nullptr, nh, disc_slot(disc_lds, L.grp));
     } else {
         d.bg = bg_template(s.pad, s.bg_red);
         d.sprite = s.rot8;
@@ -1110,11 +1176,26 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
             gt[4 * i + 3] = (float)(P.coin_enabled ? (double)s.coin_y / SCREEN : 0.0);
         }
     }
+    SPOT_CLOCK(6);
     if (leader) {
-        if (rng_loaded) g.store(io.rng, i);
+        if (rng_used) g.store(io.rng, i);
         io.core[i] = s;
         store_desc_head(&io.desc[i], d);
     }
+#ifdef MG_LAB_SPOT_CLOCK
+    __builtin_amdgcn_s_waitcnt(0);
+    SPOT_CLOCK(7);
+    {
+        const unsigned long long any_spawn = __ballot(f_spawn) != 0, any_coin = __ballot(f_coin) != 0, any_reset = __ballot(reset_me && !defer) != 0;
+        const int wave = i >> 2;
+        if ((threadIdx.x & 63) == 0 && wave < 65536) {
+            unsigned long long* o = g_lab_spot_clock + 10 * (size_t)wave;
+            for (int q = 0; q < 8; ++q) o[q] = clk[q];
+            o[8] = any_spawn | (any_coin << 1) | (any_reset << 2);
+            o[9] = (wall0 & 0xFFFFFFFFull) | (wall_clock64() << 32);
+        }
+    }
+#endif
 }
 
 template <bool EN, bool PS>
@@ -1203,7 +1284,7 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
                 SpotDesc d;
                 const int stale_holes = (int)(reinterpret_cast<const uint32_t*>(&io.desc[i])[2] & 0xFFu);
                 spot_reset<EN>(P, io, i, L, s, g, d, (gt && EN && ls == 0) ? gt + 4 * i : nullptr, stale_holes,
-                               disc_slot(reinterpret_cast<int*>(smem), L.grp), Trig{P.cos_tab, P.sin_tab});
+                               disc_slot(reinterpret_cast<int*>(smem), L.grp));
                 d.valid = DESC_SERVED;
                 if (ls == 0) {
                     io.core[i] = s;
@@ -1274,9 +1355,9 @@ class SpotFamily : public Family {
             opt_[0]->st_num_coins.set(P_.num_coins, {1}); P_.agent_health = 5; P_.r_exit = 1.0; P_.use_exit = 1;
         }
         core_.alloc(n);
-        for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) a->alloc((size_t)SLOTS * n);
+        for (auto* a : {&sp_t_, &sp_speed_}) a->alloc((size_t)SLOTS * n);
+        sp_ang_.alloc((size_t)SLOTS * n);
         sp_r_.alloc((size_t)SLOTS * n);
-        sp_done_.alloc((size_t)SLOTS * n);
         flags_.alloc(4);
         queue_.alloc((size_t)n + SQ_WORDS);
 
@@ -1483,8 +1564,8 @@ class SpotFamily : public Family {
 
     std::vector<std::pair<void*, size_t>> state_blobs() override {
         std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {coins_.p, coins_.bytes()}, {sp_r_.p, sp_r_.bytes()},
-                                                  {sp_done_.p, sp_done_.bytes()}};
-        for (auto* a : {&sp_t_, &sp_speed_, &sp_sx_, &sp_sy_, &sp_tx_, &sp_ty_, &sp_ox_, &sp_oy_}) v.push_back({a->p, a->bytes()});
+                                                  {sp_ang_.p, sp_ang_.bytes()}};
+        for (auto* a : {&sp_t_, &sp_speed_}) v.push_back({a->p, a->bytes()});
         v.push_back({flags_.p, flags_.bytes()});
         rng_.blobs(v);
         return v;
@@ -1500,9 +1581,7 @@ class SpotFamily : public Family {
     SpotIO io() {
         SpotIO o;
         o.core = core_.p;
-        o.sp_t = sp_t_.p; o.sp_speed = sp_speed_.p; o.sp_sx = sp_sx_.p; o.sp_sy = sp_sy_.p;
-        o.sp_tx = sp_tx_.p; o.sp_ty = sp_ty_.p; o.sp_ox = sp_ox_.p; o.sp_oy = sp_oy_.p;
-        o.sp_r = sp_r_.p; o.sp_done = sp_done_.p;
+        o.sp_t = sp_t_.p; o.sp_speed = sp_speed_.p; o.sp_ang = sp_ang_.p; o.sp_r = sp_r_.p;
         o.coins = coins_.p;
         o.rng = rng_.view();
         o.desc = desc_.p;
@@ -1663,8 +1742,9 @@ class SpotFamily : public Family {
    private:
     std::unique_ptr<Atlas> atlas_;
     DevArray<SpotCore> core_;
-    DevArray<double> sp_t_, sp_speed_, sp_sx_, sp_sy_, sp_tx_, sp_ty_, sp_ox_, sp_oy_, cos_, sin_;
-    DevArray<uint8_t> sp_r_, sp_done_;
+    DevArray<double> sp_t_, sp_speed_, cos_, sin_;
+    DevArray<uint32_t> sp_ang_;
+    DevArray<uint8_t> sp_r_;
     DevArray<int> queue_;  // deferred resets: the counters + n entries
     DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)
     DevArray<uint32_t> coins_;
@@ -1687,3 +1767,14 @@ void SpotFamily::raster_debug(void* frames, hipStream_t s) {
 Family* make_spot(int endless, int num_envs) { return new SpotFamily(endless, num_envs); }
 
 }  // namespace mg
+
+#ifdef MG_LAB_SPOT_CLOCK
+extern "C" int mg_lab_spot_clock(unsigned long long* host, int n_waves, int clear) {
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mg::g_lab_spot_clock)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 10 * 65536) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_spot_clock), sizeof(unsigned long long) * 10 * (size_t)n_waves) == hipSuccess ? 0 : -1;
+}
+#endif
