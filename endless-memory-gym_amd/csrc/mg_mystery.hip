@@ -197,6 +197,10 @@ struct MysteryIO {
     // telemetry of the finite variants' path generation inside the step's launches (bench.py: C3's measured reset share):
     // [0] wave-ticks (real-time clock, 10 ns) spent generating paths, [1] paths generated; mg_debug_counter "path_gen_ticks" / "path_gen_paths"
     unsigned long long* stats;
+    // per-instance option sets (mg_set_option_set / mg_bind_option_sets): instance i runs under sets[set_of[i]]; both NULL while the
+    // handle has one set.  Read by the <PS = true> forms of the reset / step / queue-server kernels only.
+    const struct MysteryParams* sets;
+    const int32_t* set_of;
 };
 constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_BG_COUNT = 96, QC_BG_LEFT = 128, QC_WORDS = 160;  // one 128-byte line each
 // MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
@@ -1058,9 +1062,11 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
 
 // Debug descriptors from the state and the current frame descriptors (see MysteryDebugComposer; oracle/mgo_mystery.c
 // mpf_debug / emp_debug).
-__global__ __launch_bounds__(256) void mystery_debug_desc_kernel(MysteryParams P, MysteryIO io, MysteryDesc* out) {
+template <bool PS>
+__global__ __launch_bounds__(256) void mystery_debug_desc_kernel(MysteryParams P0, MysteryIO io, MysteryDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
+    if (i >= P0.n) return;
+    const MysteryParams& P = PS ? io.sets[io.set_of[i]] : P0;
     const MysteryCore s = io.core[i];
     MysteryDesc d = io.desc[i];
     d.valid = 1;
@@ -1119,14 +1125,16 @@ __device__ __forceinline__ int instance_of_lane(int lpw, bool& worker) {
     return wave * lpw + lane;
 }
 
-__global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds,
+template <bool PS>
+__global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P0, MysteryIO io, const int64_t* seeds,
                                                             const uint8_t* mask, float* gt, int lpw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     path_ws_init(smem);
     const PathWS W{smem, io.jump, io.stats};
     bool worker;
     const int i = instance_of_lane(lpw, worker);
-    const bool in_range = worker && i < P.n;
+    const bool in_range = worker && i < P0.n;
+    const MysteryParams& P = (PS && in_range) ? io.sets[io.set_of[i]] : P0;  // (PS: per-instance option sets)
     const bool active = in_range && !(mask && !mask[i]);
     if (in_range && !active) io.desc[i].valid = 0;
     Pcg g;
@@ -1161,7 +1169,8 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P, Mys
 // workgroups of the raster launch that follows (mystery_raster_paths_kernel).  The launch no longer lasts as long as one noisy A* (23 us) whenever any of
 // its instances resets (MysteryPath-Grid: 0.5 % of them per step).
 constexpr int HYBRID_INLINE = 2;
-__global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions,
+template <bool PS>
+__global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, MysteryIO io, const int32_t* actions,
                                                            float* reward_out, uint8_t* done_out, float* gt,
                                                            mg_info_buffers info, int autoreset, int lpw, int defer) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1169,7 +1178,8 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
     const PathWS W{smem, io.jump, io.stats};
     bool worker;
     const int i = instance_of_lane(lpw, worker);
-    const bool active = worker && i < P.n;
+    const bool active = worker && i < P0.n;
+    const MysteryParams& P = (PS && active) ? io.sets[io.set_of[i]] : P0;  // (PS: per-instance option sets)
     MysteryCore s;
     Pcg g;
     MysteryDesc d;
@@ -1223,10 +1233,12 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P, Myst
 // plain instance = "reset".
 constexpr int EMP_Q_SEGMENT = 1 << 30;
 
-__global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P, MysteryIO io, const int32_t* actions, float* reward_out,
+template <bool PS>
+__global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, MysteryIO io, const int32_t* actions, float* reward_out,
                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
+    if (i >= P0.n) return;
+    const MysteryParams& P = PS ? io.sets[io.set_of[i]] : P0;  // (PS: per-instance option sets)
     LAB_STEP_CLOCK(0);
     int act = actions[i];  // requested together with the state record ...
     MysteryCore s = load_core(&io.core[i]);
@@ -1674,6 +1686,7 @@ __global__ __launch_bounds__(64) void emp_reset_lanes_kernel(MysteryParams P, My
 }
 
 // all != 0: mg_reset of every instance (entry k = instance k, seeds may be given); otherwise the queue is drained
+template <bool PS>
 __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, MysteryIO io, const int64_t* seeds, int all, float* reward_out,
                                                         uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1687,7 +1700,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
     int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
     while (idx < count) {
         const int entry = all ? idx : bcast(io.queue[idx], 0);
-        emp_serve_entry(P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
+        emp_serve_entry(PS ? io.sets[io.set_of[entry & (EMP_Q_SEGMENT - 1)]] : P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
         if (me) {
             idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
         }
@@ -1878,9 +1891,11 @@ class MysteryFamily : public Family {
             segs_.alloc(16);
             falloff_.alloc(4);
         }
+        sets_dev_.alloc(MG_MAX_OPTION_SETS);
         hipLaunchKernelGGL(mystery_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, core_.p);
         MG_HIP(hipDeviceSynchronize());
         rebuild();
+        defaults_ = P_;  // (the cardinal list is short: no device array behind it)
     }
 
     int action_dim() const override { return (P_.endless || P_.grid) ? 1 : 2; }
@@ -1890,25 +1905,46 @@ class MysteryFamily : public Family {
         return k == 0 ? "success" : (k == 1 ? "num_fails" : nullptr);
     }
 
-    void set_option(const std::string& key, const double* v, int n) override {
+    // One key of the reset options, for option set `set` (0 = the handle-wide set of mg_set_option).  Sets > 0 hold everything that
+    // does not change the geometry (sprites, camera offset and speeds are shared by the handle's instances).
+    void set_option(const std::string& key, const double* v, int n) override { set_option_set(0, key, v, n); }
+    void set_option_set(int set, const std::string& key, const double* v, int n) override {
+        if (set < 0 || set >= MG_MAX_OPTION_SETS) throw OptionError{-3, "option set index out of range"};
+        while ((int)extra_.size() < set) {  // a new set starts from the constructor's defaults (= the reference's), geometry from set 0
+            extra_.emplace_back(new MysteryOpt());
+            extra_.back()->P = defaults_;
+            copy_geometry(extra_.back()->P, P_);
+        }
+        MysteryParams& P = set == 0 ? P_ : extra_[set - 1]->P;
+        OptListStore& st_cardinal = set == 0 ? st_cardinal_ : extra_[set - 1]->st_cardinal;
         const bool e = P_.endless;
         auto I = [&](int& dst) { dst = to_int_checked(v[0], key.c_str()); };
         auto B = [&](int& dst) { dst = v[0] != 0.0; };
         auto must_be = [&](bool ok) { if (!ok) throw OptionError{-3, "reset parameter " + key + ": this value is not supported by the MI355X build"}; };
-        if (key == "max_steps") I(P_.max_steps);
-        else if (key == "agent_scale") { agent_scale_ = v[0]; dirty_ = true; }
-        else if (!P_.grid && key == "agent_speed") { agent_speed_ = v[0]; dirty_ = true; }
-        else if (key == "show_origin") { B(P_.show_origin); if (e) P_.show_origin = 0; /* dead branch in the reference (:150) */ }
-        else if (key == "visual_feedback") B(P_.visual_feedback);
-        else if (key == "reward_fall_off") P_.r_fall = v[0];
-        else if (key == "reward_path_progress") P_.r_progress = v[0];
-        else if (key == "reward_step") P_.r_step = v[0];
-        else if (e && key == "show_past_path") B(P_.show_past_path);
-        else if (e && key == "show_background") B(P_.show_background);
-        else if (e && key == "show_stamina") B(P_.show_stamina);
-        else if (e && key == "camera_offset_scale") { camera_offset_scale_ = v[0]; dirty_ = true; }
-        else if (e && key == "stamina_level") { I(P_.stamina_level); must_be(P_.stamina_level > 0); }
-        else if (e && key == "reward_path_progress_dense") P_.r_dense = v[0];
+        // (a geometry option in a set > 0 is accepted when it says what the handle's geometry already is)
+        auto geometry = [&](double& mine) {
+            if (set != 0) {
+                if (v[0] != mine)
+                    throw OptionError{-3, "reset parameter " + key + " changes the geometry shared by the handle's instances: it can only be set for all of them (option set 0)"};
+            } else {
+                mine = v[0];
+                dirty_ = true;
+            }
+        };
+        if (key == "max_steps") I(P.max_steps);
+        else if (key == "agent_scale") geometry(agent_scale_);
+        else if (!P_.grid && key == "agent_speed") geometry(agent_speed_);
+        else if (key == "show_origin") { B(P.show_origin); if (e) P.show_origin = 0; /* dead branch in the reference (:150) */ }
+        else if (key == "visual_feedback") B(P.visual_feedback);
+        else if (key == "reward_fall_off") P.r_fall = v[0];
+        else if (key == "reward_path_progress") P.r_progress = v[0];
+        else if (key == "reward_step") P.r_step = v[0];
+        else if (e && key == "show_past_path") B(P.show_past_path);
+        else if (e && key == "show_background") B(P.show_background);
+        else if (e && key == "show_stamina") B(P.show_stamina);
+        else if (e && key == "camera_offset_scale") geometry(camera_offset_scale_);
+        else if (e && key == "stamina_level") { I(P.stamina_level); must_be(P.stamina_level > 0); }
+        else if (e && key == "reward_path_progress_dense") P.r_dense = v[0];
         else if (!e && key == "cardinal_origin_choice") {
             must_be(n >= 1);  // any length; every value other than 0, 1, 2 takes the reference's `else` branch (mystery_path.py:155-166)
             std::vector<int> vals(n);
@@ -1916,33 +1952,47 @@ class MysteryFamily : public Family {
                 const int c = to_int_checked(v[k], key.c_str());
                 vals[k] = (c >= 0 && c <= 2) ? c : 3;
             }
-            st_cardinal_.set(P_.cardinal, vals);
+            st_cardinal.set(P.cardinal, vals);
         }
-        else if (!e && key == "show_goal") B(P_.show_goal);
-        else if (!e && key == "reward_goal") P_.r_goal = v[0];
+        else if (!e && key == "show_goal") B(P.show_goal);
+        else if (!e && key == "reward_goal") P.r_goal = v[0];
         else throw OptionError{-2, "unknown reset parameter " + key};
+        sets_dirty_ = true;
     }
+    // instance i runs under option set set_of_dev[i] (device array [num_envs], caller-owned; NULL: every instance under set 0)
+    void bind_option_sets(const int32_t* set_of_dev) override { set_of_ = set_of_dev; }
 
     void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) override {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         if (seeds) seeded_ = true;
+        const bool ps = per_set();
         if (P_.endless) {
             mg_info_buffers none;
             memset(&none, 0, sizeof(none));
             P_.lazy = 0;  // an explicit reset generates all three segments (whatever an old episode is owed comes first)
+            upload_sets(s);
             if (mask) {
                 hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
-                hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,
-                                   (uint8_t*)nullptr, gt, none, 0);
-            } else if (n_ >= 1024 && reset_by_lanes()) {  // many paths at once: one lane per instance
+                if (ps)
+                    hipLaunchKernelGGL(emp_serve_kernel<true>, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,
+                                       (uint8_t*)nullptr, gt, none, 0);
+                else
+                    hipLaunchKernelGGL(emp_serve_kernel<false>, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,
+                                       (uint8_t*)nullptr, gt, none, 0);
+            } else if (n_ >= 1024 && reset_by_lanes() && !ps) {  // many paths at once: one lane per instance
                 hipLaunchKernelGGL(emp_reset_lanes_kernel, dim3((n_ + 63) / 64), dim3(64), LW_BYTES, s, P_, io(), seeds, gt);
+            } else if (ps) {
+                hipLaunchKernelGGL(emp_serve_kernel<true>, dim3(servers(true)), dim3(256), WS_BYTES, s, P_, io(), seeds, 1, (float*)nullptr,
+                                   (uint8_t*)nullptr, gt, none, 0);
             } else {
-                hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(true)), dim3(256), WS_BYTES, s, P_, io(), seeds, 1, (float*)nullptr,
+                hipLaunchKernelGGL(emp_serve_kernel<false>, dim3(servers(true)), dim3(256), WS_BYTES, s, P_, io(), seeds, 1, (float*)nullptr,
                                    (uint8_t*)nullptr, gt, none, 0);
             }
         } else {
-            hipLaunchKernelGGL(mystery_reset_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
+            upload_sets(s);
+            if (ps) hipLaunchKernelGGL(mystery_reset_kernel<true>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
+            else hipLaunchKernelGGL(mystery_reset_kernel<false>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
         }
         raster(obs, s);
     }
@@ -1954,15 +2004,19 @@ class MysteryFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         prof.begin(0, s);
+        const bool ps = per_set();
         if (P_.endless) {
             // lazy initial segments need the fused launch (its frame workgroups carry the background jobs); any other path
             // first generates what earlier fused steps left owed
-            const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC;
+            // (per-instance option sets: the plain arrangement -- step kernel, queue server, raster -- whose kernels have a <PS> form)
+            const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC && !ps;
             P_.lazy = (fused && lazy_wanted_) ? 1 : 0;
             if (!P_.lazy && owed_possible_) flush_owed(s);
             if (P_.lazy) owed_possible_ = true;
+            upload_sets(s);
             const int sb = step_block(256);
-            hipLaunchKernelGGL(emp_step_kernel, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+            if (ps) hipLaunchKernelGGL(emp_step_kernel<true>, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+            else hipLaunchKernelGGL(emp_step_kernel<false>, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
             if (fused) {  // the queue is served inside the raster launch
                 end_logic(s);
                 prof.begin(1, s);
@@ -1978,12 +2032,22 @@ class MysteryFamily : public Family {
 #endif
                 return;
             }
-            hipLaunchKernelGGL(emp_serve_kernel, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
-                               reward, done, gt, ib, autoreset);
+            if (ps)
+                hipLaunchKernelGGL(emp_serve_kernel<true>, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
+                                   reward, done, gt, ib, autoreset);
+            else
+                hipLaunchKernelGGL(emp_serve_kernel<false>, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), (const int64_t*)nullptr, 0,
+                                   reward, done, gt, ib, autoreset);
         } else {
+            // (per-instance option sets: only this kernel has a <PS> form -- the raster launch's path service reads nothing of the options)
             const int defer = autoreset ? defer_mode() : 0;
-            hipLaunchKernelGGL(mystery_step_kernel, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
-                               (float*)nullptr, ib, autoreset, lpw(), defer);
+            upload_sets(s);
+            if (ps)
+                hipLaunchKernelGGL(mystery_step_kernel<true>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
+                                   (float*)nullptr, ib, autoreset, lpw(), defer);
+            else
+                hipLaunchKernelGGL(mystery_step_kernel<false>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
+                                   (float*)nullptr, ib, autoreset, lpw(), defer);
             if (defer) {  // the paths of this step's resets are generated by the first workgroups of the raster launch
                 end_logic(s);
                 prof.begin(1, s);
@@ -2097,7 +2161,34 @@ class MysteryFamily : public Family {
         o.bgq = bgq_.p;
         o.jump = jump_.p;
         o.stats = stats_.p;
+        o.sets = per_set() ? sets_dev_.p : nullptr;
+        o.set_of = per_set() ? set_of_ : nullptr;
         return o;
+    }
+
+    // per-instance option sets
+    struct MysteryOpt {
+        MysteryParams P;
+        OptListStore st_cardinal;
+    };
+    // what the shared atlas, the camera and the launch arrangement fix for every set of the handle
+    static void copy_geometry(MysteryParams& d, const MysteryParams& s) {
+        d.endless = s.endless; d.grid = s.grid; d.n = s.n; d.depth = s.depth; d.agent_radius = s.agent_radius; d.sprite_dim = s.sprite_dim;
+        d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.tile = s.tile; d.cross_dim = s.cross_dim; d.camera_offset = s.camera_offset;
+        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help;
+    }
+    bool per_set() const { return set_of_ != nullptr && !extra_.empty(); }
+    // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)
+    void upload_sets(hipStream_t s) {
+        if (!per_set() || !sets_dirty_) return;
+        std::vector<MysteryParams> host(MG_MAX_OPTION_SETS, P_);
+        for (size_t k = 0; k < extra_.size(); ++k) {
+            host[k + 1] = extra_[k]->P;
+            copy_geometry(host[k + 1], P_);  // (incl. lazy = 0: the plain arrangement generates every segment when it is due)
+        }
+        MG_HIP(hipMemcpyAsync(sets_dev_.p, host.data(), sizeof(MysteryParams) * host.size(), hipMemcpyHostToDevice, s));
+        MG_HIP(hipStreamSynchronize(s));  // (rare: only after an option of some set changed)
+        sets_dirty_ = false;
     }
 
     void rebuild() {
@@ -2149,7 +2240,12 @@ class MysteryFamily : public Family {
     }
 
     int n_;
-    MysteryParams P_;
+    MysteryParams P_;       // option set 0 (the handle-wide set of mg_set_option)
+    MysteryParams defaults_;
+    std::vector<std::unique_ptr<MysteryOpt>> extra_;  // option sets 1 ..
+    const int32_t* set_of_ = nullptr;
+    bool sets_dirty_ = true;
+    DevArray<MysteryParams> sets_dev_;
     double agent_scale_, agent_speed_, camera_offset_scale_ = 5.0;
     bool dirty_ = true, seeded_ = false;
 
@@ -2193,7 +2289,9 @@ void MysteryFamily::raster_debug(void* frames, hipStream_t s) {
     if (dirty_) throw std::runtime_error("options that change geometry need a reset before the next render");
     DevArray<MysteryDesc> dbg;
     dbg.alloc(n_, false);
-    hipLaunchKernelGGL(mystery_debug_desc_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
+    upload_sets(s);
+    if (per_set()) hipLaunchKernelGGL(mystery_debug_desc_kernel<true>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
+    else hipLaunchKernelGGL(mystery_debug_desc_kernel<false>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
     launch_raster<MysteryDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
     MG_HIP(hipGetLastError());
     MG_HIP(hipStreamSynchronize(s));  // dbg is released on return

@@ -106,9 +106,9 @@ int mg_set_option(mg_env* env, const char* key, const double* values, int n);
  * Options that change the geometry shared by the handle's instances (the *_scale, agent_speed, arena_size, radius and dim /
  * interval options that rebuild atlases, templates or tables) can only be set in set 0, i.e. for all instances: -3 otherwise.
  * A geometry option is accepted in a set > 0 when it says what the handle's geometry already is.
- * Families: Mortar Mayhem (all five ids) and Searing Spotlights (both ids) in this build; the Mystery Path family refuses sets
- * > 0 with -3 (one handle per set).  With more than one set in use the per-set kernels read their parameters from memory: a
- * mortar-family handle then steps with two launches, a SearingSpotlights handle resets inside its step kernel. */
+ * Every family (all ten ids).  With more than one set in use the per-set kernels read their parameters from memory and a handle
+ * steps in its plain arrangement: a mortar-family handle with two launches, a SearingSpotlights handle resets inside its step
+ * kernel, an Endless-MysteryPath handle serves its queue in a launch of its own (and generates every segment when it is due). */
 #define MG_MAX_OPTION_SETS 8
 int mg_set_option_set(mg_env* env, int set_id, const char* key, const double* values, int n);
 int mg_bind_option_sets(mg_env* env, const int32_t* set_of_dev);

@@ -27,6 +27,11 @@ CASES = [
      dict(spawn_interval=20, initial_spawns=5, coin_show_duration=2, spot_damage=2.0, max_steps=70)),
     ("SearingSpotlights-v0", dict(num_coins=[2], reward_exit=2.0, sample_agent_position=False),
      dict(num_coins=[1, 3], agent_health=2, coins_visible=True, max_steps=60, black_background=True)),
+    ("MysteryPath-Grid-v0", dict(max_steps=24, reward_goal=2.0, show_origin=True, cardinal_origin_choice=[0, 2]),
+     dict(max_steps=40, reward_fall_off=-0.1, reward_step=-0.01, show_goal=True, visual_feedback=False)),
+    ("MysteryPath-v0", dict(max_steps=30, reward_path_progress=0.2, show_goal=True), dict(max_steps=50, cardinal_origin_choice=[1, 3], show_origin=True)),
+    ("Endless-MysteryPath-v0", dict(max_steps=40, stamina_level=10, show_stamina=True, reward_path_progress_dense=0.05),
+     dict(max_steps=64, show_past_path=False, show_background=True, reward_fall_off=-0.2)),
 ]
 
 
@@ -80,18 +85,18 @@ def test_two_halves_two_option_sets(env_id, opt_a, opt_b):
     env.close()
 
 
-def test_families_without_option_sets_refuse_instead_of_reparametrising_everybody():
+def test_geometry_options_are_refused_for_a_subset_instead_of_reparametrising_everybody():
     import memory_gym_amd
     import torch
 
-    env = memory_gym_amd.make("MysteryPath-v0", num_envs=64, device=0)  # (the Mystery Path family has no option sets in this build)
+    env = memory_gym_amd.make("Endless-MysteryPath-v0", num_envs=64, device=0)
     env.reset(seed=1)
     mask = torch.zeros(64, dtype=torch.bool, device="cuda")
     mask[:10] = True
     env.reset(mask=mask)  # options=None: the instances keep what they have
     env.reset(options=dict(), mask=mask)  # the defaults they run under anyway: nothing to refuse
     with pytest.raises(NotImplementedError):
-        env.reset(options=dict(max_steps=40), mask=mask)
+        env.reset(options=dict(camera_offset_scale=3.0), mask=mask)  # the camera is the handle's
     env.close()
     env = memory_gym_amd.make("SearingSpotlights-v0", num_envs=64, device=0)  # a geometry option cannot differ between instances
     env.reset(seed=1)
@@ -101,7 +106,8 @@ def test_families_without_option_sets_refuse_instead_of_reparametrising_everybod
 
 
 @pytest.mark.parametrize("env_id", ["MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0", "MortarMayhemB-Grid-v0", "MortarMayhemB-v0",
-                                    "SearingSpotlights-v0", "Endless-SearingSpotlights-v0"])
+                                    "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-v0", "MysteryPath-Grid-v0",
+                                    "Endless-MysteryPath-v0"])
 def test_reference_sessions_two_per_handle(env_id):
     """Recorded sessions of the UNMODIFIED reference under different random option dictionaries (tests/golden/fuzz_*.npz),
     two at a time through ONE handle: instance 0 replays one session, instance 1 the next -- each reset is a masked reset with
@@ -116,7 +122,8 @@ def test_reference_sessions_two_per_handle(env_id):
     # options that fix the geometry the handle's instances share (atlases, templates) cannot differ between two instances of one
     # handle: sessions are paired with a partner of the same geometry, and the handle is brought to it by a full reset first
     geo = lambda o: tuple(repr(o.get(k)) for k in (  # noqa: E731
-        "arena_size", "agent_scale", "agent_speed", "coin_scale", "show_last_action", "initial_spawn_interval", "spawn_interval_threshold", "exit_scale"))
+        "arena_size", "agent_scale", "agent_speed", "coin_scale", "show_last_action", "initial_spawn_interval", "spawn_interval_threshold", "exit_scale",
+        "camera_offset_scale"))
     order = sorted(range(len(metas)), key=lambda j: geo(metas[j]["options"]))
     todo = [(order[j], order[j + 1]) for j in range(len(order) - 1) if geo(metas[order[j]]["options"]) == geo(metas[order[j + 1]]["options"])]
     if not todo:
