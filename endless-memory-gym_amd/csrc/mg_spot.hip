@@ -1215,7 +1215,13 @@ __global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
 // barrier, s_dcache_inv first.  Service workgroups without an entry leave at once and issue no atomic (thousands of them on
 // one address: 22 ns each, in series).  What bounds the launch is a reset's latency next to the raster's waves (~45-80 us)
 // plus the frames that follow it in the same workgroup; variants measured: profiles/r02_spot_resets.md.
-constexpr int SPOT_SVC_WGS = 512, SPOT_SVC_BATCH = 8;
+#ifndef MG_SPOT_SVC_BATCH
+#define MG_SPOT_SVC_BATCH 8
+#endif
+#ifndef MG_SPOT_SVC_WGS
+#define MG_SPOT_SVC_WGS 512
+#endif
+constexpr int SPOT_SVC_WGS = MG_SPOT_SVC_WGS, SPOT_SVC_BATCH = MG_SPOT_SVC_BATCH;
 static_assert(SPOT_SVC_BATCH * (DISC_INTS * 4 + (int)sizeof(SpotCore)) <= FRAME_BYTES, "a service batch's disc lists and core records fit into the frame area");
 // Workgroups per CU of the fused launch (round 4, profiles/r04_spot_serve.md): SIX, non-temporal stores.  Rounds 2-3 ran it at five (96
 // VGPRs and 104-124 B of scratch, 28 KiB of LDS): with the core record of a reset in LDS and the arguments of the service loop
@@ -1292,7 +1298,12 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
                     store_desc_head(&io.desc[i], d);
                 }
             }
-            __threadfence();
+            // The descriptors just stored are read back by THIS workgroup's composers through the scalar cache: the stores have to
+            // have reached the L2 (workgroup-scope release = s_waitcnt vmcnt(0); the vector L1 writes through) and the scalar cache
+            // must not answer from an older copy (s_dcache_inv).  NOT __threadfence(): at agent scope that is buffer_wbl2 +
+            // buffer_inv -- a write-back of the whole L2, which holds the launch's observation stream (round 4: the cost of the
+            // launch grew with the number of workgroups that served resets, profiles/r04_spot_serve.md).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             __builtin_amdgcn_s_dcache_inv();
             for (int k = 0; k < SPOT_SVC_BATCH && base + k < count; ++k) draw(io.queue[base + k]);
