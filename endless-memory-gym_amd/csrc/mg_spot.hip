@@ -484,6 +484,9 @@ __device__ __forceinline__ int popc128(u128m m) { return __popcll((unsigned long
 // instance re-spawned its coin).
 constexpr int ROWS_PER_LANE = 6;
 static_assert(ROWS_PER_LANE * 14 == SCREEN, "14 lanes x 6 rows cover the sampler grid");
+// ONE: with the single-disc path (the endless variant's coin re-sampling); the finite variant's reset calls it with one to ten discs
+// and has no registers to spare for a second form of the row loop (its fused raster / reset kernel spills as it is).
+template <bool ONE>
 __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx& L, int* ox, int* oy) {
     const int ls = L.ls;
     if (D.n == 0) {  // empty mask: cell k itself
@@ -495,7 +498,7 @@ __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx
     const int y0 = ls * ROWS_PER_LANE;
     // One disc (the endless variant's coin re-sampling: only the collected coin is blocked): a row's blocked cells are ONE interval
     // [lo, hi] -- no masks; the lane holding the k-th free cell finds it with two comparisons.
-    const bool one = D.n == 1;
+    const bool one = ONE && D.n == 1;
     int lo[ROWS_PER_LANE], len[ROWS_PER_LANE];
     int local_free = 0;
     if (ls < 14) {
@@ -705,7 +708,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         s.num_coins = nc;
         for (int k = 0; k < nc && k < MAX_COINS; ++k) {  // deliberately not unrolled (code size)
             int cx, cy;
-            sample_cell(g, D, L, &cx, &cy);
+            sample_cell<false>(g, D, L, &cx, &cy);
             D.push(cx, cy, 21);
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
@@ -717,7 +720,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         }
         if (P.use_exit) {  // _spawn_exit (searing_spotlights.py:280-286)
             int ex, ey;
-            sample_cell(g, D, L, &ex, &ey);
+            sample_cell<false>(g, D, L, &ex, &ey);
             ex += g.integers(2, 4);
             ey += g.integers(2, 4);
             clamp_spawn(P, ex, ey);
@@ -1038,7 +1041,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
                 D.n = 0;
                 D.push(s.coin_x, s.coin_y, 28);
                 int cx, cy;
-                sample_cell(g, D, L, &cx, &cy);
+                sample_cell<true>(g, D, L, &cx, &cy);
                 cx += g.integers(2, 4);
                 cy += g.integers(2, 4);
                 clamp_spawn(P, cx, cy);
