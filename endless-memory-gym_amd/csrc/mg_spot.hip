@@ -1708,13 +1708,14 @@ class SpotFamily : public Family {
 
     void raster(void* obs, hipStream_t s) { raster_only(obs, nullptr, s); }
 
-    // Resets served inside the raster launch: on for the finite variant up to FUSE_MAX instances (16,384: 188 vs 160 M
-    // env-steps/s: more instances finish per step and their resets place up to five objects); beyond, the step kernel's reset
-    // tail is amortised and the plain raster's six workgroups per CU win (32,768: 198 vs 194 M fused, 40,960: 202 vs 203,
-    // 49,152: 205 vs 207, 131,072: 214 vs 227); off for the endless variant at every size (16,384: 195 vs 209 M, 65,536: 226 vs
-    // 236: its step kernel's tail is shorter than what the fused launch adds).  MEMGYM_SPOT_FUSE=0 / 1 forces it off / on for
-    // both.  profiles/r03_spot_store_lab.md, section 6.
-    static constexpr int FUSE_MAX = 40960;
+    // Resets served inside the raster launch: on for the finite variant up to FUSE_MAX instances (more instances finish per step
+    // than in the endless variant and their resets place up to five objects: ~15 us for the 16 lanes of an instance, the tail of
+    // the step kernel).  Round 4, with the launch's agent-scope fence gone (profiles/r04_spot_step.md, M env-steps/s fused /
+    // not): 16,384: 216 / 182, 32,768: 235 / 206, 65,536: 247 / 228, 131,072: 234 / 241 -- beyond FUSE_MAX the step kernel's reset
+    // tail is amortised over several rounds of waves and the plain raster's seven workgroups per CU win.  Off for the endless
+    // variant (16,384: 230 / 230, 65,536: 245 / 241: its step kernel's reset tail is 4 us).  MEMGYM_SPOT_FUSE=0 / 1 (lab build)
+    // forces it off / on for both.
+    static constexpr int FUSE_MAX = 65536;
     // store flavour of the fused launch: it runs five workgroups per CU (the reset code's registers), where only the
     // non-temporal stream keeps up; MEMGYM_RASTER_NT forces (tuning only)
     bool fused_nt() const {
