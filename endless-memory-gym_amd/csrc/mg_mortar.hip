@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
         R.tid = t;
         MortarComposer::compose(&d, R);
         __syncthreads();
-        store_frame<MG_OBS_U8_XYC, false>(smem, obs, env, t);
+        store_frame<MG_OBS_U8_XYC, false>(smem, obs, env, t);  // (plain stores: non-temporal ones 281 -> 226-241 M at 65,536, round 4)
         __syncthreads();
     }
 }

@@ -1620,7 +1620,7 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
         if (MysteryComposer::skip(d)) continue;
         MysteryComposer::compose(d, R);
         __syncthreads();
-        store_frame<FMT, false>(smem, obs, env, tid);
+        store_frame<FMT, false>(smem, obs, env, tid);  // (plain stores: non-temporal ones cost this launch 20 %, profiles/r04_emp.md)
         __syncthreads();
     }
 }
@@ -1723,12 +1723,23 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 // 1,024 / 1,536 service workgroups at 7 workgroups per CU (72 VGPRs, the path generator spills) 218 / 217 / 216 / 224 / 234;
 // at 5 per CU (96 VGPRs) 212 / 211 / 215 / 224 / 227; at 4 per CU 210 / 212 / 213 / 219 / 223.
 #ifndef MG_LAB_EMP_SVC  // measurement builds: -DMG_LAB_EMP_SVC=<workgroups> -DMG_LAB_EMP_LB=<workgroups per CU>
-#define MG_LAB_EMP_SVC 384  // round 3, with lazy initial segments (an entry is one path, not three): profiles/r03_emp.md
+#define MG_LAB_EMP_SVC 256  // round 4, with non-temporal frame stores (round 3: 384, with lazy initial segments: profiles/r03_emp.md)
 #endif
 #ifndef MG_LAB_EMP_LB
 #define MG_LAB_EMP_LB 5
 #endif
 constexpr int EMP_SVC_WGS = MG_LAB_EMP_SVC;
+// Frame stores of the fused launch: NON-TEMPORAL (round 4).  Alone, a plain store stream is the faster one for these frames (110 us
+// against 131 us for 32,768 of them, and every other launch of the mortar / mystery families keeps plain stores: -15 to -20 % with
+// nt); beside the path service the plain stream takes 149-152 us and the non-temporal one still 129-136 us -- it does not push the
+// service waves' working set (segment stores, queue, the generator's spills) out of the L2.  183-190 -> 203-209 M env-steps/s at
+// 32,768 instances; buffer-addressed stores, 4 / 6 workgroups per CU, 256 / 512 / 768 service workgroups: all within 2 % of it
+// (profiles/r04_emp.md).  -DMG_LAB_EMP_NT=0: plain stores (measurement builds).
+#ifdef MG_LAB_EMP_NT
+constexpr bool EMP_NT = MG_LAB_EMP_NT != 0;
+#else
+constexpr bool EMP_NT = true;
+#endif
 #ifdef MG_LAB_EMP_CLOCK  // measurement builds only: per-workgroup start / end of service / end, constant-rate clock (10 ns)
 static __device__ unsigned long long g_lab_emp_clock[3 * 16384];
 #define LAB_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_emp_clock[3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
@@ -1788,7 +1799,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
                 any = true;
                 MysteryComposer::compose(&sdesc[w], R);
                 __syncthreads();
-                store_frame<FMT, false>(smem, obs, e, tid);
+                store_frame<FMT, EMP_NT>(smem, obs, e, tid);
                 __syncthreads();
             }
             if (!any) break;
@@ -1831,7 +1842,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
         if (d->valid != 1) continue;  // masked, or drawn by the workgroup that serves its queue entry
         MysteryComposer::compose(d, R);
         __syncthreads();
-        store_frame<FMT, false>(smem, obs, env, tid);
+        store_frame<FMT, EMP_NT>(smem, obs, env, tid);
         __syncthreads();
     }
     LAB_CLOCK(2);
