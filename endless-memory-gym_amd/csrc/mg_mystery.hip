@@ -42,6 +42,7 @@ struct MysteryParams {
     int svc_prio;       // wave priority of the path-service waves inside the fused raster launches (s_setprio)
     int lazy;           // Endless: a reset generates ONE of its three initial segments, the other two are owed (see EMP_OWED)
     int path_help;      // frame workgroups help with long path queues (MEMGYM_PATH_HELP=0: the 128 dedicated workgroups alone, round 2)
+    int bg_coop;        // Endless, fused launch: owed segments as queue entries of the service waves (small launches), not one per lane of frame workgroups
     OptList cardinal;
     double r_goal, r_fall, r_progress, r_dense, r_step;
 };
@@ -1232,6 +1233,8 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, Mys
 // graph.  Entries: instance | EMP_Q_SEGMENT = "append one segment, then finish the step (which may end in a reset)";
 // plain instance = "reset".
 constexpr int EMP_Q_SEGMENT = 1 << 30;
+constexpr int EMP_Q_OWED = 1 << 29;  // "generate one of the segments this instance is owed" (a background job served like an entry: bg_coop)
+constexpr int EMP_Q_INST = EMP_Q_OWED - 1;
 
 template <bool PS>
 __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, MysteryIO io, const int32_t* actions, float* reward_out,
@@ -1279,7 +1282,7 @@ __global__ __launch_bounds__(256) void emp_enqueue_kernel(int n, MysteryIO io, c
 __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int entry, const int64_t* seeds, float* reward_out,
                                 uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc* d_out = nullptr) {
     const bool me = (threadIdx.x & 63) == 0;
-    const int i = entry & (EMP_Q_SEGMENT - 1);
+    const int i = entry & EMP_Q_INST;
     float* gti = gt ? gt + 3 * i : nullptr;
     Pcg g;
     MysteryCore s;
@@ -1293,15 +1296,27 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
         memset(&s, 0, sizeof(s));
     }
     int reset_me = 1;
-    if (entry & EMP_Q_SEGMENT) {
+    if (entry & (EMP_Q_SEGMENT | EMP_Q_OWED)) {
         // the new segment is due: whatever is still owed comes first (stream order), or -- emp_step_a's conservative test --
         // only what is owed is due and `current_segment > num_segments - 2` does not hold yet
         int want = 0;
         if (me) {
-            want = EMP_OWED(s) + ((s.cur_seg > s.num_seg + EMP_OWED(s) - 2) ? 1 : 0);
-            EMP_OWED(s) = 0;
+            if (entry & EMP_Q_OWED) {  // a background job: one owed segment, nothing else
+                want = EMP_OWED(s) > 0 ? 1 : 0;
+                EMP_OWED(s) = (uint8_t)(EMP_OWED(s) - want);
+            } else {
+                want = EMP_OWED(s) + ((s.cur_seg > s.num_seg + EMP_OWED(s) - 2) ? 1 : 0);
+                EMP_OWED(s) = 0;
+            }
         }
         serve_emp(io, W, i, want, s, g);
+        if (entry & EMP_Q_OWED) {  // only the fields a segment changes: the frame and the rest of the record are this step's already
+            if (me && want) {
+                io.core[i] = s;
+                g.store(io.rng, i);
+            }
+            return;
+        }
         if (me)
             reset_me = emp_step_b(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
                                   gti, info, autoreset, d) ? 1 : 0;
@@ -1700,7 +1715,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
     int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
     while (idx < count) {
         const int entry = all ? idx : bcast(io.queue[idx], 0);
-        emp_serve_entry(PS ? io.sets[io.set_of[entry & (EMP_Q_SEGMENT - 1)]] : P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
+        emp_serve_entry(PS ? io.sets[io.set_of[entry & EMP_Q_INST]] : P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
         if (me) {
             idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
         }
@@ -1728,7 +1743,10 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 #ifndef MG_LAB_EMP_LB
 #define MG_LAB_EMP_LB 5
 #endif
-constexpr int EMP_SVC_WGS = MG_LAB_EMP_SVC;
+#ifndef MG_LAB_EMP_SVC_SMALL
+#define MG_LAB_EMP_SVC_SMALL 768
+#endif
+constexpr int EMP_SVC_WGS = MG_LAB_EMP_SVC, EMP_SVC_WGS_SMALL = MG_LAB_EMP_SVC_SMALL;
 // Frame stores of the fused launch: NON-TEMPORAL (round 4).  Alone, a plain store stream is the faster one for these frames (110 us
 // against 131 us for 32,768 of them, and every other launch of the mortar / mystery families keeps plain stores: -15 to -20 % with
 // nt); beside the path service the plain stream takes 149-152 us and the non-temporal one still 129-136 us -- it does not push the
@@ -1778,14 +1796,18 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
         const int wv = tid >> 6;
         const bool me = (tid & 63) == 0;
         const int count = queue_count(&io.qctr[QC_COUNT], n);
+        // bg_coop (launches of up to ~20,000 instances): the owed segments are entries count .. count + bg - 1 of the same queue --
+        // with the lane-per-path generator of the frame workgroups (below) such a launch lasts as long as that generator's one
+        // path, ~105 us, whatever its frames take
+        const int bg = P.bg_coop ? queue_count(&io.qctr[QC_BG_COUNT], n) : 0;
         const int waves = svc * 4;
         int idx = bcast((int)(blockIdx.x * 4 + wv), 0);
         for (;;) {
             int inst = -1;
-            if (idx < count) {
-                const int entry = bcast(io.queue[idx], 0);
+            if (idx < count + bg) {
+                const int entry = idx < count ? bcast(io.queue[idx], 0) : (bcast(io.bgq[idx - count], 0) | EMP_Q_OWED);
                 emp_serve_entry(P, io, W, entry, nullptr, reward_out, done_out, gt, info, autoreset, &sdesc[wv]);
-                inst = entry & (EMP_Q_SEGMENT - 1);
+                if (!(entry & EMP_Q_OWED)) inst = entry & EMP_Q_INST;
                 if (me) idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
                 idx = bcast(idx, 0);
             }
@@ -1802,13 +1824,16 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
                 store_frame<FMT, EMP_NT>(smem, obs, e, tid);
                 __syncthreads();
             }
-            if (!any) break;
+            // (a round in which every wave served a background job draws nothing and goes on)
+            const bool more = __syncthreads_or(idx < count + bg);
+            if (!any && !more) break;
             __syncthreads();  // served[] / sdesc[] are rewritten by the next round: every wave has finished reading them
         }
         if (tid == 0 && atomicAdd(&io.qctr[QC_LEFT], 1) == svc - 1) {  // last service workgroup out
             io.qctr[QC_COUNT] = 0;
             io.qctr[QC_HEAD] = 0;
             io.qctr[QC_LEFT] = 0;
+            if (P.bg_coop) io.qctr[QC_BG_COUNT] = 0;
         }
         LAB_CLOCK(2);
         return;
@@ -1817,7 +1842,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
     // of them, one per lane, with the lane-per-path generator in the workgroup's frame buffer, then the workgroup starts on
     // its frames; ~105 us that run beside the other workgroups' frames, and nothing of this launch depends on them.  The
     // last participant clears the counter (participants read it before that can happen, see mystery_raster_paths_kernel).
-    if ((int)blockIdx.x - svc < EMP_BG_WGS) {
+    if ((int)blockIdx.x - svc < EMP_BG_WGS && !P.bg_coop) {
         const int bg = queue_count(&io.qctr[QC_BG_COUNT], n);
         const int busy = min(EMP_BG_WGS, (bg + 63) / 64);
         const int b = (int)blockIdx.x - svc;
@@ -1865,6 +1890,7 @@ class MysteryFamily : public Family {
         // Endless-MysteryPath: 187-189 -> 175-182 us per fused launch (profiles/r03_emp.md); no effect on MysteryPath-Grid's
         P_.svc_prio = [endless] { const char* e = lab_env("MEMGYM_SVC_PRIO"); return e ? atoi(e) : (endless ? 1 : 0); }();
         P_.path_help = [] { const char* e = lab_env("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
+        P_.bg_coop = lab_int("MEMGYM_EMP_BG_COOP", n <= 20480 ? 1 : 0);
         lazy_wanted_ = endless && [] { const char* e = lab_env("MEMGYM_EMP_LAZY"); return e ? atoi(e) != 0 : true; }();
         P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
         if (endless) {
@@ -2031,7 +2057,7 @@ class MysteryFamily : public Family {
             if (fused) {  // the queue is served inside the raster launch
                 end_logic(s);
                 prof.begin(1, s);
-                const int svc = EMP_SVC_WGS;
+                const int svc = P_.bg_coop ? EMP_SVC_WGS_SMALL : EMP_SVC_WGS;  // (small launches: the owed segments are entries too)
                 const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + svc;
                 hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
                                    P_, io(), reward, done, gt, ib, autoreset, svc);
@@ -2186,7 +2212,7 @@ class MysteryFamily : public Family {
     static void copy_geometry(MysteryParams& d, const MysteryParams& s) {
         d.endless = s.endless; d.grid = s.grid; d.n = s.n; d.depth = s.depth; d.agent_radius = s.agent_radius; d.sprite_dim = s.sprite_dim;
         d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.tile = s.tile; d.cross_dim = s.cross_dim; d.camera_offset = s.camera_offset;
-        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help;
+        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help; d.bg_coop = s.bg_coop;
     }
     bool per_set() const { return set_of_ != nullptr && !extra_.empty(); }
     // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)
