@@ -353,6 +353,25 @@ def secondary_workloads(primary, dev, settle, traffic=True):
     return out
 
 
+def other_workloads(primary, dev, settle):
+    """The three env ids that are in no BASELINE config (their launches were the ones furthest below the roofline in round 3):
+    same measurement as the secondary workloads, without the PMC child passes (profiles/ holds those); informational."""
+    out = []
+    for env_id in ("SearingSpotlights-v0", "Endless-MysteryPath-v0", "MysteryPath-Grid-v0"):
+        if env_id == primary:
+            continue
+        r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev)
+        algo = FRAME + DESC_BYTES[env_id]  # algorithmic bytes of the dominant launch per instance-step (frame + descriptor)
+        out.append({"workload": "%s, %d envs" % (env_id, r["n_local"]), "value": r["value"], "unit": "env steps/s", "ms_per_step": r["ms_per_step"],
+                    "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"], "value_windows": r["value_windows"],
+                    "obs_placement_zones": (r["obs_placement"] or {}).get("zones"),
+                    "roofline": {"bytes_per_launch_per_instance": algo, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac_dominant_kernel": algo * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if r["raster_avg_ms"] else None,
+                                 "frac_whole_step_frame_bytes_only": algo * r["n_local"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 "traffic": None, "traffic_note": "not measured in this run: profiles/r04b_*.md hold the PMC passes"}})
+    return out
+
+
 def c1_leg(episodes=200):
     """BASELINE config C1 (the reference's own loop, /root/reference/bench.py:12-30, restated in tests/c1_loop.py): one
     MortarMayhem-Grid-v0 instance, reset(seed=1), actions from Generator(PCG64(12345)), `episodes` episodes with the resets
@@ -488,6 +507,7 @@ def main():
                          "'peer' = the raster kernels store straight into rank 0's HBM (memory_gym_amd.dist.PeerObsBuffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational C3 / C4 / C5 measurements")
+    ap.add_argument("--no-other", action="store_true", help="skip the informational measurements of the env ids that are in no BASELINE config")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-instance C1 leg")
@@ -617,6 +637,11 @@ def main():
                 out["secondary_workloads"] = secondary_workloads(env_id, dev, args.settle, traffic=not args.no_traffic)
             except Exception as e:
                 out["secondary_workloads"] = "failed: %s" % e
+            if not args.no_other:
+                try:
+                    out["other_workloads"] = other_workloads(env_id, dev, args.settle)
+                except Exception as e:
+                    out["other_workloads"] = "failed: %s" % e
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -22,7 +22,7 @@ g = torch.Generator(device="cuda").manual_seed(1)
 for t in range(260):
     env.step(torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32))
 torch.cuda.synchronize()
-W = 9728 + 384 if n <= 32768 else 14336 + 384
+W = 14336 + 256
 W = min(W, 16384)
 buf = np.zeros(3 * 16384, np.uint64)
 _native.LIB.mg_lab_emp_clock.argtypes = [C.c_void_p, C.c_int]
@@ -31,7 +31,7 @@ c = buf.reshape(16384, 3).astype(np.float64)
 live = c[:, 0] > 0
 t0 = c[live, 0].min()
 us = (c - t0) / 100.0
-svc, bg = 384, 512
+svc, bg = 256, 512
 
 
 def stats(name, rows, col):
