@@ -17,7 +17,7 @@ def build_binary():
     return __graft_entry__.build_c_abi_test()
 
 
-@pytest.mark.parametrize("env_id,steps,groups", [("MortarMayhem-Grid-v0", 150, 1), ("Endless-MysteryPath-v0", 120, 1), ("SearingSpotlights-v0", 100, 1),
+@pytest.mark.parametrize("env_id,steps,groups", [("MortarMayhem-Grid-v0", 80, 1), ("Endless-MysteryPath-v0", 70, 1), ("SearingSpotlights-v0", 60, 1),
                                                  ("Endless-MortarMayhem-v0", 80, 2)])
 def test_c_host_program_matches_the_oracle(env_id, steps, groups):
     exe = build_binary()

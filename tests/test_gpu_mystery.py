@@ -88,7 +88,7 @@ EMP_OPTS = [
 
 @pytest.mark.parametrize("opt_idx", range(len(MP_OPTS)))
 def test_finite_parity(opt_idx):
-    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=560 if opt_idx != 1 else 200, policy=path_follower, n_policy=64)
+    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=540 if opt_idx != 1 else 200, policy=path_follower, n_policy=64)
     assert n_done > 0
 
 
@@ -100,7 +100,7 @@ def test_grid_parity(opt_idx):
 
 @pytest.mark.parametrize("opt_idx", range(len(EMP_OPTS)))
 def test_endless_parity(opt_idx):
-    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=400, policy=endless_follower, n_policy=64)
+    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=260, policy=endless_follower, n_policy=64)
     assert n_done > 0
 
 

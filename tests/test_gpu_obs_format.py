@@ -20,7 +20,7 @@ def test_float_formats_match_uint8(env_id, n_act):
     import memory_gym_amd
     import torch
 
-    n, steps = 96, 80
+    n, steps = 96, 50
     envs = {f: memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format=f) for f in ("u8_xyc", "f32_chw", "f16_chw", "bf16_chw")}
     assert envs["f32_chw"].obs.shape == (n, 3, 84, 84) and envs["f32_chw"].obs.dtype == torch.float32
     assert envs["f16_chw"].obs.shape == (n, 3, 84, 84) and envs["f16_chw"].obs.dtype == torch.float16

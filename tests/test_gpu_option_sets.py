@@ -64,7 +64,7 @@ def test_two_halves_two_option_sets(env_id, opt_a, opt_b):
     disc = env.action_dim == 1
     g = np.random.Generator(np.random.PCG64(5))
     sd = None
-    for t in range(160):
+    for t in range(120):
         a = (g.integers(0, 4, n) if disc else g.integers(0, 3, (n, 2))).astype(np.int32)
         obs, rew, done, _, _ = env.step(a)
         vis = obs["visual_observation"] if isinstance(obs, dict) else obs

@@ -43,13 +43,13 @@ SS_OPTS = [
 
 @pytest.mark.parametrize("opt_idx", range(len(ESS_OPTS)))
 def test_endless_parity(opt_idx):
-    n_done = run_parity("Endless-SearingSpotlights-v0", ESS_OPTS[opt_idx], n=160, steps=320, policy=coin_seeker, n_policy=64)
+    n_done = run_parity("Endless-SearingSpotlights-v0", ESS_OPTS[opt_idx], n=160, steps=240, policy=coin_seeker, n_policy=64)
     assert n_done > 0 or opt_idx == 2
 
 
 @pytest.mark.parametrize("opt_idx", range(len(SS_OPTS)))
 def test_finite_parity(opt_idx):
-    n_done = run_parity("SearingSpotlights-v0", SS_OPTS[opt_idx], n=160, steps=300, policy=coin_seeker, n_policy=64)
+    n_done = run_parity("SearingSpotlights-v0", SS_OPTS[opt_idx], n=160, steps=230, policy=coin_seeker, n_policy=64)
     assert n_done > 0
 
 
