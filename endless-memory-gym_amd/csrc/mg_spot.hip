@@ -1243,6 +1243,11 @@ struct SpotServeArgs {
     SpotParams P;
     SpotIO io;
     float* gt;
+    // Resets a serving workgroup takes per round: as few as serve every queued instance in ONE round (the launch is as long as a
+    // reset plus the frames its workgroup draws behind it: 4,096 instances 74 -> 117 M env-steps/s with one instead of eight),
+    // within [batch_min, batch_max] (host: 1 .. 8 up to 12,288 instances -- a step in which every instance is truncated at once
+    // still takes few rounds -- and 8 beyond, where eight measured 1-2 % ahead of the adaptive choice).  profiles/r04_spot_step.md section 4.
+    int batch_min, batch_max;
 };
 template <bool EN, bool BORDER, bool NT>
 __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kernel(SpotServeArgs a) {
@@ -1260,7 +1265,9 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
     const cptr<SpotDesc> cdescs = as_const(a.descs);
     const bool service = (int)blockIdx.x < SPOT_SVC_WGS;
     const int count = service ? queue_count(&a.io.qctr[SQ_COUNT], n) : 0;
-    if (service && (int)blockIdx.x * SPOT_SVC_BATCH >= count) return;
+    int batch = (count + SPOT_SVC_WGS - 1) / SPOT_SVC_WGS;
+    batch = batch < a.batch_min ? a.batch_min : (batch > a.batch_max ? a.batch_max : batch);
+    if (service && (int)blockIdx.x * batch >= count) return;
     Composer::recycle(R);
     __syncthreads();
     auto draw = [&](int env) {
@@ -1273,14 +1280,14 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
         __syncthreads();
     };
     if (service) {
-        for (int base = blockIdx.x * SPOT_SVC_BATCH; base < count; base += SPOT_SVC_WGS * SPOT_SVC_BATCH) {
+        for (int base = blockIdx.x * batch; base < count; base += SPOT_SVC_WGS * batch) {
             const SpotServeArgs MG_KERNARG_AS* ka = (const SpotServeArgs MG_KERNARG_AS*)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             const SpotParams& P = *(const SpotParams*)&ka->P;
             const SpotIO& io = *(const SpotIO*)&ka->io;
             float* const gt = ka->gt;
             const int e = base + (tid >> 4), ls = tid & 15;
-            if (tid < 16 * SPOT_SVC_BATCH && e < count) {
+            if (tid < 16 * batch && e < count) {
                 const int i = io.queue[e];
                 Pcg g;
                 g.load(io.rng, i);
@@ -1309,9 +1316,9 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             __builtin_amdgcn_s_dcache_inv();
-            for (int k = 0; k < SPOT_SVC_BATCH && base + k < count; ++k) draw(io.queue[base + k]);
+            for (int k = 0; k < batch && base + k < count; ++k) draw(io.queue[base + k]);
         }
-        const int busy = (count + SPOT_SVC_BATCH - 1) / SPOT_SVC_BATCH < SPOT_SVC_WGS ? (count + SPOT_SVC_BATCH - 1) / SPOT_SVC_BATCH : SPOT_SVC_WGS;
+        const int busy = (count + batch - 1) / batch < SPOT_SVC_WGS ? (count + batch - 1) / batch : SPOT_SVC_WGS;
         if (tid == 0 && atomicAdd(&a.io.qctr[SQ_LEFT], 1) == busy - 1) {  // last service workgroup out
             a.io.qctr[SQ_COUNT] = 0;
             a.io.qctr[SQ_LEFT] = 0;
@@ -1560,7 +1567,9 @@ class SpotFamily : public Family {
         prof.begin(1, s);
         if (defer) {
             const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + SPOT_SVC_WGS;
-            const SpotServeArgs va{desc_.p, atlas_->dev(), obs, n_, P_, io(), gt};
+            const int forced_batch = lab_int("MEMGYM_SPOT_SVC_BATCH", 0);  // (lab build: exactly this many)
+            const bool fb = forced_batch >= 1 && forced_batch <= SPOT_SVC_BATCH;
+            const SpotServeArgs va{desc_.p, atlas_->dev(), obs, n_, P_, io(), gt, fb ? forced_batch : (n_ <= 12288 ? 1 : SPOT_SVC_BATCH), fb ? forced_batch : SPOT_SVC_BATCH};
             const bool nt = fused_nt();                // non-temporal: with plain stores the fused launch loses 5-15 us at every occupancy
             const int serve_lds = RASTER_LDS_REQUEST;  // 25 KiB: six per CU
 #define SPOT_FUSED2(EN, BO, NT) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT>), dim3(grid), dim3(256), serve_lds, s, va)

@@ -184,3 +184,11 @@ def test_oversized_sprites_are_refused():
         env.reset(seed=0, options=dict(agent_scale=0.5))
     env.reset(seed=0, options=dict(agent_scale=0.28))
     env.close()
+
+
+@pytest.mark.parametrize("n", [700, 3000])
+def test_every_instance_truncated_in_the_same_step(n):
+    """The fused raster / reset launch takes as few resets per serving workgroup as serve the queue in one round (1 .. 8, chosen in
+    the kernel from the queue's length: csrc/mg_spot.hip SpotServeArgs): with max_steps = 9 every instance is truncated in steps 9,
+    18 and 27 -- n resets at once, two and eight per workgroup, several rounds for the larger batch."""
+    run_parity("SearingSpotlights-v0", dict(max_steps=9), n=n, steps=30, check_every=3)
