@@ -1721,9 +1721,10 @@ class SpotFamily : public Family {
     // than in the endless variant and their resets place up to five objects: ~15 us for the 16 lanes of an instance, the tail of
     // the step kernel).  Round 4, with the launch's agent-scope fence gone (profiles/r04_spot_step.md, M env-steps/s fused /
     // not): 16,384: 216 / 182, 32,768: 235 / 206, 65,536: 247 / 228, 131,072: 234 / 241 -- beyond FUSE_MAX the step kernel's reset
-    // tail is amortised over several rounds of waves and the plain raster's seven workgroups per CU win.  Off for the endless
-    // variant (16,384: 230 / 230, 65,536: 245 / 241: its step kernel's reset tail is 4 us).  MEMGYM_SPOT_FUSE=0 / 1 (lab build)
-    // forces it off / on for both.
+    // tail is amortised over several rounds of waves and the plain raster's seven workgroups per CU win.  The endless variant (its
+    // step kernel's reset tail is 4 us) the other way round: off up to 16,384 instances (230 / 230; the plain raster stores with
+    // the cached policy there), on beyond, where the plain raster stores non-temporally as well (32,768: 242-244 / 233-234,
+    // 65,536: 245-248 / 239-242, 131,072: 256-257 / 236-252).  MEMGYM_SPOT_FUSE=0 / 1 (lab build) forces it off / on for both.
     static constexpr int FUSE_MAX = 65536;
     // store flavour of the fused launch: it runs five workgroups per CU (the reset code's registers), where only the
     // non-temporal stream keeps up; MEMGYM_RASTER_NT forces (tuning only)
@@ -1739,7 +1740,7 @@ class SpotFamily : public Family {
             const char* e = lab_env("MEMGYM_SPOT_FUSE");
             return e ? (atoi(e) != 0 ? 1 : 0) : -1;
         }();
-        return forced >= 0 ? forced != 0 : (!P_.endless && n_ <= FUSE_MAX);
+        return forced >= 0 ? forced != 0 : (P_.endless ? n_ > RASTER_PLAIN_MAX : n_ <= FUSE_MAX);
     }
 
     std::vector<std::unique_ptr<SpotOpt>> opt_;  // [0] = the handle-wide set (P_ below is its parameter block)
