@@ -52,6 +52,8 @@ struct SpotParams {
     OptList num_coins;
     const double* cos_tab;          // [360] integer degrees, exact for multiples of 90
     const double* sin_tab;
+    const uint4* jump;              // [16][2] PCG64 jump constants {A^(k+1), S_(k+1)} (new_spots_at_reset)
+    int lab_fallback;               // lab build (MEMGYM_SPOT_RESET_FALLBACK=k): every k-th instance takes new_spots_at_reset's fall-back, as after a rejected draw (tests)
 };
 
 struct __attribute__((aligned(16))) SpotCore {
@@ -628,6 +630,79 @@ __device__ __forceinline__ void new_spot(const SpotParams& P, const SpotIO& io, 
     if (rec) *rec = n;
 }
 
+// The spotlights a reset starts with (free_mask == 0xFFFF: the q-th takes slot q, which lane q owns): 5 draws each, one after another
+// in the generator's stream -- 20 of the ~27 draws of a reset, ~3 of the ~4 us by which a resetting instance's wave outlasts the
+// others (profiles/r04_spot_step.md).  The stream's NEXT 16 outputs do not have to be produced one after another: PCG64's state
+// after k steps is A^k s + S_k inc (S_k = 1 + A + ... + A^(k-1)), so lane j of the instance's 16 computes output j + 1 directly
+// (two 128-bit multiplications with its pair of constants, P.jump) and lane q < count picks the three outputs spotlight q
+// consumes.  Which halves feed which draw depends on whether the stream arrives with a buffered half (numpy's next_uint32 hands
+// out the low half of a fresh 64-bit output and keeps the high half; Generator.uniform takes a fresh output and leaves the
+// buffer alone):   buffered:  radius <- the buffered half (spotlight 0: the stream's own; q > 0: the high half of output 3q),
+//                             speed <- output 3q+1, start <- low(3q+2), target <- high(3q+2), offset <- low(3q+3);
+//                  otherwise: radius <- low(3q+1), speed <- output 3q+2, start <- high(3q+1), target <- low(3q+3), offset <- high(3q+3).
+// Either way a spotlight consumes three outputs, the stream ends with the same "buffered" flag it came with, and the buffer word holds
+// the high half of output 3 count (numpy keeps a used half in place).  This holds as long as no bounded draw is rejected (Lemire:
+// possible only when the low word of the product is below the range, ~1e-7 per draw): a lane that sees such a low word makes the
+// whole group fall back to the one-after-another form below from the untouched stream -- that form is the definition.
+// Returns false if it did nothing (the caller then runs the loop over new_spot()).
+__device__ __forceinline__ bool new_spots_at_reset(const SpotParams& P, const SpotIO& io, int i, const LaneCtx& L, SpotCore& s, Pcg& g, int count,
+                                                   const uint4 jm, const uint4 jq) {
+    const uint32_t n_r = (uint32_t)(P.r_hi - P.r_lo);
+    if (count < 1 || count > 5 || n_r < 2u) return false;  // (16 outputs = 5 spotlights; a one-value radius range draws nothing)
+    const int ls = L.ls;
+    const u128 M = ((u128)jm.w << 96) | ((u128)jm.z << 64) | ((u128)jm.y << 32) | jm.x;
+    const u128 S = ((u128)jq.w << 96) | ((u128)jq.z << 64) | ((u128)jq.y << 32) | jq.x;
+    const u128 st = M * g.state + S * g.inc;  // the state after ls + 1 steps
+    uint32_t lo, hi;
+    {
+        const uint64_t h = (uint64_t)(st >> 64), l = (uint64_t)st, x = h ^ l;
+        const unsigned rot = (unsigned)(h >> 58);
+        const uint64_t o = (x >> rot) | (x << ((64 - rot) & 63));
+        lo = (uint32_t)o;
+        hi = (uint32_t)(o >> 32);
+    }
+    const int q = ls < count ? ls : 0;  // this lane's spotlight (lanes >= count follow spotlight 0 and store nothing)
+    const uint32_t lo1 = __shfl(lo, 3 * q, 16), hi1 = __shfl(hi, 3 * q, 16);
+    const uint32_t lo2 = __shfl(lo, 3 * q + 1, 16), hi2 = __shfl(hi, 3 * q + 1, 16);
+    const uint32_t lo3 = __shfl(lo, 3 * q + 2, 16), hi3 = __shfl(hi, 3 * q + 2, 16);
+    const uint32_t hi0 = __shfl(hi, q > 0 ? 3 * q - 1 : 0, 16);
+    const bool buffered = g.has;
+    const uint32_t x_radius = buffered ? (q > 0 ? hi0 : g.buf) : lo1;
+    const uint64_t x_speed = buffered ? (((uint64_t)hi1 << 32) | lo1) : (((uint64_t)hi2 << 32) | lo2);
+    const uint32_t x_start = buffered ? lo2 : hi1;
+    const uint32_t x_target = buffered ? hi2 : lo3;
+    const uint32_t x_offset = buffered ? lo3 : hi3;
+    const uint64_t m_radius = (uint64_t)x_radius * n_r, m_start = (uint64_t)x_start * 360u, m_target = (uint64_t)x_target * 90u,
+                   m_offset = (uint64_t)x_offset * 270u;
+    const bool maybe_rejected = (uint32_t)m_radius < n_r || (uint32_t)m_start < 360u || (uint32_t)m_target < 90u || (uint32_t)m_offset < 270u ||
+                                (P.lab_fallback > 0 && i % P.lab_fallback == 0);
+    if (((uint32_t)(__ballot(maybe_rejected) >> L.gshift) & 0xFFFFu) != 0u) return false;
+    // the stream after 3 count outputs (all 16 lanes hold the same copy)
+    {
+        const int last = 3 * count - 1;
+        const uint32_t a = __shfl((uint32_t)st, last, 16), b = __shfl((uint32_t)(st >> 32), last, 16);
+        const uint32_t c = __shfl((uint32_t)(st >> 64), last, 16), d = __shfl((uint32_t)(st >> 96), last, 16);
+        g.state = ((u128)d << 96) | ((u128)c << 64) | ((u128)b << 32) | a;
+        g.buf = __shfl(hi, last, 16);
+    }
+    s.n_spots = (uint8_t)count;
+    s.free_mask = 0xFFFFu & ~((1u << count) - 1u);
+    s.order = 0x43210ull & ((1ull << (4 * count)) - 1ull);
+    if (ls < count) {  // Spotlight.__init__ of spotlight ls, as in new_spot()
+        const int radius = P.r_lo + (int)(m_radius >> 32);
+        const double speed = P.speed_lo + (P.speed_hi - P.speed_lo) * ((double)(x_speed >> 11) * (1.0 / 9007199254740992.0));
+        const int start = (int)(m_start >> 32);
+        const int target = start + 180 + (-45 + (int)(m_target >> 32));
+        const int offset = target + (-135 + (int)(m_offset >> 32));
+        const size_t k = (size_t)i * SLOTS + ls;
+        io.sp_r[k] = (uint8_t)(radius | (P.black_background ? 0x80 : 0));
+        io.sp_t[k] = 0.0;
+        io.sp_speed[k] = speed;
+        io.sp_ang[k] = pack_angles(start, target, offset);
+    }
+    return true;
+}
+
 template <bool EN>
 __device__ __forceinline__ void fill_topbar(const SpotParams& P, const SpotCore& s, SpotDesc& d, bool reset_frame, int a0, int a1) {
     d.c_base = EN ? C_BLACK : C_GREY50;
@@ -653,6 +728,7 @@ template <bool EN>
 __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io, int i, const LaneCtx& L, SpotCore& s, Pcg& g, SpotDesc& d, float* gt,
                                            int stale_holes, int* slot) {  // slot: disc_slot() of the calling kernel's LDS array
     const int ls = L.ls;
+    const uint4 jm = P.jump[2 * ls], jq = P.jump[2 * ls + 1];  // (new_spots_at_reset: requested here, used after the first draws)
     s.t = 0;
     s.coin_t = 0;
     s.ep_sum = 0.0;
@@ -685,7 +761,8 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     s.free_mask = 0xFFFFu;
     s.spawn_timer = 0;
     s.n_intervals = (uint8_t)P.num_spawns;
-    for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g);
+    if (!new_spots_at_reset(P, io, i, L, s, g, P.initial_spawns, jm, jq))
+        for (int k = 0; k < P.initial_spawns; ++k) new_spot(P, io, i, ls, s, g);
     s.coins_collected = 0;
     s.n_coins = 0;
     s.has_coin = 0;
@@ -1399,6 +1476,18 @@ class SpotFamily : public Family {
             }
         }
         cos_.upload(ct);
+        {   // s_k = A^k s_0 + S_k inc for k = 1 .. 16 (PCG64's 128-bit LCG, multiplier as in mg_device.hpp Pcg::advance)
+            const u128 A = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
+            std::vector<uint4> jt(32);
+            u128 m = 1, q = 0;
+            for (int k = 0; k < 16; ++k) {
+                q = q * A + 1;  // S_(k+1) = S_k A + 1
+                m = m * A;      // A^(k+1)
+                jt[2 * k] = make_uint4((uint32_t)m, (uint32_t)(m >> 32), (uint32_t)(m >> 64), (uint32_t)(m >> 96));
+                jt[2 * k + 1] = make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(q >> 64), (uint32_t)(q >> 96));
+            }
+            jump_.upload(jt);
+        }
         sin_.upload(st);
         sets_dev_.alloc(MG_MAX_OPTION_SETS);
         hipLaunchKernelGGL(spot_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, core_.p);
@@ -1643,6 +1732,8 @@ class SpotFamily : public Family {
         P_.interval0 = (int)(initial_spawn_interval_ + spawn_interval_threshold_);
         P_.cos_tab = cos_.p;
         P_.sin_tab = sin_.p;
+        P_.jump = jump_.p;
+        P_.lab_fallback = lab_int("MEMGYM_SPOT_RESET_FALLBACK", 0);
 
         atlas_.reset(new Atlas());
         for (auto& sp : sprites) atlas_->add_stamp(sp, 256);  // 0..7   (SpotComposer::Pre holds StampRegs<1> per layer)
@@ -1694,7 +1785,7 @@ class SpotFamily : public Family {
         d.show_last_action = s.show_last_action; d.agent_radius = s.agent_radius; d.sprite_half = s.sprite_half;
         d.coin_radius = s.coin_radius; d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.spawn_clamp = s.spawn_clamp; d.bar_x = s.bar_x;
         d.bar_w = s.bar_w; d.quarter = s.quarter; d.bar_h = s.bar_h; d.exit_half = s.exit_half; d.half_diag = s.half_diag;
-        d.exit_radius = s.exit_radius; d.interval0 = s.interval0; d.cos_tab = s.cos_tab; d.sin_tab = s.sin_tab;
+        d.exit_radius = s.exit_radius; d.interval0 = s.interval0; d.cos_tab = s.cos_tab; d.sin_tab = s.sin_tab; d.jump = s.jump; d.lab_fallback = s.lab_fallback;
     }
     bool per_set() const { return set_of_ != nullptr && opt_.size() > 1; }
     void upload_sets(hipStream_t s) {
@@ -1769,6 +1860,7 @@ class SpotFamily : public Family {
     DevArray<SpotCore> core_;
     DevArray<double> sp_t_, sp_speed_, cos_, sin_;
     DevArray<uint32_t> sp_ang_;
+    DevArray<uint4> jump_;  // SpotParams::jump
     DevArray<uint8_t> sp_r_;
     DevArray<int> queue_;  // deferred resets: the counters + n entries
     DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)

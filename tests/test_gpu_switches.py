@@ -21,6 +21,8 @@ CASES = [
     ("MEMGYM_MYSTERY_DEFER", "0", "MysteryPath-Grid-v0", 160, 150),         # ... and not, for the grid variant
     ("MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 200),    # resets inside the raster launch
     ("MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 200),            # ... and not, for the finite variant
+    ("MEMGYM_SPOT_RESET_FALLBACK", "3", "Endless-SearingSpotlights-v0", 160, 200),  # every third instance: the reset's spotlights one after another (what a rejected draw falls back to)
+    ("MEMGYM_SPOT_RESET_FALLBACK", "2", "SearingSpotlights-v0", 160, 200),
     ("MEMGYM_MORTAR_FUSE", "0", "MortarMayhem-Grid-v0", 300, 150),          # step and raster as two launches
     ("MEMGYM_MORTAR_FUSE", "0", "Endless-MortarMayhem-v0", 300, 150),
     ("MEMGYM_LAB_NONE", "1", "MortarMayhem-Grid-v0", 300, 60),             # the lab build itself, no switch set
