@@ -920,11 +920,10 @@ struct SpotStepArgs {
     int autoreset, defer;
 };
 
-// The step of instance i as its 16 lanes execute it (lane ls owns spotlight slot ls).  Written to need few registers at once
-// (round 4: 123 -> 65-78 VGPRs; it was written for a one-launch step that measured slower and is gone, profiles/r04_spot_one_launch.md,
-// and the two-launch step kept what it gained at large launches): the RNG stream is read where the first draw happens (spawns,
-// coin re-sampling and resets are rare), the slot record after the spawn, a newborn spotlight is read back from memory, and the
-// core record lives in LDS.
+// The step of instance i as its 16 lanes execute it (lane ls owns spotlight slot ls).  The launch lasts as long as its slowest wave
+// (all waves of a 16,384-instance launch are resident at once): every load the step can need is requested up front -- core record,
+// generator stream, the lane's 17-byte slot record -- and the rare paths (spawn, coin re-sampling, reset) are kept short
+// (profiles/r04_spot_step.md: 20.5 -> 14 us).  The core record lives in LDS (round 4: 123 -> 69-88 VGPRs).
 #ifdef MG_LAB_SPOT_CLOCK  // measurement builds only (tools/spot_step_timeline.py): eight stamps + flags per wave of the step kernel
 static __device__ unsigned long long g_lab_spot_clock[10 * 65536];
 #define SPOT_CLOCK(slot) do { clk[slot] = (unsigned long long)clock64(); } while (0)
