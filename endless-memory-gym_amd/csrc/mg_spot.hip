@@ -486,9 +486,36 @@ __device__ __forceinline__ int popc128(u128m m) { return __popcll((unsigned long
 // instance re-spawned its coin).
 constexpr int ROWS_PER_LANE = 6;
 static_assert(ROWS_PER_LANE * 14 == SCREEN, "14 lanes x 6 rows cover the sampler grid");
-// ONE: with the single-disc path (the endless variant's coin re-sampling); the finite variant's reset calls it with one to ten discs
-// and has no registers to spare for a second form of the row loop (its fused raster / reset kernel spills as it is).
-template <bool ONE>
+// One row of the grid under one or two discs: the blocked cells as two sorted, disjoint intervals [a1, a1 + l1), [a2, a2 + l2)
+// (a length of 0 = none; two overlapping or touching spans are returned as one).
+__device__ __forceinline__ void row_spans(const Discs& D, int y, int& a1, int& l1, int& a2, int& l2) {
+    int lo[2] = {0, 0}, hi[2] = {-1, -1};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if (d >= D.n) continue;
+        const int dx = D.p[d], dr = D.p[2 * MAX_DISCS + d], ddy = y - D.p[MAX_DISCS + d], rem = dr * dr - ddy * ddy - 1;
+        if (rem < 0) continue;
+        const int hw = isqrt_floor(rem);
+        lo[d] = dx - hw < 0 ? 0 : dx - hw;
+        hi[d] = dx + hw > SCREEN - 1 ? SCREEN - 1 : dx + hw;
+    }
+    const bool e0 = hi[0] >= lo[0], e1 = hi[1] >= lo[1];
+    if (e0 && e1 && lo[0] <= hi[1] + 1 && lo[1] <= hi[0] + 1) {  // one span
+        a1 = lo[0] < lo[1] ? lo[0] : lo[1];
+        l1 = (hi[0] > hi[1] ? hi[0] : hi[1]) - a1 + 1;
+        a2 = SCREEN;
+        l2 = 0;
+        return;
+    }
+    const bool first0 = e0 && (!e1 || lo[0] < lo[1]);  // which span comes first (an empty one goes last)
+    const int fa = first0 ? lo[0] : lo[1], fb = first0 ? hi[0] : hi[1], sa = first0 ? lo[1] : lo[0], sb = first0 ? hi[1] : hi[0];
+    const bool fe = first0 ? e0 : e1, se = first0 ? e1 : e0;
+    a1 = fe ? fa : SCREEN;
+    l1 = fe ? fb - fa + 1 : 0;
+    a2 = se ? sa : SCREEN;
+    l2 = se ? sb - sa + 1 : 0;
+}
+
 __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx& L, int* ox, int* oy) {
     const int ls = L.ls;
     if (D.n == 0) {  // empty mask: cell k itself
@@ -498,26 +525,18 @@ __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx
         return SCREEN * SCREEN;
     }
     const int y0 = ls * ROWS_PER_LANE;
-    // One disc (the endless variant's coin re-sampling: only the collected coin is blocked): a row's blocked cells are ONE interval
-    // [lo, hi] -- no masks; the lane holding the k-th free cell finds it with two comparisons.
-    const bool one = ONE && D.n == 1;
-    int lo[ROWS_PER_LANE], len[ROWS_PER_LANE];
+    // One or two discs (the endless variant's coin re-sampling: the collected coin; the finite variant's first coin and, with one
+    // coin, its exit: agent, agent + coin): a row's blocked cells are at most two spans -- no 128-bit masks, the k-th free cell by
+    // comparisons (round 4; SearingSpotlights-v0 at 4,096 instances, where the launch is as long as one reset: 126 -> 135 M
+    // env-steps/s with the one-disc form alone).
+    const bool few = D.n <= 2;
     int local_free = 0;
     if (ls < 14) {
-        if (one) {
-            const int dx = D.p[0], dy = D.p[MAX_DISCS], dr = D.p[2 * MAX_DISCS];
-#pragma unroll
+        if (few) {
             for (int j = 0; j < ROWS_PER_LANE; ++j) {
-                const int ddy = y0 + j - dy, rem = dr * dr - ddy * ddy - 1;
-                int a = 0, b = -1;
-                if (rem >= 0) {
-                    const int hw = isqrt_floor(rem);
-                    a = dx - hw < 0 ? 0 : dx - hw;
-                    b = dx + hw > SCREEN - 1 ? SCREEN - 1 : dx + hw;
-                }
-                lo[j] = a;
-                len[j] = b >= a ? b - a + 1 : 0;
-                local_free += SCREEN - len[j];
+                int a1, l1, a2, l2;
+                row_spans(D, y0 + j, a1, l1, a2, l2);
+                local_free += SCREEN - l1 - l2;
             }
         } else {
             for (int j = 0; j < ROWS_PER_LANE; ++j) local_free += SCREEN - popc128(row_mask(D, y0 + j));
@@ -533,16 +552,21 @@ __device__ __forceinline__ int sample_cell(Pcg& g, const Discs& D, const LaneCtx
     int k = g.integers(0, free_total);  // identical in all 16 lanes
     const int excl = incl - local_free;
     int fx = -1, fy = -1;
-    if (one && k >= excl && k < incl) {
+    if (few && k >= excl && k < incl) {  // exactly one lane
         int kk = k - excl;
-#pragma unroll
         for (int j = 0; j < ROWS_PER_LANE; ++j) {
-            const int fr = SCREEN - len[j];
-            if (fy < 0 && kk < fr) {
-                fx = kk < lo[j] ? kk : kk + len[j];
+            int a1, l1, a2, l2;
+            row_spans(D, y0 + j, a1, l1, a2, l2);
+            const int fr = SCREEN - l1 - l2;
+            if (kk < fr) {
+                int x = kk;
+                if (x >= a1) x += l1;
+                if (x >= a2) x += l2;
+                fx = x;
                 fy = y0 + j;
+                break;
             }
-            if (fy < 0) kk -= fr;
+            kk -= fr;
         }
     } else if (k >= excl && k < incl) {  // exactly one lane
         int kk = k - excl;
@@ -785,7 +809,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         s.num_coins = nc;
         for (int k = 0; k < nc && k < MAX_COINS; ++k) {  // deliberately not unrolled (code size)
             int cx, cy;
-            sample_cell<false>(g, D, L, &cx, &cy);
+            sample_cell(g, D, L, &cx, &cy);
             D.push(cx, cy, 21);
             cx += g.integers(2, 4);
             cy += g.integers(2, 4);
@@ -797,7 +821,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
         }
         if (P.use_exit) {  // _spawn_exit (searing_spotlights.py:280-286)
             int ex, ey;
-            sample_cell<false>(g, D, L, &ex, &ey);
+            sample_cell(g, D, L, &ex, &ey);
             ex += g.integers(2, 4);
             ey += g.integers(2, 4);
             clamp_spawn(P, ex, ey);
@@ -1117,7 +1141,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
                 D.n = 0;
                 D.push(s.coin_x, s.coin_y, 28);
                 int cx, cy;
-                sample_cell<true>(g, D, L, &cx, &cy);
+                sample_cell(g, D, L, &cx, &cy);
                 cx += g.integers(2, 4);
                 cy += g.integers(2, 4);
                 clamp_spawn(P, cx, cy);
