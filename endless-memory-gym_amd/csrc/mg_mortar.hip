@@ -913,7 +913,8 @@ class MortarFamily : public Family {
     // (re)build geometry-dependent constants, atlases and templates
     void rebuild() {
         int radius = 0;
-        std::vector<Stamp> sprites = build_agent_sprites(agent_scale_, &radius);
+        // (the grid variants accept agent_scale and never read it: GridCharacterController(SCALE, ...), mortar_mayhem_grid.py:249)
+        std::vector<Stamp> sprites = build_agent_sprites(P_.variant == V_GRID ? 1.0 * SCALE : agent_scale_, &radius);
         std::vector<Stamp> glyphs = build_glyphs(SCALE);
         P_.tile = (int)(56 * SCALE);
         P_.arena_x0 = SCREEN / 2 - ((P_.tile * P_.N) >> 1);

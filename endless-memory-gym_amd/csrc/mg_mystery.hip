@@ -87,12 +87,17 @@ struct __attribute__((aligned(16))) MysteryDesc {
 };
 static_assert(sizeof(MysteryDesc) == 64, "MysteryDesc must be 64 bytes");
 
-struct MysteryComposer {
+// BIG = false: the agent sprite (up to 1,024 pixels: every agent_scale up to 0.28) is requested with the frame's other loads and held
+// in four registers per lane.  BIG = true (an agent_scale whose sprite is larger; chosen per handle by MysteryFamily::rebuild): the
+// sprite is blitted from the atlas by the generation-1 stamp() loop, any size; everything else is the same code.
+template <bool BIG>
+struct MysteryComposerT {
     typedef MysteryDesc Desc;
     static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->valid == 0; }
     static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
         const Desc& d = *dp;
-        StampRegs<4> sprite = stamp_fetch<4>(R, d.sprite);
+        StampRegs<4> sprite;
+        if constexpr (!BIG) sprite = stamp_fetch<4>(R, d.sprite);
         StampRegs<1> cross;
         if (d.cross_on) cross = stamp_fetch<1>(R, ST_CROSS);
         if (d.bg_on) fill_template(R, d.bg_phase);
@@ -110,7 +115,8 @@ struct MysteryComposer {
             }
         }
         __syncthreads();
-        stamp_apply<4>(R, sprite, d.sx, d.sy);
+        if constexpr (BIG) stamp(R, d.sprite, d.sx, d.sy);
+        else stamp_apply<4>(R, sprite, d.sx, d.sy);
         if (d.stamina_on) {
             __syncthreads();
             rect(R, SCREEN - STAMINA_W, 0, STAMINA_W, SCREEN, C_GREEN, false);
@@ -125,6 +131,8 @@ struct MysteryComposer {
         }
     }
 };
+typedef MysteryComposerT<false> MysteryComposer;
+typedef MysteryComposerT<true> MysteryBigComposer;
 
 // _build_debug_surface (mystery_path.py:103-117, endless_mystery_path.py:162-182).  The descriptor is a debug one
 // (mystery_debug_desc_kernel): pad8[0] = 1 finite -- tile_mask[0] = the path between its ends (white), tile_mask[1] = the walls
@@ -140,13 +148,15 @@ __device__ __forceinline__ void rect_blend_white(const RasterCtx& R, int x, int 
         }
     }
 }
-struct MysteryDebugComposer {
+template <bool BIG>
+struct MysteryDebugComposerT {
     typedef MysteryDesc Desc;
     static __device__ __forceinline__ bool skip(const Desc*) { return false; }
     static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
         const Desc& d = *dp;
         const bool endless = d.pad8[0] == 2;
-        StampRegs<4> sprite = stamp_fetch<4>(R, d.sprite);
+        StampRegs<4> sprite;
+        if constexpr (!BIG) sprite = stamp_fetch<4>(R, d.sprite);
         StampRegs<1> cross;
         if (d.cross_on) cross = stamp_fetch<1>(R, ST_CROSS);
         if (d.bg_on) fill_template(R, d.bg_phase);
@@ -167,7 +177,8 @@ struct MysteryDebugComposer {
             rect(R, d.origin_x * TILE, d.origin_y * TILE, TILE, TILE, C_BLUE, false);
         }
         __syncthreads();
-        stamp_apply<4>(R, sprite, d.sx, d.sy);
+        if constexpr (BIG) stamp(R, d.sprite, d.sx, d.sy);
+        else stamp_apply<4>(R, sprite, d.sx, d.sy);
         if (d.cross_on) {
             __syncthreads();
             stamp_apply<1>(R, cross, d.cross_x, d.cross_y);
@@ -182,6 +193,8 @@ struct MysteryDebugComposer {
         }
     }
 };
+typedef MysteryDebugComposerT<false> MysteryDebugComposer;
+typedef MysteryDebugComposerT<true> MysteryDebugBigComposer;
 
 struct MysteryIO {
     MysteryCore* core;
@@ -2046,7 +2059,7 @@ class MysteryFamily : public Family {
             // lazy initial segments need the fused launch (its frame workgroups carry the background jobs); any other path
             // first generates what earlier fused steps left owed
             // (per-instance option sets: the plain arrangement -- step kernel, queue server, raster -- whose kernels have a <PS> form)
-            const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC && !ps;
+            const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC && !ps && !big_sprites_;
             P_.lazy = (fused && lazy_wanted_) ? 1 : 0;
             if (!P_.lazy && owed_possible_) flush_owed(s);
             if (P_.lazy) owed_possible_ = true;
@@ -2077,7 +2090,7 @@ class MysteryFamily : public Family {
                                    reward, done, gt, ib, autoreset);
         } else {
             // (per-instance option sets: only this kernel has a <PS> form -- the raster launch's path service reads nothing of the options)
-            const int defer = autoreset ? defer_mode() : 0;
+            const int defer = (autoreset && !big_sprites_) ? defer_mode() : 0;
             upload_sets(s);
             if (ps)
                 hipLaunchKernelGGL(mystery_step_kernel<true>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
@@ -2230,7 +2243,8 @@ class MysteryFamily : public Family {
 
     void rebuild() {
         int radius = 0;
-        std::vector<Stamp> sprites = build_agent_sprites(agent_scale_, &radius);
+        // (MysteryPath-Grid-v0 accepts agent_scale and never reads it: GridCharacterController(SCALE, ...), mystery_path_grid.py:188)
+        std::vector<Stamp> sprites = build_agent_sprites(P_.grid ? 1.0 * SCALE : agent_scale_, &radius);
         P_.agent_radius = radius;
         P_.sprite_dim = sprites[0].w;
         double inv = 1.0 / std::sqrt(2.0);
@@ -2246,8 +2260,11 @@ class MysteryFamily : public Family {
         Stamp cross = build_cross(SCALE);
         P_.cross_dim = cross.w;
         atlas_.reset(new Atlas());
-        for (auto& sp : sprites) atlas_->add_stamp(sp, 1024);  // 0..7   (MysteryComposer: StampRegs<4>)
-        atlas_->add_stamp(cross, 256);                          // 8      (StampRegs<1>)
+        // MysteryComposer holds a sprite of up to 1,024 pixels in StampRegs<4>; a larger one (agent_scale beyond 0.28) switches the
+        // handle to MysteryBigComposer and to the plain launch arrangement (the fused launches compose with the register form)
+        big_sprites_ = sprites[0].w * sprites[0].h > 1024;
+        for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
+        atlas_->add_stamp(cross, 256);                    // 8      (StampRegs<1>; build_cross(SCALE): no option scales it)
         if (P_.endless) {
             // show_background: draw_column_tile_surface / draw_icy_surface (pygame_assets.py:780-817) blitted every `tile`
             // pixels from x = bg_scroll - tile on (endless_mystery_path.py:141-143) = one template per scroll phase
@@ -2267,14 +2284,12 @@ class MysteryFamily : public Family {
     }
 
     void raster_only(void* obs, const uint8_t* only, hipStream_t s) override {
-        launch_raster<MysteryComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
+        if (big_sprites_) launch_raster<MysteryBigComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
+        else launch_raster<MysteryComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
         MG_HIP(hipGetLastError());
     }
 
-    void raster(void* obs, hipStream_t s) {
-        launch_raster<MysteryComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s);
-        MG_HIP(hipGetLastError());
-    }
+    void raster(void* obs, hipStream_t s) { raster_only(obs, nullptr, s); }
 
     int n_;
     MysteryParams P_;       // option set 0 (the handle-wide set of mg_set_option)
@@ -2285,6 +2300,7 @@ class MysteryFamily : public Family {
     DevArray<MysteryParams> sets_dev_;
     double agent_scale_, agent_speed_, camera_offset_scale_ = 5.0;
     bool dirty_ = true, seeded_ = false;
+    bool big_sprites_ = false;  // rebuild(): the agent sprites exceed MysteryComposer's registers
 
    public:
     void on_state_loaded() override {
@@ -2329,7 +2345,8 @@ void MysteryFamily::raster_debug(void* frames, hipStream_t s) {
     upload_sets(s);
     if (per_set()) hipLaunchKernelGGL(mystery_debug_desc_kernel<true>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
     else hipLaunchKernelGGL(mystery_debug_desc_kernel<false>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), dbg.p);
-    launch_raster<MysteryDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+    if (big_sprites_) launch_raster<MysteryDebugBigComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
+    else launch_raster<MysteryDebugComposer>(dbg.p, atlas_->dev(), frames, MG_OBS_U8_XYC, n_, s);
     MG_HIP(hipGetLastError());
     MG_HIP(hipStreamSynchronize(s));  // dbg is released on return
 }

@@ -1759,11 +1759,13 @@ class SpotFamily : public Family {
         P_.lab_fallback = lab_int("MEMGYM_SPOT_RESET_FALLBACK", 0);
 
         atlas_.reset(new Atlas());
-        for (auto& sp : sprites) atlas_->add_stamp(sp, 256);  // 0..7   (SpotComposer::Pre holds StampRegs<1> per layer)
-        atlas_->add_stamp(build_coin(coin_scale_), 256);       // 8
+        // (any size: SpotComposer::Pre holds the first 256 padded pixels of a layer's stamp in registers -- every default stamp in
+        // full -- and stamp_apply_lit reads what a *_scale option adds beyond that from the atlas while it composes)
+        for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
+        atlas_->add_stamp(build_coin(coin_scale_));       // 8
         if (!P_.endless) {
-            atlas_->add_stamp(build_exit(exit_scale_, false), 256);  // 9
-            atlas_->add_stamp(build_exit(exit_scale_, true), 256);   // 10
+            atlas_->add_stamp(build_exit(exit_scale_, false));  // 9
+            atlas_->add_stamp(build_exit(exit_scale_, true));   // 10
         }
         atlas_->set_templates(build_chessboards(SCALE, SCREEN));
         atlas_->upload();

@@ -103,10 +103,25 @@ inline void ring(Stamp& s, int x0, int y0, int r, int t, uint8_t v) {
     }
 }
 
+// 1-px circle (pygame 2.4 draw.c draw_circle_bresenham_thin, what draw.circle does for width == 1: the hand outline for
+// agent_scale in [1/3, 2/3), the coin's ring for coin_scale in [0.5, 1)): the end points of the spans disc() fills.
+inline void thin_circle(Stamp& s, int x0, int y0, int r, uint8_t v) {
+    int f = 1 - r, ddx = 0, ddy = -2 * r, x = 0, y = r;
+    auto put = [&](int px, int py) { s.span(px, py, px, v); };
+    while (x < y) {
+        if (f >= 0) { --y; ddy += 2; f += ddy; }
+        ++x; ddx += 2; f += ddx + 1;
+        put(x0 + x - 1, y0 + y - 1); put(x0 - x, y0 + y - 1); put(x0 + x - 1, y0 - y); put(x0 - x, y0 - y);
+        put(x0 + y - 1, y0 + x - 1); put(x0 + y - 1, y0 - x); put(x0 - y, y0 + x - 1); put(x0 - y, y0 - x);
+    }
+}
+
+// pygame.draw.circle(surface, colour, centre, radius, width)
 inline void circle(Stamp& s, int x0, int y0, int r, int width, uint8_t v) {
     if (r < 1 || width < 0) return;
     if (width > r) width = r;
     if (width == 0 || width == r) disc(s, x0, y0, r, v);
+    else if (width == 1) thin_circle(s, x0, y0, r, v);
     else ring(s, x0, y0, r, width, v);
 }
 

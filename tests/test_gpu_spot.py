@@ -168,24 +168,6 @@ def test_scale_options(env_id, opts):
     run_parity(env_id, opts, n=48, steps=150, policy=coin_seeker, n_policy=24)
 
 
-def test_oversized_sprites_are_refused():
-    """A sprite that does not fit the raster's per-layer registers must be an error, not a truncated drawing."""
-    import memory_gym_amd
-
-    env = memory_gym_amd.make("SearingSpotlights-v0", num_envs=4, device=0)
-    with pytest.raises(NotImplementedError, match="sprite larger"):
-        env.reset(seed=0, options=dict(agent_scale=0.6))
-    with pytest.raises(NotImplementedError, match="sprite larger"):
-        env.reset(seed=0, options=dict(exit_scale=1.0))
-    env.reset(seed=0)  # the handle is still usable with supported values
-    env.close()
-    env = memory_gym_amd.make("MysteryPath-v0", num_envs=4, device=0)
-    with pytest.raises(NotImplementedError, match="sprite larger"):
-        env.reset(seed=0, options=dict(agent_scale=0.5))
-    env.reset(seed=0, options=dict(agent_scale=0.28))
-    env.close()
-
-
 @pytest.mark.parametrize("n", [700, 3000])
 def test_every_instance_truncated_in_the_same_step(n):
     """The fused raster / reset launch takes as few resets per serving workgroup as serve the queue in one round (1 .. 8, chosen in

@@ -22,6 +22,14 @@ int main(int argc, char** argv) {
         fwrite(g.px.data(), 1, g.px.size(), f);
     }
     fwrite(templ.data(), 1, templ.size(), f);
+    if (argc >= 6) {  // coin_scale exit_scale: the spotlight family's coin and exit (closed, open) stamps
+        mg::Stamp extra[3] = {mg::build_coin(atof(argv[4])), mg::build_exit(atof(argv[5]), false), mg::build_exit(atof(argv[5]), true)};
+        for (auto& g : extra) {
+            int d[2] = {g.w, g.h};
+            fwrite(d, sizeof(int), 2, f);
+            fwrite(g.px.data(), 1, g.px.size(), f);
+        }
+    }
     fclose(f);
     return 0;
 }
