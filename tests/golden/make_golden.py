@@ -524,12 +524,17 @@ def main_fuzz():
     # optional: --seed S --trials T --out DIR (a wider one-off hunt into a scratch directory; the committed fixtures use the defaults)
     arg = {sys.argv[k]: sys.argv[k + 1] for k in range(len(sys.argv) - 1) if sys.argv[k].startswith("--")}
     seed0, trials, out_dir = int(arg.get("--seed", 1000)), int(arg.get("--trials", 6)), arg.get("--out", HERE)
+    # --default-geometry: the same dictionaries without their *_scale keys -> fuzzd_<env>.npz (sessions that can share one handle:
+    # tests/test_gpu_option_sets.py replays them two per handle, and geometry is per handle)
+    default_geometry = "--default-geometry" in sys.argv
     os.makedirs(out_dir, exist_ok=True)
     for env_id, gen in CASES:
         rng = np.random.Generator(np.random.PCG64(seed0 + sum(map(ord, env_id))))
         rows_all, meta = [], []
         for trial in range(trials):
             options = gen(rng, env_id)
+            if default_geometry:
+                options = {k: v for k, v in options.items() if k not in ("agent_scale", "coin_scale", "exit_scale")}
             try:
                 rows = run_session(env_id, 100 + trial, options, 0.9, 160)
             except Exception as e:  # an option set the reference itself cannot run is not a fixture
@@ -540,7 +545,7 @@ def main_fuzz():
             meta.append(dict(seed=100 + trial, options=options, skill=0.9, n_steps=160, episodes=n_eps))
             print(env_id, "fuzz trial", trial, "rows", len(rows), "episodes", n_eps)
         out = pack(rows_all, meta)
-        fn = os.path.join(out_dir, "fuzz_" + env_id.replace("-", "_") + ".npz")
+        fn = os.path.join(out_dir, ("fuzzd_" if default_geometry else "fuzz_") + env_id.replace("-", "_") + ".npz")
         np.savez_compressed(fn, **out)
         print("  ->", fn, os.path.getsize(fn) // 1024, "KiB")
 

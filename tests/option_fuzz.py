@@ -1,11 +1,19 @@
-"""Seeded generators of reset-option dictionaries inside the ranges the HIP path and the oracle support; shared by
-tests/test_gpu_option_fuzz.py (HIP vs oracle) and tests/golden/make_golden.py (oracle vs the reference: "fuzz" sessions)."""
+"""Seeded generators of reset-option dictionaries; shared by tests/test_gpu_option_fuzz.py (HIP vs oracle) and
+tests/golden/make_golden.py (oracle vs the reference: "fuzz" sessions).  Every key of the reference's reset-options dictionaries
+is drawn, the geometry options (`agent_scale`, `coin_scale`, `exit_scale`: 0.5x .. 2x their defaults) included; what stays out
+are values the REFERENCE cannot run and the capacity limits include/memgym.h names (16 live spotlights per instance)."""
 import numpy as np  # noqa: F401
 
 
 def _lst(rng, lo, hi, kmax=3):
     k = int(rng.integers(1, kmax + 1))
     return sorted({int(v) for v in rng.integers(lo, hi + 1, k)})
+
+
+def _scale(rng, default):
+    """0.5x .. 2x the default of a *_scale option; crosses the sprite sizes the composers keep in registers (csrc/mg_raster.hpp
+    StampRegs) and the width regimes of pygame.draw.circle (filled / 1 px / thick ring)"""
+    return float(default * rng.choice([0.5, 0.7, 0.8, 1.0, 1.0, 1.2, 1.36, 1.6, 1.8, 2.0]))
 
 
 def _rew(rng):
@@ -26,6 +34,8 @@ def mortar_opts(rng, env_id):
         o.update(arena_size=int(rng.integers(2, 7)), command_count=_lst(rng, 1, 12), reward_episode_success=_rew(rng))
     if not grid:
         o.update(agent_speed=float(rng.choice([2.0, 3.0, 4.0])))
+    # drawn last, so that the other values of a trial are the ones earlier fixtures had (the grid ids accept the key and ignore it)
+    o.update(agent_scale=_scale(rng, 0.25))
     return o
 
 
@@ -35,10 +45,11 @@ def mystery_opts(rng, env_id):
                     show_past_path=bool(rng.integers(0, 2)), visual_feedback=bool(rng.integers(0, 2)), reward_fall_off=_rew(rng),
                     reward_path_progress=_rew(rng), reward_path_progress_dense=_rew(rng), reward_step=_rew(rng),
                     camera_offset_scale=float(rng.choice([3.0, 5.0, 7.0])), show_background=bool(rng.integers(0, 2)),
-                    agent_speed=float(rng.choice([2.0, 3.0, 4.0])))
+                    agent_speed=float(rng.choice([2.0, 3.0, 4.0])), agent_scale=_scale(rng, 0.25))
     o = dict(max_steps=int(rng.integers(20, 200)), cardinal_origin_choice=_lst(rng, 0, 3, 4), show_origin=bool(rng.integers(0, 2)),
              show_goal=bool(rng.integers(0, 2)), visual_feedback=bool(rng.integers(0, 2)), reward_goal=_rew(rng), reward_fall_off=_rew(rng),
              reward_path_progress=_rew(rng), reward_step=_rew(rng))
+    o.update(agent_scale=_scale(rng, 0.25))
     return o
 
 
@@ -63,6 +74,9 @@ def spot_opts(rng, env_id):
                  show_last_action=bool(rng.integers(0, 2)), exit_visible=bool(rng.integers(0, 2)))
     # drawn last, so that the other values of a trial are the ones earlier fixtures had
     o.update(black_background=bool(rng.integers(0, 4) == 0), hide_chessboard=bool(rng.integers(0, 4) == 0))
+    o.update(agent_scale=_scale(rng, 0.25), coin_scale=_scale(rng, 0.375))
+    if not env_id.startswith("Endless"):
+        o.update(exit_scale=_scale(rng, 0.5))
     return o
 
 

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): replay the REFERENCE's recorded sessions (tests/golden/{logic,fuzz,long}_*.npz: captured from the unmodified
+"""GPU (-m gpu): replay the REFERENCE's recorded sessions (tests/golden/{logic,fuzz,fuzzd,long}_*.npz: captured from the unmodified
 reference by tests/golden/make_golden.py) straight through the HIP path -- the public single-instance API over the C ABI --
 without the oracle in between: reward (the reference's Python float, bit for bit), done, the numpy PCG64 words after every
 call, info["ground_truth"] and the terminal info dict must equal what the reference produced."""
@@ -22,7 +22,7 @@ def load(env_id, kind):
 
 # "long": option lists of 9..41 entries (tests/golden/make_golden.py --long), incl. lists beyond the 32 entries the kernels
 # keep in their arguments
-CASES = [(e, k) for e in ENV_IDS for k in ("logic", "fuzz")] + [
+CASES = [(e, k) for e in ENV_IDS for k in ("logic", "fuzz", "fuzzd")] + [
     (e, "long") for e in ENV_IDS if os.path.exists(os.path.join(GOLDEN, "long_" + e.replace("-", "_") + ".npz"))]
 
 

@@ -1,6 +1,7 @@
 """GPU (-m gpu): randomised sweep over the reset-options space.  For every env id a seeded generator draws option
-dictionaries inside the ranges both the HIP path and the oracle support (lists for the "sample one per episode" keys,
-rewards, durations, sizes, speeds), and the HIP path must stay bit-exact with the oracle under random actions."""
+dictionaries over every key of the reference's reset-options dictionaries (tests/option_fuzz.py: lists for the "sample one
+per episode" keys, rewards, durations, sizes, speeds and the *_scale geometry options), and the HIP path must stay bit-exact
+with the oracle under random actions.  The same generators produce the reference-recorded tests/golden/fuzz_*.npz."""
 import os
 
 import numpy as np

@@ -5,7 +5,7 @@ runs different curricula side by side.  reset(options=..., mask=...) of the Pyth
 the instances that are being reset.  Checked: one handle whose halves (and, later, a third group) run under different
 `command_count` / reward / `max_steps` / display options, each group bit-exact against its OWN oracle batch -- frames,
 rewards, dones, RNG streams, through same-step auto-resets and a checkpoint; and reference sessions recorded under different
-option dictionaries (tests/golden/fuzz_*.npz) replayed two per handle."""
+option dictionaries (tests/golden/fuzzd_*.npz) replayed two per handle."""
 import glob
 import json
 import os
@@ -109,13 +109,14 @@ def test_geometry_options_are_refused_for_a_subset_instead_of_reparametrising_ev
                                     "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-v0", "MysteryPath-Grid-v0",
                                     "Endless-MysteryPath-v0"])
 def test_reference_sessions_two_per_handle(env_id):
-    """Recorded sessions of the UNMODIFIED reference under different random option dictionaries (tests/golden/fuzz_*.npz),
+    """Recorded sessions of the UNMODIFIED reference under different random option dictionaries (tests/golden/fuzzd_*.npz),
     two at a time through ONE handle: instance 0 replays one session, instance 1 the next -- each reset is a masked reset with
     that session's options.  Rewards as the reference's Python floats, dones and the numpy PCG64 words after every call."""
     import memory_gym_amd
     import torch
 
-    z = np.load(os.path.join(HERE, "golden", "fuzz_" + env_id.replace("-", "_") + ".npz"))
+    # (fuzzd: the fuzz generators without their *_scale keys -- geometry belongs to the handle, so two sessions can share one)
+    z = np.load(os.path.join(HERE, "golden", "fuzzd_" + env_id.replace("-", "_") + ".npz"))
     metas = json.loads(str(z["meta"]))
     disc = None
     pairs = checked = refused = 0

@@ -28,10 +28,13 @@ def sessions(env_id, kind="logic"):
 # "logic": hand-picked sessions; "fuzz": seeded random option dictionaries (tests/option_fuzz.py, make_golden.py --fuzz);
 # "long": "sample one per episode" option lists of 9..41 entries (make_golden.py --long)
 LONG_IDS = [e for e in ENV_IDS if os.path.exists(os.path.join(GOLDEN, "long_" + e.replace("-", "_") + ".npz"))]
-ALL = [s for e in ENV_IDS for s in sessions(e)] + [s for e in ENV_IDS for s in sessions(e, "fuzz")] + [s for e in LONG_IDS for s in sessions(e, "long")]
+# "fuzzd": the fuzz generators without their *_scale keys (make_golden.py --fuzz --default-geometry)
+FUZZD_IDS = [e for e in ENV_IDS if os.path.exists(os.path.join(GOLDEN, "fuzzd_" + e.replace("-", "_") + ".npz"))]
+ALL = ([s for e in ENV_IDS for s in sessions(e)] + [s for e in ENV_IDS for s in sessions(e, "fuzz")] + [s for e in LONG_IDS for s in sessions(e, "long")]
+       + [s for e in FUZZD_IDS for s in sessions(e, "fuzzd")])
 
 
-@pytest.mark.parametrize("env_id,si,kind", ALL, ids=["%s-%s%d" % (a[0], a[2][:2] if a[2] == "long" else a[2][0], a[1]) for a in ALL])
+@pytest.mark.parametrize("env_id,si,kind", ALL, ids=["%s-%s%d" % (a[0], {"logic": "l", "fuzz": "f", "long": "lo", "fuzzd": "fd"}[a[2]], a[1]) for a in ALL])
 def test_replay_matches_reference(env_id, si, kind):
     z = load(env_id, kind)
     meta = json.loads(str(z["meta"]))[si]
