@@ -169,6 +169,11 @@ __device__ __forceinline__ void free_move(int a0, int a1, int v_axis, int v_diag
 // select chain over eight uniform (scalar) operands and the byte with a shift -- indexing the list with a lane's draw
 // would be a load from the kernel-argument segment, one more dependent memory round trip in the reset's serial code.
 // Longer lists (any length) live in a device array owned by the family (OptListStore, mg_family.hpp) and cost that load.
+// Index of the option set an instance runs under (include/memgym.h: mg_bind_option_sets), from the caller's int32 array: masked
+// to the MG_MAX_OPTION_SETS = 8 parameter blocks every handle uploads, so that a stray entry reads SOME block of the handle
+// (never-written sets hold the reference's defaults) instead of memory beyond them.
+__device__ __forceinline__ int set_index(const int32_t* set_of, int i) { return set_of[i] & 7; }
+
 constexpr int OPT_INLINE = 32;
 struct OptList {
     int n;

@@ -16,6 +16,7 @@
 namespace mg {
 
 void set_error(const std::string& msg);
+static_assert(MG_MAX_OPTION_SETS == 8, "set_index() (mg_device.hpp) masks an instance's set index with 7");
 
 #define MG_HIP(expr)                                                                                 \
     do {                                                                                             \

@@ -238,13 +238,13 @@ struct MortarIO {
 };
 constexpr int ERR_CMD_OVERFLOW = 32;  // include/memgym.h: Endless Mortar Mayhem command list longer than its capacity
 
-// PS: per-instance option sets -- the parameters come from memory, io.sets[io.set_of[i]], instead of from the kernel arguments
+// PS: per-instance option sets -- the parameters come from memory, io.sets[set_index(io.set_of, i)], instead of from the kernel arguments
 template <bool PS>
 __global__ __launch_bounds__(256) void mortar_reset_kernel(MortarParams P0, int n, MortarIO io, const int64_t* seeds,
                                                            const uint8_t* mask, float* gt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const MortarParams& P = PS ? io.sets[io.set_of[i]] : P0;
+    const MortarParams& P = PS ? io.sets[set_index(io.set_of, i)] : P0;
     MortarDesc d;
     memset(&d, 0, sizeof(d));
     d.glyph_x0 = (int16_t)P.glyph_x0;
@@ -303,7 +303,7 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
         // (the caller has dropped lanes with i >= n: the wave's first lane has its smallest i, so it is active whenever any lane is)
     }
     const MortarIO& io = a.io;
-    const MortarParams& P = PS ? io.sets[io.set_of[i]] : a.P;  // (PS: per-instance option sets)
+    const MortarParams& P = PS ? io.sets[set_index(io.set_of, i)] : a.P;  // (PS: per-instance option sets)
     const int32_t* const actions = a.actions;
     float* const reward_out = a.reward_out;
     uint8_t* const done_out = a.done_out;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
 __global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P0, int n, MortarIO io, MortarDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const MortarParams& P = io.set_of ? io.sets[io.set_of[i]] : P0;
+    const MortarParams& P = io.set_of ? io.sets[set_index(io.set_of, i)] : P0;
     const MortarState s = io.state[i];
     const uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     MortarDesc d = io.desc[i];
@@ -966,7 +966,9 @@ class MortarFamily : public Family {
     // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)
     void upload_sets(hipStream_t s) {
         if (!per_set() || !sets_dirty_) return;
-        std::vector<MortarParams> host(MG_MAX_OPTION_SETS, P_);
+        MortarParams fresh = defaults_;  // a set that was never written: the reference's defaults under the handle's geometry (include/memgym.h)
+        copy_geometry(fresh, P_);
+        std::vector<MortarParams> host(MG_MAX_OPTION_SETS, fresh);
         for (size_t k = 0; k < opt_.size(); ++k) host[k] = opt_[k]->P;
         MG_HIP(hipMemcpyAsync(sets_dev_.p, host.data(), sizeof(MortarParams) * host.size(), hipMemcpyHostToDevice, s));
         MG_HIP(hipStreamSynchronize(s));  // (rare: only after an option of some set changed)

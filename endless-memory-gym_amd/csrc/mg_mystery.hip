@@ -1080,7 +1080,7 @@ template <bool PS>
 __global__ __launch_bounds__(256) void mystery_debug_desc_kernel(MysteryParams P0, MysteryIO io, MysteryDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P0.n) return;
-    const MysteryParams& P = PS ? io.sets[io.set_of[i]] : P0;
+    const MysteryParams& P = PS ? io.sets[set_index(io.set_of, i)] : P0;
     const MysteryCore s = io.core[i];
     MysteryDesc d = io.desc[i];
     d.valid = 1;
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P0, My
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool in_range = worker && i < P0.n;
-    const MysteryParams& P = (PS && in_range) ? io.sets[io.set_of[i]] : P0;  // (PS: per-instance option sets)
+    const MysteryParams& P = (PS && in_range) ? io.sets[set_index(io.set_of, i)] : P0;  // (PS: per-instance option sets)
     const bool active = in_range && !(mask && !mask[i]);
     if (in_range && !active) io.desc[i].valid = 0;
     Pcg g;
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, Mys
     bool worker;
     const int i = instance_of_lane(lpw, worker);
     const bool active = worker && i < P0.n;
-    const MysteryParams& P = (PS && active) ? io.sets[io.set_of[i]] : P0;  // (PS: per-instance option sets)
+    const MysteryParams& P = (PS && active) ? io.sets[set_index(io.set_of, i)] : P0;  // (PS: per-instance option sets)
     MysteryCore s;
     Pcg g;
     MysteryDesc d;
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P0.n) return;
-    const MysteryParams& P = PS ? io.sets[io.set_of[i]] : P0;  // (PS: per-instance option sets)
+    const MysteryParams& P = PS ? io.sets[set_index(io.set_of, i)] : P0;  // (PS: per-instance option sets)
     LAB_STEP_CLOCK(0);
     int act = actions[i];  // requested together with the state record ...
     MysteryCore s = load_core(&io.core[i]);
@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
     int idx = bcast((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), 0);
     while (idx < count) {
         const int entry = all ? idx : bcast(io.queue[idx], 0);
-        emp_serve_entry(PS ? io.sets[io.set_of[entry & EMP_Q_INST]] : P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
+        emp_serve_entry(PS ? io.sets[set_index(io.set_of, entry & EMP_Q_INST)] : P, io, W, entry, seeds, reward_out, done_out, gt, info, autoreset);
         if (me) {
             idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
         }
@@ -2231,7 +2231,10 @@ class MysteryFamily : public Family {
     // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)
     void upload_sets(hipStream_t s) {
         if (!per_set() || !sets_dirty_) return;
-        std::vector<MysteryParams> host(MG_MAX_OPTION_SETS, P_);
+        MysteryParams fresh = defaults_;  // a set that was never written: the reference's defaults under the handle's geometry (include/memgym.h)
+        copy_geometry(fresh, P_);
+        std::vector<MysteryParams> host(MG_MAX_OPTION_SETS, fresh);
+        host[0] = P_;
         for (size_t k = 0; k < extra_.size(); ++k) {
             host[k + 1] = extra_[k]->P;
             copy_geometry(host[k + 1], P_);  // (incl. lazy = 0: the plain arrangement generates every segment when it is due)

@@ -904,7 +904,7 @@ __device__ __forceinline__ void store_desc_head(SpotDesc* dst, const SpotDesc& d
 }
 static_assert(MAX_COINS == 8, "store_desc_head packs eight coin words");
 
-// PS: per-instance option sets -- the parameters come from memory, io.sets[io.set_of[i]], instead of from the kernel arguments
+// PS: per-instance option sets -- the parameters come from memory, io.sets[set_index(io.set_of, i)], instead of from the kernel arguments
 template <bool EN, bool PS>
 __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P0, SpotIO io, const int64_t* seeds, const uint8_t* mask,
                                                          float* gt) {
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void spot_reset_kernel(SpotParams P0, SpotIO i
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int i = gid >> 4, ls = gid & 15;
     if (i >= P0.n) return;
-    const SpotParams& P = PS ? io.sets[io.set_of[i]] : P0;
+    const SpotParams& P = PS ? io.sets[set_index(io.set_of, i)] : P0;
     if (mask && !mask[i]) {
         if (ls == 0) io.desc[i].valid = 0;
         return;
@@ -964,7 +964,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
 #endif
     SPOT_CLOCK(0);
     const SpotIO& io = a.io;
-    const SpotParams& P = PS ? io.sets[io.set_of[i]] : a.P;  // (PS: per-instance option sets)
+    const SpotParams& P = PS ? io.sets[set_index(io.set_of, i)] : a.P;  // (PS: per-instance option sets)
     const int32_t* const actions = a.actions;
     float* const reward_out = a.reward_out;
     uint8_t* const done_out = a.done_out;
@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
 __global__ __launch_bounds__(256) void spot_debug_desc_kernel(SpotParams P0, SpotIO io, SpotDesc* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P0.n) return;
-    const SpotParams& P = io.set_of ? io.sets[io.set_of[i]] : P0;
+    const SpotParams& P = io.set_of ? io.sets[set_index(io.set_of, i)] : P0;
     SpotDesc d = io.desc[i];
     const SpotCore s = io.core[i];
     d.valid = 1;
@@ -1815,7 +1815,9 @@ class SpotFamily : public Family {
     bool per_set() const { return set_of_ != nullptr && opt_.size() > 1; }
     void upload_sets(hipStream_t s) {
         if (!per_set() || !sets_dirty_) return;
-        std::vector<SpotParams> host(MG_MAX_OPTION_SETS, P_);
+        SpotParams fresh = defaults_;  // a set that was never written: the reference's defaults under the handle's geometry (include/memgym.h)
+        copy_geometry(fresh, P_);
+        std::vector<SpotParams> host(MG_MAX_OPTION_SETS, fresh);
         for (size_t k = 0; k < opt_.size(); ++k) {
             copy_geometry(opt_[k]->P, P_);  // (ordered_holes may have been switched on since the last rebuild)
             host[k] = opt_[k]->P;

@@ -256,8 +256,17 @@ class VecMemoryGym:
                 raise NotImplementedError("more than %d different option sets alive in one handle" % _native.MG_MAX_OPTION_SETS)
             k = free[0]
             while len(self._set_params) <= k:
-                self._set_params.append(dict(DEFAULTS[self.env_id]))
-            self._write_set(k, params)
+                self._set_params.append({})
+            # EVERY key is sent (an empty `have`): the library then checks each geometry key against the handle's geometry and
+            # refuses a set whose agent_scale / arena_size / ... differs from it -- also when the value asked for is the
+            # reference's default and the handle's is not (diffing against the defaults sent nothing in that case and
+            # the instances silently ran under the handle's geometry)
+            self._set_params[k] = {}
+            try:
+                self._write_set(k, params)
+            except Exception:
+                self._set_params[k] = {}  # half-written: never matched by a later reset, rewritten in full when it is reused
+                raise
         if self._set_of is None:
             self._set_of = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
             _native.check(_native.LIB.mg_bind_option_sets(self._h, self._set_of.data_ptr()), "mg_bind_option_sets")
@@ -267,7 +276,12 @@ class VecMemoryGym:
         params = process_reset_params(self.env_id, options)
         self._write_set(0, params)
         if self._set_of is not None:
-            self._set_of.zero_()  # a reset of every instance: all of them run under these options
+            # a reset of every instance: all of them run under these options.  The per-instance index is unbound again, so the
+            # handle is back in its one-set launch arrangement (one-launch mortar step, fused resets, lazy segments), and the other
+            # sets are forgotten: their geometry entries may be stale now, a later masked reset writes the set it needs in full.
+            _native.check(_native.LIB.mg_bind_option_sets(self._h, None), "mg_bind_option_sets")
+            self._set_of = None
+        del self._set_params[1:]
         self.reset_params = params
         if self.env_id in ("MortarMayhemB-Grid-v0", "MortarMayhemB-v0"):  # mortar_mayhem_b_grid.py:149-153
             self.max_episode_steps = calc_max_episode_steps(
@@ -300,14 +314,15 @@ class VecMemoryGym:
     def reset(self, seed=None, return_info=True, options=None, mask=None):
         """Env.reset(seed, options) for all instances, or for those selected by the bool/uint8 tensor `mask`: the options then belong
         to those instances only (per-instance option sets, include/memgym.h: mg_set_option_set); mask with options=None re-starts
-        them under the options each of them has."""
+        them under the options each of them has.  `reset_params` and `max_episode_steps` describe the options of the latest FULL
+        reset (option set 0); a masked reset with options does not change them."""
         with torch.cuda.device(self.device):
+            if mask is not None and seed is None and not self._seeded:  # (checked before any option state changes)
+                raise RuntimeError("a masked reset(seed=None) needs an earlier full reset: the other instances have no RNG stream yet")
             if mask is None:
                 self._apply_options(options)
             else:
                 self._apply_options_masked(options, mask)
-            if mask is not None and seed is None and not self._seeded:
-                raise RuntimeError("a masked reset(seed=None) needs an earlier full reset: the other instances have no RNG stream yet")
             s = self._seed_tensor(seed)
             m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
             if m is not None and self._swapped:
@@ -412,15 +427,18 @@ class VecMemoryGym:
             if sd.get("option_sets") is not None:
                 for k, p in enumerate(sd["option_sets"]):
                     while len(self._set_params) <= k:
-                        self._set_params.append(dict(DEFAULTS[self.env_id]))
-                    if k > 0:
-                        self._write_set(k, {kk: vv for kk, vv in p.items() if kk in DEFAULTS[self.env_id]})
+                        self._set_params.append({})
+                    if k > 0 and p:  # (an empty entry: a slot that was never filled or half-written when the checkpoint was taken)
+                        self._set_params[k] = {}
+                        self._write_set(k, process_reset_params(self.env_id, {kk: vv for kk, vv in p.items() if kk in DEFAULTS[self.env_id]}))
                 if self._set_of is None:
                     self._set_of = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
                     _native.check(_native.LIB.mg_bind_option_sets(self._h, self._set_of.data_ptr()), "mg_bind_option_sets")
                 self._set_of.copy_(torch.as_tensor(np.asarray(sd["set_of"], dtype=np.int32), device=self.device))
-            elif self._set_of is not None:
-                self._set_of.zero_()
+            elif self._set_of is not None:  # the checkpoint was taken with one option set: back to that arrangement
+                _native.check(_native.LIB.mg_bind_option_sets(self._h, None), "mg_bind_option_sets")
+                self._set_of = None
+                del self._set_params[1:]
             buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
             _native.check(_native.LIB.mg_set_state(self._h, buf.ctypes.data, buf.size), "mg_set_state")
             self._seeded = bool(sd.get("seeded", True))  # (env.obs shows the restored episodes from the next step on)

@@ -105,6 +105,64 @@ def test_geometry_options_are_refused_for_a_subset_instead_of_reparametrising_ev
     env.close()
 
 
+@pytest.mark.parametrize("env_id,geo,other", [("SearingSpotlights-v0", dict(agent_scale=0.5), dict(num_coins=[2])),
+                                              ("MortarMayhem-v0", dict(agent_scale=0.4), dict(command_count=[5])),
+                                              ("MysteryPath-v0", dict(agent_scale=0.5), dict(max_steps=40)),
+                                              ("Endless-MysteryPath-v0", dict(camera_offset_scale=3.0), dict(stamina_level=9))])
+def test_a_subset_cannot_silently_run_under_the_handles_non_default_geometry(env_id, geo, other):
+    """the handle's geometry is NOT the reference's default; a masked reset whose options hold the default geometry
+    value (by not naming the key) asks for a geometry the handle does not have -- that must be refused, not run under the
+    handle's.  With the handle's geometry named, the subset gets its set; a later FULL reset that changes the geometry forgets
+    the sets (their geometry entries would be stale) and unbinds the per-instance index."""
+    import memory_gym_amd
+    import oracle_lib
+    import torch
+
+    n = 32
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    seeds = np.arange(n, dtype=np.int64) + 5
+    env.reset(seed=seeds, options=geo)
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+    mask[: n // 2] = True
+    with pytest.raises(NotImplementedError):
+        env.reset(seed=seeds, options=other, mask=mask)  # (other) + default geometry != the handle's geometry
+    both = dict(geo, **other)
+    obs, _ = env.reset(seed=seeds, options=both, mask=mask)
+    ref = oracle_lib.OracleBatch(env_id, n // 2, options=_full(env_id, both))
+    vis = obs["visual_observation"] if isinstance(obs, dict) else obs
+    assert np.array_equal(vis[: n // 2].cpu().numpy(), ref.reset(seeds[: n // 2]))
+    ref.close()
+    assert env._set_of is not None
+    # a full reset back to the reference's defaults: one set again, nothing bound
+    obs, _ = env.reset(seed=seeds)
+    assert env._set_of is None and len(env._set_params) == 1
+    ref = oracle_lib.OracleBatch(env_id, n)
+    vis = obs["visual_observation"] if isinstance(obs, dict) else obs
+    assert np.array_equal(vis.cpu().numpy(), ref.reset(seeds))
+    ref.close()
+    # the set written above named the OLD geometry: asking for it again is a geometry mismatch now, not a match with a stale set
+    with pytest.raises(NotImplementedError):
+        env.reset(seed=seeds, options=both, mask=mask)
+    obs, _ = env.reset(seed=seeds, options=other, mask=mask)  # (other) + default geometry == the handle's geometry now
+    ref = oracle_lib.OracleBatch(env_id, n // 2, options=_full(env_id, other))
+    vis = obs["visual_observation"] if isinstance(obs, dict) else obs
+    assert np.array_equal(vis[: n // 2].cpu().numpy(), ref.reset(seeds[: n // 2]))
+    ref.close()
+    env.close()
+
+
+def test_masked_reset_validates_before_it_touches_option_state():
+    import memory_gym_amd
+    import torch
+
+    env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=8, device=0)
+    mask = torch.ones(8, dtype=torch.bool, device="cuda")
+    with pytest.raises(RuntimeError, match="earlier full reset"):
+        env.reset(options=dict(command_count=[3]), mask=mask)
+    assert env._set_of is None and len(env._set_params) == 1
+    env.close()
+
+
 @pytest.mark.parametrize("env_id", ["MortarMayhem-Grid-v0", "MortarMayhem-v0", "Endless-MortarMayhem-v0", "MortarMayhemB-Grid-v0", "MortarMayhemB-v0",
                                     "SearingSpotlights-v0", "Endless-SearingSpotlights-v0", "MysteryPath-v0", "MysteryPath-Grid-v0",
                                     "Endless-MysteryPath-v0"])
