@@ -162,27 +162,27 @@ __device__ __forceinline__ void free_move(int a0, int a1, int v_axis, int v_diag
     }
 }
 
-// "sample one per episode" option list (np_random.choice(list) == list[integers(0, len)], e.g.
-// mortar_mayhem_grid.py:181,253-254,268-269; mystery_path.py:154; searing_spotlights.py:408).  The reference accepts lists
-// of any length.  Entries are bytes (every list option of the reference is a small count or duration; hosts refuse values
-// outside 0..255).  Up to OPT_INLINE entries travel in the kernel arguments, four per dword: the word is picked with a
-// select chain over eight uniform (scalar) operands and the byte with a shift -- indexing the list with a lane's draw
-// would be a load from the kernel-argument segment, one more dependent memory round trip in the reset's serial code.
-// Longer lists (any length) live in a device array owned by the family (OptListStore, mg_family.hpp) and cost that load.
 // Index of the option set an instance runs under (include/memgym.h: mg_bind_option_sets), from the caller's int32 array: masked
 // to the MG_MAX_OPTION_SETS = 8 parameter blocks every handle uploads, so that a stray entry reads SOME block of the handle
 // (never-written sets hold the reference's defaults) instead of memory beyond them.
 __device__ __forceinline__ int set_index(const int32_t* set_of, int i) { return set_of[i] & 7; }
 
+// "sample one per episode" option list (np_random.choice(list) == list[integers(0, len)], e.g.
+// mortar_mayhem_grid.py:181,253-254,268-269; mystery_path.py:154; searing_spotlights.py:408).  The reference accepts lists
+// of any length with any ints.  A list of up to OPT_INLINE entries that all fit a byte (every default, every list a curriculum
+// plausibly uses) travels in the kernel arguments, four entries per dword: the word is picked with a select chain over eight
+// uniform (scalar) operands and the byte with a shift -- indexing the list with a lane's draw would be a load from the
+// kernel-argument segment, one more dependent memory round trip in the reset's serial code.  Longer lists and lists with
+// larger entries (round 5: 32-bit) live in a device array owned by the family (OptListStore, mg_family.hpp) and cost that load.
 constexpr int OPT_INLINE = 32;
 struct OptList {
     int n;
     uint32_t w[OPT_INLINE / 4];
-    const uint8_t* ext;  // n > OPT_INLINE: all n entries, device memory
+    const int32_t* ext;  // non-NULL: all n entries, device memory (n > OPT_INLINE or an entry beyond 255)
 };
 __device__ __forceinline__ int choice(Pcg& g, const OptList& l) {
     const int k = g.integers(0, l.n);
-    if (__builtin_expect(l.n > OPT_INLINE, 0)) return (int)l.ext[k];  // uniform branch
+    if (__builtin_expect(l.ext != nullptr, 0)) return l.ext[k];  // uniform branch
     const int wi = k >> 2;
     uint32_t w = l.w[0];
 #pragma unroll

@@ -112,17 +112,21 @@ struct RngStore {
     }
 };
 
-// Host side of an OptList (mg_device.hpp): packs the entries, owns the device copy of lists longer than OPT_INLINE.
+// Host side of an OptList (mg_device.hpp): packs the entries, owns the device copy of lists that do not fit the inline form.
 struct OptListStore {
-    DevArray<uint8_t> ext;
-    // values must already be validated to lie in 0..255
+    DevArray<int32_t> ext;
+    std::vector<int> host;  // the entries as set (capacity checks at reset time)
+    int max() const { int m = 0; for (int x : host) m = x > m ? x : m; return m; }
     void set(OptList& l, const std::vector<int>& v) {
+        host = v;
         l.n = (int)v.size();
         for (int j = 0; j < OPT_INLINE / 4; ++j) l.w[j] = 0u;
         l.ext = nullptr;
-        for (int k = 0; k < l.n && k < OPT_INLINE; ++k) l.w[k >> 2] |= (uint32_t)(v[k] & 0xFF) << (8 * (k & 3));
-        if (l.n > OPT_INLINE) {
-            std::vector<uint8_t> b(v.begin(), v.end());
+        bool bytes = true;
+        for (int x : v) bytes = bytes && x >= 0 && x <= 255;
+        for (int k = 0; bytes && k < l.n && k < OPT_INLINE; ++k) l.w[k >> 2] |= (uint32_t)(v[k] & 0xFF) << (8 * (k & 3));
+        if (l.n > OPT_INLINE || !bytes) {
+            std::vector<int32_t> b(v.begin(), v.end());
             // the previous array may still be read by kernels in flight on some stream: synchronise before it goes
             MG_HIP(hipDeviceSynchronize());
             ext.upload(b);

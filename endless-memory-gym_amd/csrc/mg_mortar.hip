@@ -46,16 +46,18 @@ struct MortarParams {
 struct __attribute__((aligned(16))) MortarState {
     int16_t ax, ay;          // agent rect centre
     int16_t disp_x, disp_y;  // centre of the rect the frame shows (differs from ax/ay only through the Endless stale-sprite quirk)
-    uint8_t rot8;            // agent.rotation / 45
+    uint8_t rot8 : 3;        // agent.rotation / 45
+    uint8_t disp_is_agent : 1;  // rotated_agent_rect is the live agent's rect
+    uint8_t tiles_on : 1;
     uint8_t disp_sprite;     // sprite index the frame shows, 0xFF = none yet
-    uint8_t disp_is_agent;   // rotated_agent_rect is the live agent's rect
-    uint8_t tiles_on;
     int8_t tx, ty;           // target tile
     int8_t nx, ny;           // normalized agent position
     uint16_t num_cmds, cur_cmd;
     uint16_t vis_pos, vis_len, vis_base;  // display schedule: next entry, length, first command it covers
     uint16_t cmd_steps, verify_step;
-    uint8_t show_dur, show_delay, expl_dur, expl_delay;
+    // this episode's draws from the "sample one per episode" lists: 16 bits each (round 5; bytes before -- the reference takes
+    // any int, mortar_mayhem_grid.py:253-254,268-269); the host refuses only what overflows the 16-bit display schedule
+    uint16_t show_dur, show_delay, expl_dur, expl_delay;
     uint8_t gx, gy;          // grid controller position
     int32_t ep_len, t, total_completed;
     uint32_t dbg_pops;       // debug view only: entries popped from the reference's CLONE of the display schedule (one per debug
@@ -181,8 +183,8 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
     if (P.taskb) {  // mortar_mayhem_b_grid.py:172 `_command_visualization = None`: nothing is drawn (no draws either)
         s.show_dur = s.show_delay = 0;
     } else {
-        s.show_dur = (uint8_t)choice(g, P.show_dur);
-        s.show_delay = (uint8_t)choice(g, P.show_delay);
+        s.show_dur = (uint16_t)choice(g, P.show_dur);
+        s.show_delay = (uint16_t)choice(g, P.show_delay);
     }
     s.vis_len = (uint16_t)(n * (s.show_dur + s.show_delay));
     s.vis_base = 0;
@@ -205,8 +207,8 @@ __device__ void mortar_reset(const MortarParams& P, MortarState& s, Pcg& g, uint
     s.t = 0;
     s.ep_len = 0;
     s.ep_sum = 0.0;
-    s.expl_dur = (uint8_t)choice(g, P.expl_dur);
-    s.expl_delay = (uint8_t)choice(g, P.expl_delay);
+    s.expl_dur = (uint16_t)choice(g, P.expl_dur);
+    s.expl_delay = (uint16_t)choice(g, P.expl_delay);
 
     // reset frame: blue arena, sprite 0 at the NEW agent position, first glyph
     d.tmpl = 0;
@@ -788,10 +790,12 @@ class MortarFamily : public Family {
             if (a < 4 || a > 9) throw OptionError{-4, "assert 4 <= allowed_commands <= 9"};
             P.allowed = a;
         }
-        else if (!P_.taskb && key == "command_show_duration") list(P.show_dur, O.st_show_dur, 1, 100);
-        else if (!P_.taskb && key == "command_show_delay") list(P.show_delay, O.st_show_delay, 0, 100);
-        else if (key == "explosion_duration") list(P.expl_dur, O.st_expl_dur, 1, 200);
-        else if (key == "explosion_delay") list(P.expl_delay, O.st_expl_delay, 1, 200);
+        // (entries are 16 bits in MortarState; an explosion entry of 0 is the reference's ZeroDivisionError in `% explosion_delay` (:304,343),
+        // a show duration of 0 with a delay of 0 its IndexError at the reset's pop(0) (:257))
+        else if (!P_.taskb && key == "command_show_duration") list(P.show_dur, O.st_show_dur, 1, 65535);
+        else if (!P_.taskb && key == "command_show_delay") list(P.show_delay, O.st_show_delay, 0, 65535);
+        else if (key == "explosion_duration") list(P.expl_dur, O.st_expl_dur, 1, 65535);
+        else if (key == "explosion_delay") list(P.expl_delay, O.st_expl_delay, 1, 65535);
         else if (key == "visual_feedback") P.visual_feedback = v[0] != 0.0;
         else if (key == "reward_command_failure") P.r_fail = v[0];
         else if (key == "reward_command_success") P.r_succ = v[0];
@@ -823,6 +827,11 @@ class MortarFamily : public Family {
     void reset(const int64_t* seeds, const uint8_t* mask, void* obs, float* gt, hipStream_t s) override {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
+        for (auto& O : opt_) {  // the display schedule (commands x (duration + delay) entries) is indexed with 16 bits
+            const long long n_max = P_.variant == V_ENDLESS ? O->P.initial_count : O->st_command_count.max();
+            if (!P_.taskb && n_max * ((long long)O->st_show_dur.max() + O->st_show_delay.max()) > 65535)
+                throw OptionError{-3, "command_count x (command_show_duration + command_show_delay) exceeds the 65,535 entries of this build's display schedule"};
+        }
         if (seeds) seeded_ = true;  // with a mask the caller is responsible for having seeded the other instances
         upload_sets(s);
         if (per_set())

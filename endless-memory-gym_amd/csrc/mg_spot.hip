@@ -46,7 +46,12 @@ struct SpotParams {
     int agent_radius, sprite_half, coin_radius;
     int v_axis_i, v_diag_i;
     int spawn_clamp;                // _process_spawn_pos offset
-    int bar_x, bar_w, quarter, bar_h, exit_half;
+    int bar_x, bar_w, quarter, bar_h;
+    // finite variant: the Exit stamps the handle holds, one pair (closed, open) per GENERATION = distinct exit_scale still on
+    // some instance's screen (a stale exit keeps the size it was made with: exit_gen_of); exit_gen = the one new exits get,
+    // exit_halves = (int(20 * exit_scale) >> 1) of each generation, a byte each
+    int exit_gen;
+    uint64_t exit_halves;
     double speed_lo, speed_hi, damage, agent_health, exit_radius, half_diag;
     double r_inside, r_outside, r_death, r_coin, r_exit;
     OptList num_coins;
@@ -127,13 +132,18 @@ struct SpotView {
 typedef SpotView<DescWordsMem> SpotViewMem;
 __device__ __forceinline__ SpotViewMem view_of(cptr<SpotDesc> dp) { return SpotViewMem{DescWordsMem{(cptr<uint32_t>)dp}}; }
 
-constexpr int ST_COIN = 8, ST_EXIT_CLOSED = 9, ST_EXIT_OPEN = 10;
+constexpr int ST_COIN = 8, ST_EXIT0 = 9;  // exit of generation g: closed ST_EXIT0 + 2 g, open ST_EXIT0 + 2 g + 1
+constexpr int EXIT_GENS = 8;
 // hide_chessboard / black_background paint over the two background surfaces an environment object keeps for its lifetime
 // (searing_spotlights.py:349-351, 234-235, 420-421; endless :313-315, 223-224, 376-377): per instance, sticky across
 // episodes and option changes.  Templates: 0 blue board, 1 red board, 2 white, 3 black.
 constexpr uint32_t BG_CHESS = 0, BG_WHITE = 1, BG_BLACK = 2, BG_MODE_SHIFT = 20, BG_MODE_MASK = 0xFu << BG_MODE_SHIFT;
 // SpotCore::pad bit 24: the instance has had an exit (searing_spotlights.py: self.exit exists); sticky like the board modes
-constexpr uint32_t PAD_HAS_EXIT = 1u << 24, PAD_STICKY = BG_MODE_MASK | PAD_HAS_EXIT;
+// bits 27..25: the generation of that exit (SpotParams::exit_gen when it was spawned) -- self.exit is an object of its own in the
+// reference: with use_exit = False it stays on screen as it was made, also once exit_scale has changed (searing_spotlights.py:431-435)
+constexpr uint32_t PAD_HAS_EXIT = 1u << 24, PAD_EXIT_GEN_SHIFT = 25, PAD_EXIT_GEN_MASK = (uint32_t)(EXIT_GENS - 1) << PAD_EXIT_GEN_SHIFT;
+constexpr uint32_t PAD_STICKY = BG_MODE_MASK | PAD_HAS_EXIT | PAD_EXIT_GEN_MASK;
+__device__ __forceinline__ int exit_gen_of(uint32_t pad) { return (int)((pad & PAD_EXIT_GEN_MASK) >> PAD_EXIT_GEN_SHIFT); }
 constexpr int ERR_NO_EXIT = 256;  // include/memgym.h: use_exit = False for an instance that never had an exit
 __device__ __forceinline__ uint32_t bg_mode(uint32_t pad, int red) { return (pad >> (BG_MODE_SHIFT + 2 * red)) & 3u; }
 __device__ __forceinline__ uint32_t bg_set(uint32_t pad, int red, uint32_t m) {
@@ -828,7 +838,7 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
             s.exit_x = (int16_t)ex;
             s.exit_y = (int16_t)ey;
             s.exit_open = 0;
-            s.pad |= PAD_HAS_EXIT;
+            s.pad = (s.pad & ~PAD_EXIT_GEN_MASK) | ((uint32_t)P.exit_gen << PAD_EXIT_GEN_SHIFT) | PAD_HAS_EXIT;
         } else if (!(s.pad & PAD_HAS_EXIT)) {
             // use_exit == False: nothing is spawned, sampled or drawn (:413-416) and the frame keeps blitting self.exit -- the Exit
             // of an earlier episode, where it was and as it was last drawn (open / closed).  Without one the reference raises
@@ -866,9 +876,12 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
                 d.coins[k] = (uint32_t)(cx - P.coin_radius + 128) | ((uint32_t)(cy - P.coin_radius + 128) << 16);
             }
         }
-        d.exit_stamp = (s.pad & PAD_HAS_EXIT) ? (s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED) : 0xFF;
-        d.exit_x = (int16_t)(s.exit_x - P.exit_half);
-        d.exit_y = (int16_t)(s.exit_y - P.exit_half);
+        {
+            const int eg = exit_gen_of(s.pad), half = (int)((P.exit_halves >> (8 * eg)) & 0xFFu);
+            d.exit_stamp = (s.pad & PAD_HAS_EXIT) ? (uint8_t)(ST_EXIT0 + 2 * eg + (s.exit_open ? 1 : 0)) : 0xFF;
+            d.exit_x = (int16_t)(s.exit_x - half);
+            d.exit_y = (int16_t)(s.exit_y - half);
+        }
     }
     fill_topbar<EN>(P, s, d, true, 0, 0);
     if (gt) {
@@ -1264,9 +1277,10 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
                 reinterpret_cast<uint4*>(coins)[0] = make_uint4(coin_pos[0], coin_pos[1], coin_pos[2], coin_pos[3]);
                 reinterpret_cast<uint4*>(coins)[1] = make_uint4(coin_pos[4], coin_pos[5], coin_pos[6], coin_pos[7]);
             }
-            d.exit_stamp = (s.pad & PAD_HAS_EXIT) ? (s.exit_open ? ST_EXIT_OPEN : ST_EXIT_CLOSED) : 0xFF;
-            d.exit_x = (int16_t)(s.exit_x - P.exit_half);
-            d.exit_y = (int16_t)(s.exit_y - P.exit_half);
+            const int eg = exit_gen_of(s.pad), half = (int)((P.exit_halves >> (8 * eg)) & 0xFFu);
+            d.exit_stamp = (s.pad & PAD_HAS_EXIT) ? (uint8_t)(ST_EXIT0 + 2 * eg + (s.exit_open ? 1 : 0)) : 0xFF;
+            d.exit_x = (int16_t)(s.exit_x - half);
+            d.exit_y = (int16_t)(s.exit_y - half);
         }
         if (reset_me) d.valid = DESC_QUEUED;
         SpotCore tb = s;
@@ -1480,6 +1494,7 @@ class SpotFamily : public Family {
         sp_ang_.alloc((size_t)SLOTS * n);
         sp_r_.alloc((size_t)SLOTS * n);
         flags_.alloc(4);
+        exit_hist_.alloc(1 + EXIT_GENS);
         queue_.alloc((size_t)n + SQ_WORDS);
 
         coins_.alloc((size_t)MAX_COINS * n);
@@ -1702,6 +1717,7 @@ class SpotFamily : public Family {
                                                   {sp_ang_.p, sp_ang_.bytes()}};
         for (auto* a : {&sp_t_, &sp_speed_}) v.push_back({a->p, a->bytes()});
         v.push_back({flags_.p, flags_.bytes()});
+        v.push_back({exit_hist_.p, exit_hist_.bytes()});
         rng_.blobs(v);
         return v;
     }
@@ -1747,7 +1763,6 @@ class SpotFamily : public Family {
         P_.spawn_clamp = (int)(30 * SCALE);
         P_.quarter = (int)(SCREEN / 4);
         P_.bar_h = (int)(16 * SCALE);
-        P_.exit_half = (int)(20 * exit_scale_) >> 1;
         if (P_.show_last_action) { P_.bar_x = (int)(P_.quarter * 2.75); P_.bar_w = (int)(P_.quarter * 0.5); }
         else { P_.bar_x = P_.quarter * 2; P_.bar_w = P_.quarter * 2; }
         P_.half_diag = std::sqrt(std::pow((double)SCREEN, 2) + std::pow((double)SCREEN, 2)) / 2;
@@ -1763,9 +1778,25 @@ class SpotFamily : public Family {
         // full -- and stamp_apply_lit reads what a *_scale option adds beyond that from the atlas while it composes)
         for (auto& sp : sprites) atlas_->add_stamp(sp);  // 0..7
         atlas_->add_stamp(build_coin(coin_scale_));       // 8
-        if (!P_.endless) {
-            atlas_->add_stamp(build_exit(exit_scale_, false));  // 9
-            atlas_->add_stamp(build_exit(exit_scale_, true));   // 10
+        if (!P_.endless) {  // 9 + 2 g, 10 + 2 g: the exits of generation g (free generations: an empty stamp)
+            pick_exit_generation();
+            P_.exit_halves = 0;
+            for (int g = 0; g < EXIT_GENS; ++g) {
+                if (exit_gen_used_[g]) {
+                    const int half = (int)(20 * exit_gen_scale_[g]) >> 1;
+                    if (half > 255) throw OptionError{-3, "exit_scale beyond 25: the exit would be six screens wide"};
+                    P_.exit_halves |= (uint64_t)half << (8 * g);
+                    atlas_->add_stamp(build_exit(exit_gen_scale_[g], false));
+                    atlas_->add_stamp(build_exit(exit_gen_scale_[g], true));
+                } else {
+                    atlas_->add_stamp(Stamp(1, 1));
+                    atlas_->add_stamp(Stamp(1, 1));
+                }
+            }
+            std::vector<double> hist(1 + EXIT_GENS, 0.0);
+            for (int g = 0; g < EXIT_GENS; ++g) hist[1 + g] = exit_gen_used_[g] ? exit_gen_scale_[g] : 0.0;
+            hist[0] = (double)P_.exit_gen;
+            MG_HIP(hipMemcpy(exit_hist_.p, hist.data(), sizeof(double) * hist.size(), hipMemcpyHostToDevice));
         }
         atlas_->set_templates(build_chessboards(SCALE, SCREEN));
         atlas_->upload();
@@ -1779,6 +1810,35 @@ class SpotFamily : public Family {
             defaults_ = D.P;
         }
         sets_dirty_ = true;
+    }
+
+    // The generation new exits belong to = the slot that holds exit_scale_; a new scale takes a free slot.  Slots are only ever
+    // freed here, when all eight are taken: the instances' pads are read back and the generations no exit refers to any more
+    // are released (rare: eight different exit sizes in the life of one handle).
+    void pick_exit_generation() {
+        for (int g = 0; g < EXIT_GENS; ++g)
+            if (exit_gen_used_[g] && exit_gen_scale_[g] == exit_scale_) { P_.exit_gen = g; return; }
+        auto take_free = [&]() {
+            for (int g = 0; g < EXIT_GENS; ++g)
+                if (!exit_gen_used_[g]) {
+                    exit_gen_used_[g] = true;
+                    exit_gen_scale_[g] = exit_scale_;
+                    P_.exit_gen = g;
+                    return true;
+                }
+            return false;
+        };
+        if (take_free()) return;
+        MG_HIP(hipDeviceSynchronize());
+        std::vector<uint32_t> pads(n_);
+        MG_HIP(hipMemcpy2D(pads.data(), sizeof(uint32_t), reinterpret_cast<const char*>(core_.p) + offsetof(SpotCore, pad), sizeof(SpotCore),
+                           sizeof(uint32_t), n_, hipMemcpyDeviceToHost));
+        bool alive[EXIT_GENS] = {false, false, false, false, false, false, false, false};
+        for (uint32_t pad : pads)
+            if (pad & PAD_HAS_EXIT) alive[(pad & PAD_EXIT_GEN_MASK) >> PAD_EXIT_GEN_SHIFT] = true;
+        for (int g = 0; g < EXIT_GENS; ++g) exit_gen_used_[g] = alive[g];
+        if (!take_free())
+            throw OptionError{-3, "exits of eight different exit_scale values are still on screen (use_exit = False keeps them); a ninth size needs a reset with use_exit = True first"};
     }
 
     // per-instance option sets
@@ -1809,7 +1869,7 @@ class SpotFamily : public Family {
         d.endless = s.endless; d.n = s.n; d.ordered_holes = s.ordered_holes;
         d.show_last_action = s.show_last_action; d.agent_radius = s.agent_radius; d.sprite_half = s.sprite_half;
         d.coin_radius = s.coin_radius; d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.spawn_clamp = s.spawn_clamp; d.bar_x = s.bar_x;
-        d.bar_w = s.bar_w; d.quarter = s.quarter; d.bar_h = s.bar_h; d.exit_half = s.exit_half; d.half_diag = s.half_diag;
+        d.bar_w = s.bar_w; d.quarter = s.quarter; d.bar_h = s.bar_h; d.exit_gen = s.exit_gen; d.exit_halves = s.exit_halves; d.half_diag = s.half_diag;
         d.exit_radius = s.exit_radius; d.interval0 = s.interval0; d.cos_tab = s.cos_tab; d.sin_tab = s.sin_tab; d.jump = s.jump; d.lab_fallback = s.lab_fallback;
     }
     bool per_set() const { return set_of_ != nullptr && opt_.size() > 1; }
@@ -1878,6 +1938,15 @@ class SpotFamily : public Family {
         int f = 0;
         MG_HIP(hipMemcpy(&f, flags_.p, sizeof(int), hipMemcpyDeviceToHost));
         if (f) P_.ordered_holes = 1;
+        if (!P_.endless) {  // the exit generations the restored instances refer to; the atlas follows
+            std::vector<double> hist(1 + EXIT_GENS, 0.0);
+            MG_HIP(hipMemcpy(hist.data(), exit_hist_.p, sizeof(double) * hist.size(), hipMemcpyDeviceToHost));
+            for (int g = 0; g < EXIT_GENS; ++g) {
+                exit_gen_used_[g] = hist[1 + g] != 0.0;
+                exit_gen_scale_[g] = hist[1 + g];
+            }
+            rebuild();
+        }
         sets_dirty_ = true;
     }
     void raster_debug(void* frames, hipStream_t s) override;
@@ -1891,6 +1960,11 @@ class SpotFamily : public Family {
     DevArray<uint8_t> sp_r_;
     DevArray<int> queue_;  // deferred resets: the counters + n entries
     DevArray<int> flags_;  // [0] = SpotParams::ordered_holes: travels with the state (spotlights with a border may be alive in it)
+    // finite variant: [0] = SpotParams::exit_gen, [1 + g] = exit_scale of generation g (0 = free); travels with the state (the
+    // instances' exits name their generation, SpotCore::pad)
+    DevArray<double> exit_hist_;
+    double exit_gen_scale_[EXIT_GENS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool exit_gen_used_[EXIT_GENS] = {false, false, false, false, false, false, false, false};
     DevArray<uint32_t> coins_;
     DevArray<SpotDesc> desc_;
     ErrorWord err_;

@@ -424,6 +424,9 @@ class VecMemoryGym:
             if opts is not None and any(self._applied.get(k) != v for k, v in opts.items()):
                 # options only take effect at a reset: do one (its frames and RNG consumption are overwritten right below)
                 self.reset(seed=0, options={k: v for k, v in opts.items() if k in DEFAULTS[self.env_id]})
+                # whatever that throw-away reset flagged (e.g. use_exit=False on instances that have no exit YET: the restored
+                # ones bring theirs) says nothing about the restored episodes
+                _native.LIB.mg_poll_errors(self._h, C.byref(C.c_int()))
             if sd.get("option_sets") is not None:
                 for k, p in enumerate(sd["option_sets"]):
                     while len(self._set_params) <= k:

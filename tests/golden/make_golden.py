@@ -401,6 +401,9 @@ LONG_SESSIONS = {
                   explosion_duration=_D40, explosion_delay=_L40), 0.9, 900),
         (12, dict(arena_size=6, allowed_commands=9, command_count=list(range(1, 33)), explosion_duration=[2] * 33 + [3],
                   explosion_delay=[4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]), 0.8, 900),
+        # entries beyond a byte (the reference takes any int; the HIP path kept these draws in bytes until round 5)
+        (13, dict(command_count=[1, 2], command_show_duration=[300, 2], command_show_delay=[260, 0], explosion_duration=[270, 2],
+                  explosion_delay=[400, 3]), 0.95, 3000),
     ],
     "MortarMayhem-v0": [
         (11, dict(command_count=_CC16, command_show_duration=[1, 2, 3, 4, 1, 2, 3, 4, 1, 2, 3], explosion_duration=[d + 2 for d in _D40],
@@ -409,12 +412,15 @@ LONG_SESSIONS = {
     "Endless-MortarMayhem-v0": [
         (11, dict(command_show_duration=[1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 1], command_show_delay=[0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 2, 2],
                   explosion_duration=[d + 2 for d in _D40], explosion_delay=[d + 8 for d in _L40]), 0.6, 1500),
+        (13, dict(initial_command_count=1, command_show_duration=[1, 280], explosion_duration=[2, 260], explosion_delay=[300, 4],
+                  max_steps=900), 0.97, 3000),
     ],
     "MortarMayhemB-Grid-v0": [
         (11, dict(command_count=_CC16 + [20, 18], explosion_duration=_D40, explosion_delay=_L40), 0.9, 900),
     ],
     "MortarMayhemB-v0": [
         (11, dict(command_count=_CC16 + [20, 18], explosion_duration=[d + 2 for d in _D40], explosion_delay=[d + 8 for d in _L40]), 0.95, 1200),
+        (13, dict(command_count=[2, 3], explosion_duration=[3, 300], explosion_delay=[320, 8]), 0.97, 2500),
     ],
     "MysteryPath-v0": [
         (11, dict(max_steps=24, cardinal_origin_choice=[0, 1, 2, 3, 3, 2, 1, 0, 2, 2, 1, 3]), 0.9, 700),

@@ -198,3 +198,25 @@ def test_checkpoint_roundtrip():
     for (o1, r1, d1), (o2, r2, d2) in zip(out1, out2):
         assert (o1 == o2).all() and (r1 == r2).all() and (d1 == d2).all()
     env.close()
+
+
+@pytest.mark.parametrize("env_id,opts,steps", [
+    ("MortarMayhem-Grid-v0", dict(command_count=[1, 2], command_show_duration=[300, 2], command_show_delay=[260, 1], explosion_duration=[270, 2], explosion_delay=[400, 3]), 1300),
+    ("Endless-MortarMayhem-v0", dict(initial_command_count=1, command_show_duration=[1, 280], explosion_duration=[2, 260], explosion_delay=[300, 4], max_steps=700), 900),
+    ("MortarMayhemB-v0", dict(command_count=[2, 3], explosion_duration=[3, 300], explosion_delay=[320, 8]), 900)])
+def test_list_entries_beyond_a_byte(env_id, opts, steps):
+    """"sample one per episode" lists take any int in the reference (mortar_mayhem_grid.py:253-254,268-269); the per-episode draws
+    are 16 bits wide in MortarState (bytes until round 5).  tests/golden/long_*.npz holds reference sessions of the same kind."""
+    from gpu_parity import run_parity as run_parity_any  # (handles MortarMayhemB's Dict observation)
+
+    run_parity_any(env_id, opts, n=48, steps=steps, check_every=7)
+
+
+def test_a_display_schedule_beyond_16_bits_is_refused():
+    import memory_gym_amd
+
+    env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=4, device=0)
+    with pytest.raises(NotImplementedError, match="display schedule"):
+        env.reset(seed=0, options=dict(command_count=[32], command_show_duration=[2000], command_show_delay=[100]))
+    env.reset(seed=0, options=dict(command_count=[1], command_show_duration=[60000], command_show_delay=[5000]))
+    env.close()

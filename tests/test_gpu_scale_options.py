@@ -96,3 +96,39 @@ def test_debug_view_with_large_sprites(env_id, opts):
         ref.step(a, autoreset=True, want_obs=False)
     env.close()
     ref.close()
+
+
+def test_stale_exits_keep_the_size_they_were_made_with():
+    """use_exit = False keeps the instance's EARLIER exit on screen (searing_spotlights.py:431-435) -- an object of its own in the
+    reference, so it keeps its size when exit_scale changes meanwhile.  The handle holds one pair of exit stamps per size still on
+    some screen (csrc/mg_spot.hip: exit generations); a checkpoint carries them."""
+    import memory_gym_amd
+    import oracle_lib
+    from memory_gym_amd.reset_params import process_reset_params
+
+    env_id, n = "SearingSpotlights-v0", 24
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    ref = oracle_lib.OracleBatch(env_id, n)
+    prng = np.random.Generator(np.random.PCG64(17))
+    seeds = np.arange(n, dtype=np.int64) + 40
+    phases = [dict(exit_scale=0.5, max_steps=30, agent_health=100), dict(use_exit=False, exit_scale=1.0, max_steps=25, agent_health=100),
+              dict(use_exit=False, exit_scale=0.3, max_steps=25, agent_health=100, exit_visible=True),
+              dict(exit_scale=0.8, max_steps=30, agent_health=100), dict(use_exit=False, exit_scale=0.25, max_steps=20, agent_health=100)]
+    for k, opts in enumerate(phases):
+        ref.set_options(process_reset_params(env_id, opts))
+        obs, _ = env.reset(seed=seeds if k == 0 else None, options=opts)
+        assert np.array_equal(obs.cpu().numpy(), ref.reset(seeds if k == 0 else None)), "reset frames of phase %d" % k
+        for t in range(45):
+            a = np.stack([coin_seeker(ref.envs[i], prng) for i in range(n)]).astype(np.int32)
+            obs, rew, done, _, _ = env.step(a)
+            o2, r2, d2 = ref.step(a, autoreset=True)
+            assert np.array_equal(done.cpu().numpy(), d2.astype(bool)), "phase %d step %d: done" % (k, t)
+            assert np.array_equal(obs.cpu().numpy(), o2), "phase %d step %d: frames" % (k, t)
+            if k == 2 and t == 20:  # a restore into a fresh handle brings the stamps of the stale exits along
+                sd = env.state_dict()
+                env.close()
+                env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+                env.load_state_dict(sd)
+    env.check_errors()
+    env.close()
+    ref.close()
