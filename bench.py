@@ -27,8 +27,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 the library on the launch stream: every 8th step of the timed region when K >= 64; for shorter runs the timed region stays
 undisturbed and the 32 steps after it are all bracketed) and `cpu_baseline` (the CPU oracle = a port of the reference's
 algorithm, bounded sample, OpenMP over instances, timed in a subprocess; rank 0, N = 1 only).  N = 1 also carries
-`c1` (BASELINE config C1, the reference's own bench.py loop: one instance, reset(seed=1), actions from PCG64(12345), 200
-episodes -- the HIP single-instance adapter and the oracle on one thread), the C3 entry's `reset_share` (time of the
+`c1` (BASELINE config C1, the reference's own bench.py loop: one instance, reset(seed=1), actions from PCG64(12345), 1,000
+episodes -- BASELINE's 1,000 since round 5 -- the HIP single-instance adapter and the oracle on one thread), the C3 entry's `reset_share` (time of the
 path-generating resets over the step time) and, when rocprofv3 is on PATH, `roofline.traffic` MEASURED by two child passes
 of this very command (--pmc WRITE_SIZE, --pmc FETCH_SIZE; /opt/skills/guides/MI355X_MICROARCH.md, HBM section).
 """
@@ -208,6 +208,26 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
 
     for k in range(settle):  # setup: de-synchronise the episodes
         one_step(k)
+    # ... and keep stepping until the rate is flat (C4's first timed window was 5 % below the other five -- 200 steps
+    # do not settle every workload): windows of 50 steps until two in a row are within 1 % of their predecessor, at most 20
+    settle_windows = []
+    if not (gather and dist_on):
+        sa, sb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        flat = 0
+        for w in range(20):
+            sa.record()
+            for k in range(50):
+                one_step(settle + 50 * w + k)
+            sb.record()
+            torch.cuda.synchronize()
+            settle_windows.append(sa.elapsed_time(sb))
+            if w and abs(settle_windows[-1] - settle_windows[-2]) <= 0.01 * settle_windows[-2]:
+                flat += 1
+                if flat >= 2:
+                    break
+            else:
+                flat = 0
+        settle += 50 * len(settle_windows)
     for k in range(W):
         one_step(settle + k)
     in_region = events and K >= 64
@@ -256,6 +276,25 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
         raster_ms, raster_n = env.get_profile(1)
         logic_ms, logic_n = env.get_profile(0)
         env.set_profiling(False)
+    # per-box control: pure store streams over the SAME observation buffer at the SAME launch size, right beside
+    # the timed region -- a linear 16-byte fill (the memory system's store ceiling here) and the raster's store shape without
+    # any compose work (include/memgym.h: mg_store_probe).  Best and median of 9 launches each after 3 warm-ups.
+    box = None
+    if obs_format == "u8_xyc" and peer is None and hasattr(memory_gym_amd._native.LIB, "mg_store_probe"):
+        import ctypes as C
+        box = {}
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for pattern, name in ((0, "linear_fill"), (1, "frame_shaped")):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
+            for q in range(12):
+                evs[q].record()
+                memory_gym_amd._native.check(memory_gym_amd._native.LIB.mg_store_probe(C.c_void_p(env.obs.data_ptr()), n_local, pattern, stream), "mg_store_probe")
+            evs[12].record()
+            torch.cuda.synchronize()
+            ms = sorted(evs[q].elapsed_time(evs[q + 1]) for q in range(3, 12))
+            box[name] = {"best_GBps": FRAME * n_local / (ms[0] * 1e-3) / 1e9, "median_GBps": FRAME * n_local / (ms[len(ms) // 2] * 1e-3) / 1e9,
+                         "best_ms": ms[0], "median_ms": ms[len(ms) // 2]}
+        env.step(acts[0])  # (the probes zeroed the observations: one step redraws every frame)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -292,7 +331,8 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     out = {"env_id": env_id, "n_local": n_local, "n_total": n_total, "seconds": dt_max, "value": n_total * K / dt_max,
            "wall_ms_per_step": dt_wall / K * 1e3, "timing": ("host clock between the fences (a collective runs beside the launch stream)"
                                                                if (gather and dist_on) else "hipEvent pair on the launch stream around the K steps"),
-           "extra": extra, "value_windows": windows, "path_gen": path_gen,
+           "extra": extra, "value_windows": windows, "path_gen": path_gen, "box": box, "setup_steps": settle,
+           "settle_windows_ms": settle_windows,
            "ms_per_step": dt_max / K * 1e3, "raster_avg_ms": raster_ms / raster_n if raster_n else None, "raster_launches": raster_n,
            "logic_avg_ms": logic_ms / logic_n if logic_n else None, "event_region": region,
            "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if dist_on else None, "note": note}
@@ -324,6 +364,9 @@ def secondary_workloads(primary, dev, settle, traffic=True):
               "frac_whole_step": STEP_BYTES[env_id] * r["n_local"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
               "dominant_kernel": "step + raster in one launch" if not r["logic_avg_ms"] else "raster",
               "frac_dominant_kernel": (entry["raster_GBps"] / HBM_PEAK_GBPS) if entry["raster_GBps"] else None, "traffic": None}
+        if r.get("box") and entry["raster_GBps"]:
+            rl["box_ceiling_GBps"] = {"linear_fill": r["box"]["linear_fill"]["median_GBps"], "frame_shaped": r["box"]["frame_shaped"]["median_GBps"]}
+            rl["frac_of_box_ceiling"] = entry["raster_GBps"] / r["box"]["frame_shaped"]["median_GBps"]
         if traffic:
             tb, meta = measure_traffic(env_id, r["n_local"])
             rl["traffic"], rl["traffic_source"] = tb, meta.get("source")
@@ -368,11 +411,13 @@ def other_workloads(primary, dev, settle):
                     "roofline": {"bytes_per_launch_per_instance": algo, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac_dominant_kernel": algo * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if r["raster_avg_ms"] else None,
                                  "frac_whole_step_frame_bytes_only": algo * r["n_local"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 "traffic": None, "traffic_note": "not measured in this run: profiles/r04b_*.md hold the PMC passes"}})
+                                 "box_ceiling_GBps": ({"linear_fill": r["box"]["linear_fill"]["median_GBps"], "frame_shaped": r["box"]["frame_shaped"]["median_GBps"]} if r.get("box") else None),
+                                 "frac_of_box_ceiling": (algo * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 / r["box"]["frame_shaped"]["median_GBps"]) if (r.get("box") and r["raster_avg_ms"]) else None,
+                                 "traffic": None, "traffic_note": "not measured in this run: profiles/ holds the PMC passes"}})
     return out
 
 
-def c1_leg(episodes=200):
+def c1_leg(episodes=1000):
     """BASELINE config C1 (the reference's own loop, /root/reference/bench.py:12-30, restated in tests/c1_loop.py): one
     MortarMayhem-Grid-v0 instance, reset(seed=1), actions from Generator(PCG64(12345)), `episodes` episodes with the resets
     inside the timed region.  The HIP single-instance adapter here, the CPU oracle (one thread) in a subprocess; both walk
@@ -560,7 +605,7 @@ def main():
         out = {
             "metric": "env steps/sec (aggregate)", "value": r["value"], "unit": "env steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format, "setup_steps": args.settle,
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format, "setup_steps": r["setup_steps"],
             "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 obs (%s), same-step auto-reset, uniform random "
                                    "actions generated on device%s" % (env_id, n_local, world, args.obs_format, gather_txt),
                        "env_id": env_id, "envs_per_gpu": n_local, "envs_total": r["n_total"],
@@ -577,7 +622,13 @@ def main():
             out["gather_check"] = r["gather_check"]
         if r["raster_launches"]:
             avg_ms = r["raster_avg_ms"]
-            rb = (FRAME * obs_elem + DESC_BYTES.get(env_id, 16)) * n_local
+            # Algorithmic bytes of the timed launch per instance-step.  Mortar family: the step's workgroups ride in front of the
+            # raster's in ONE launch, so that launch moves the whole step's bytes: SURVEY.md 8(d)'s figure (MortarMayhem-Grid
+            # 21,305 B; rounds 3-4 priced it at the raster's 21,184 only).  Two-launch families: the raster's frame + descriptor.
+            one_launch = not r["logic_avg_ms"]
+            per_inst = (STEP_BYTES.get(env_id, FRAME + DESC_BYTES.get(env_id, 16)) + FRAME * (obs_elem - 1)) if one_launch \
+                else (FRAME * obs_elem + DESC_BYTES.get(env_id, 16))
+            rb = per_inst * n_local
             achieved = rb / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source, traffic_meta = None, None, None
             if world == 1 and obs_elem == 1 and not args.no_traffic:
@@ -595,13 +646,20 @@ def main():
                     traffic = None
             # (mortar family: the step's workgroups ride in front of the raster's in ONE launch, so `avg_launch_ms` is the whole
             # step's launch and there is no separate logic kernel to time; the algorithmic bytes stay the raster's)
-            one_launch = not r["logic_avg_ms"]
             out["roofline"] = {"bound": "hbm", "kernel": "step + raster in one launch (rank 0)" if one_launch else "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                                "traffic_passes": traffic_meta,
-                               "bytes_per_launch": rb, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],
+                               "bytes_per_launch": rb, "bytes_per_instance_step": per_inst, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],
                                "event_region": r["event_region"], "logic_kernel_avg_ms": r["logic_avg_ms"],
                                "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * r["n_total"] / (r["seconds"] / K) / 1e9}
+            if r.get("box"):
+                # the same buffer, the same launch size, pure stores: what separates the box (and the buffer's placement) from the code
+                b = r["box"]
+                out["roofline"]["box_ceiling_GBps"] = {"linear_fill": b["linear_fill"]["median_GBps"], "frame_shaped": b["frame_shaped"]["median_GBps"],
+                                                       "linear_fill_best": b["linear_fill"]["best_GBps"], "frame_shaped_best": b["frame_shaped"]["best_GBps"],
+                                                       "how": "mg_store_probe over this run's observation buffer (%d frames), median / best of 9 launches each, right behind the timed region" % n_local}
+                out["roofline"]["frac_of_box_ceiling"] = achieved / b["frame_shaped"]["median_GBps"]
+                out["roofline"]["frac_of_linear_fill"] = achieved / b["linear_fill"]["median_GBps"]
         if r["obs_placement"]:  # mg_obs_alloc: observation buffer assembled from pieces in different HBM zones
             out["obs_placement"] = r["obs_placement"]
 

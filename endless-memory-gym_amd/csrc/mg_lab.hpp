@@ -4,8 +4,8 @@
 // there and every branch behind it folds away.  The same sources built with -DMG_LAB (lib/lab/libmemgym_hip_lab.so,
 // __graft_entry__.build_lab()) honour the MEMGYM_* switches named at their call sites; tools/ and the few tests that need a
 // hook (tests/test_gpu_switches.py, test_gpu_error_bits.py, test_gpu_one_launch.py) load that build through MEMGYM_HIP_LIB.
-// What a USER can set stays outside this header: MEMGYM_OBS_PLACEMENT / MEMGYM_OBS_SEARCH_GB (Python mirror) and
-// MEMGYM_OBS_SEARCH_MS (mg_placement.hip).
+// What a USER can set stays outside the library altogether: MEMGYM_OBS_PLACEMENT / MEMGYM_OBS_SEARCH_GB / MEMGYM_OBS_SEARCH_MS are
+// read by the Python mirror (vec_env.py) and travel as arguments (mg_obs_alloc's budget, mg_obs_set_search_ms).
 #pragma once
 #include <stdlib.h>
 

@@ -71,6 +71,9 @@ def _load():
     L.mg_obs_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(ObsAllocInfo)]
     L.mg_obs_free.argtypes = [C.c_void_p]
     L.mg_obs_debug_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    if hasattr(L, "mg_obs_set_search_ms"):  # (absent from builds of earlier rounds that tools/ A/B against through MEMGYM_HIP_LIB)
+        L.mg_obs_set_search_ms.argtypes = [C.c_double]
+        L.mg_store_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.mg_enable_peer_access.argtypes = [C.c_int, C.c_int]
     L.mg_debug_rng.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     if hasattr(L, "mg_set_option_set"):

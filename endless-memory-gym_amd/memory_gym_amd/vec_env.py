@@ -88,7 +88,8 @@ class _ObsMemory:
 def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
     """A tensor of `shape` / `dtype` on `device` whose memory comes from mg_obs_alloc (pieces from two HBM zones, see
     include/memgym.h); returns (tensor, info dict).  The memory is released when the last tensor viewing it goes away.
-    MEMGYM_OBS_SEARCH_GB bounds the transient filler allocations of the search (default: half of the free memory, at
+    MEMGYM_OBS_SEARCH_MS bounds the search in time (default 1,500 ms), MEMGYM_OBS_SEARCH_GB its transient filler allocations
+    (default: half of the free memory, at
     most 128 GiB -- VRAM that other processes on the GPU cannot have for the few milliseconds the search lasts; 0 = do not
     search).  The buffer is accessible from this device and from every device with peer access to it."""
     device = torch.device(device)
@@ -97,6 +98,9 @@ def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
     if search_budget_bytes is None:
         e = os.environ.get("MEMGYM_OBS_SEARCH_GB")
         search_budget_bytes = _native.MG_OBS_SEARCH_DEFAULT if e is None else int(float(e) * (1 << 30))
+    ms = os.environ.get("MEMGYM_OBS_SEARCH_MS")  # time bound of the search (default 1,500 ms; include/memgym.h: mg_obs_set_search_ms)
+    if ms is not None and hasattr(_native.LIB, "mg_obs_set_search_ms"):
+        _native.check(_native.LIB.mg_obs_set_search_ms(float(ms)), "mg_obs_set_search_ms")
     ptr, info = C.c_void_p(), _native.ObsAllocInfo()
     with torch.cuda.device(device):
         torch.cuda.current_stream().synchronize()

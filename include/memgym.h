@@ -222,8 +222,13 @@ int mg_peek_errors(mg_env* env, int* flags);
  * less, and runtimes without hipMemCreate, get a plain hipMalloc.  The range is accessible from the owning device and from
  * every device that reports peer access to it.  Virtual address ranges are never returned to the runtime (a reused range can
  * keep stale translations on ROCm 7.2): a process that allocates and frees buffers for ever uses address space, not memory.
- * Synchronous; 2-10 ms typically, bounded by MEMGYM_OBS_SEARCH_MS (1.5 s).  mg_obs_free releases a buffer obtained here
- * (after synchronising the device); the pieces go to a pool of at most ten for the next buffer. */
+ * Synchronous; 2-10 ms typically.  The search is bounded in time (mg_obs_set_search_ms, default 1,500 ms): the clock is read
+ * after every handle the walk creates and the walk ends when the time spent plus the projected cost of handing everything
+ * back would pass the bound, so that the call as a whole stays within 1.5 x the bound plus the assembly of the buffer
+ * (info.search_ms; a search that runs out of time ends with what it has: two zones if it found them, else the plain
+ * allocation).  The library reads no environment variable for any of this (the Python mirror forwards MEMGYM_OBS_SEARCH_MS /
+ * MEMGYM_OBS_SEARCH_GB as arguments).  mg_obs_free releases a buffer obtained here (after synchronising the device); the
+ * pieces go to a pool of at most ten for the next buffer. */
 typedef struct mg_obs_alloc_info {
     int zones;               /* 2, 3 = pieces from that many zones; 1 = no second zone within the budget (plain
                               * allocation); 0 = plain allocation without a search (small buffer, no room)          */
@@ -237,6 +242,13 @@ typedef struct mg_obs_alloc_info {
 #define MG_OBS_SEARCH_DEFAULT ((size_t)-1)
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out_dev, mg_obs_alloc_info* info);
 int mg_obs_free(void* obs_dev);
+int mg_obs_set_search_ms(double ms);  /* process-wide; >= 0 */
+/* Measurement hook (bench.py's per-box control: roofline.box_ceiling_GBps): ONE launch of a pure store stream over
+ * n_frames x 21,168 bytes at obs_dev on `stream`; the caller times it with events.  pattern 0 = linear fill, one 16-byte
+ * store per thread (the memory system's ceiling for stores at this size and placement); pattern 1 = the raster's store
+ * shape without compose work (persistent 256-lane workgroups writing whole frames; the raster's grid and residency) = the
+ * ceiling of a frame-shaped stream.  Overwrites the buffer with zeros. */
+int mg_store_probe(void* obs_dev, size_t n_frames, int pattern, hipStream_t stream);
 /* Test hook: live buffers, pooled spare pieces, bytes of virtual address space reserved so far. */
 int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* reserved_va_bytes);
 
