@@ -36,6 +36,14 @@ struct mg_env {
     int obs_format = MG_OBS_U8_XYC;
     float* vec_dev = nullptr;
     int prof_stride = 0;
+    // mg_single_open: pinned, device-mapped host buffers of the single-instance fast path (host address, device address)
+    struct Single {
+        bool open = false;
+        char *host = nullptr, *dev = nullptr;
+        size_t bytes = 0;
+        size_t o_action = 0, o_seed = 0, o_obs = 0, o_vec = 0, o_reward32 = 0, o_reward = 0, o_done = 0, o_gt32 = 0, o_gt = 0, o_ep_reward = 0,
+               o_ep_length = 0, o_aux = 0;
+    } single;
     hipStream_t gs[MG_MAX_GROUPS] = {};
     hipEvent_t ev_in = nullptr, ev_logic[MG_MAX_GROUPS] = {}, ev_done[MG_MAX_GROUPS] = {};
     int groups() const { return (int)fams.size(); }
@@ -113,6 +121,10 @@ mg::Family* make_family(int family, int variant, int n) {
     return mg::make_mystery(variant, n);
 }
 void destroy_families(mg_env* e) {
+    if (e->single.host) {  // (the families hold device views of it: mg_destroy synchronises first)
+        (void)hipHostFree(e->single.host);
+        e->single = mg_env::Single();
+    }
     for (auto* f : e->fams) delete f;
     e->fams.clear();
     e->fam = nullptr;
@@ -249,6 +261,7 @@ int mg_set_groups(mg_env* env, int groups) {
         if (groups != 1 && groups != 2 && groups != 4 && groups != 8) throw std::runtime_error("mg_set_groups: 1, 2, 4 or 8 groups");
         if (env->num_envs % groups != 0 || env->num_envs / groups < 1) throw std::runtime_error("mg_set_groups: num_envs must be divisible by the number of groups");
         if (env->started) throw std::runtime_error("mg_set_groups: the grouping is fixed by the first mg_reset");
+        if (env->single.open) throw std::runtime_error("mg_set_groups: the handle is open for the single-instance fast path");
         if (groups != env->groups()) {
             const int before = env->groups();
             try {
@@ -397,6 +410,7 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
             for (int k = 0; k < MG_INFO_SLOTS; ++k) gi.aux_dev[k] = off(ib.aux_dev[k], b);
             gi.final_obs_dev = ib.final_obs_dev ? (char*)ib.final_obs_dev + b * ob : nullptr;
             gi.reward64_dev = off(ib.reward64_dev, b);
+            gi.gt64_dev = off(ib.gt64_dev, b * gd);
             mg::Family* f = env->fams[g];
             void* obs_g = (char*)obs_dev + b * ob;
             if (autoreset && gi.final_obs_dev) {
@@ -409,7 +423,93 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
             } else {
                 f->step(actions_dev + b * ad, obs_g, reward_dev + b, done_dev + b, off(gt_dev, b * gd), &gi, autoreset, gst);
             }
+            if (gi.gt64_dev) f->ground_truth64(gi.gt64_dev, gst);
         });
+    });
+}
+
+int mg_ground_truth64(mg_env* env, double* gt64_dev, void* stream) {
+    return guarded(env, [&] {
+        const int gd = env->fam->gt_dim();
+        if (!gd) return;
+        if (!gt64_dev) throw std::runtime_error("mg_ground_truth64: gt64_dev is NULL");
+        for_groups(env, (hipStream_t)stream, false, [&](int g, hipStream_t st) {
+            env->fams[g]->sync_state();
+            env->fams[g]->ground_truth64(gt64_dev + (size_t)env->base[g] * gd, st);
+        });
+    });
+}
+
+// ---- the single-instance fast path (include/memgym.h: mg_single_io) ----
+int mg_single_open(mg_env* env, mg_single_io* io) {
+    return guarded(env, [&] {
+        if (!io || io->struct_size != sizeof(mg_single_io)) throw std::runtime_error("mg_single_open: set io->struct_size = sizeof(mg_single_io)");
+        if (env->num_envs != 1 || env->groups() != 1) throw std::runtime_error("mg_single_open: the handle must hold exactly one instance in one group");
+        mg_env::Single& S = env->single;
+        if (!S.open) {
+            size_t o = 0;
+            auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+            S.o_action = take(8); S.o_seed = take(8);
+            S.o_obs = take(84 * 84 * 3 * 4);  // room for every observation format
+            S.o_vec = take(sizeof(float) * 256);
+            S.o_reward32 = take(4); S.o_reward = take(8); S.o_done = take(1);
+            S.o_gt32 = take(sizeof(float) * 8); S.o_gt = take(sizeof(double) * 8);
+            S.o_ep_reward = take(8); S.o_ep_length = take(4); S.o_aux = take(sizeof(float) * MG_INFO_SLOTS * 64);  // (one 256-byte line per slot)
+            S.bytes = o;
+            MG_HIP(hipHostMalloc((void**)&S.host, S.bytes, hipHostMallocMapped | hipHostMallocCoherent));
+            memset(S.host, 0, S.bytes);
+            MG_HIP(hipHostGetDevicePointer((void**)&S.dev, S.host, 0));
+            S.open = true;
+        }
+        if (env->fam->vec_dim()) {  // the vector observation is written at every reset, into the mapped buffer from now on
+            env->vec_dev = (float*)(S.dev + S.o_vec);
+            env->fam->bind_vector_obs(env->vec_dev);
+        }
+        io->obs = S.host + S.o_obs;
+        io->vec = env->fam->vec_dim() ? (float*)(S.host + S.o_vec) : nullptr;
+        io->reward = (double*)(S.host + S.o_reward);
+        io->done = (uint8_t*)(S.host + S.o_done);
+        io->gt = (double*)(S.host + S.o_gt);
+        io->ep_reward = (double*)(S.host + S.o_ep_reward);
+        io->ep_length = (int32_t*)(S.host + S.o_ep_length);
+        for (int k = 0; k < MG_INFO_SLOTS; ++k) io->aux[k] = (float*)(S.host + S.o_aux + 256 * k);
+    });
+}
+
+int mg_single_reset(mg_env* env, int64_t seed, int has_seed, void* stream) {
+    return guarded(env, [&] {
+        mg_env::Single& S = env->single;
+        if (!S.open) throw std::runtime_error("mg_single_reset: mg_single_open first");
+        hipStream_t st = (hipStream_t)stream;
+        *(int64_t*)(S.host + S.o_seed) = seed;
+        mg::Family* f = env->fam;
+        f->reset(has_seed ? (const int64_t*)(S.dev + S.o_seed) : nullptr, nullptr, S.dev + S.o_obs, f->gt_dim() ? (float*)(S.dev + S.o_gt32) : nullptr, st);
+        f->ground_truth64((double*)(S.dev + S.o_gt), st);
+        env->started = true;
+        MG_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream) {
+    return guarded(env, [&] {
+        mg_env::Single& S = env->single;
+        if (!S.open) throw std::runtime_error("mg_single_step: mg_single_open first");
+        hipStream_t st = (hipStream_t)stream;
+        int32_t* act = (int32_t*)(S.host + S.o_action);
+        act[0] = a0;
+        act[1] = a1;
+        mg_info_buffers ib;
+        memset(&ib, 0, sizeof(ib));
+        ib.struct_size = sizeof(ib);
+        ib.ep_reward_dev = (double*)(S.dev + S.o_ep_reward);
+        ib.ep_length_dev = (int32_t*)(S.dev + S.o_ep_length);
+        for (int k = 0; k < MG_INFO_SLOTS; ++k) ib.aux_dev[k] = (float*)(S.dev + S.o_aux + 256 * k);
+        ib.reward64_dev = (double*)(S.dev + S.o_reward);
+        mg::Family* f = env->fam;
+        f->step((const int32_t*)(S.dev + S.o_action), S.dev + S.o_obs, (float*)(S.dev + S.o_reward32), (uint8_t*)(S.dev + S.o_done),
+                f->gt_dim() ? (float*)(S.dev + S.o_gt32) : nullptr, &ib, 0, st);
+        f->ground_truth64((double*)(S.dev + S.o_gt), st);
+        MG_HIP(hipStreamSynchronize(st));
     });
 }
 

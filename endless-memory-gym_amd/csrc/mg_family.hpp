@@ -218,6 +218,10 @@ class Family {
     // put off without changing any result (Endless Mystery Path: owed path segments) is done now.  Synchronous.
     virtual void sync_state() {}
     virtual void debug_rng(int i, uint64_t out[6]) = 0;
+    // info["ground_truth"] as the reference returns it -- float64 (e.g. endless_mortar_mayhem.py:259,358) -- of every instance,
+    // [num_envs][gt_dim], computed from the CURRENT state (the float32 gt_dev of mg_step / mg_reset is its rounding); a small
+    // launch of its own, only when a caller asks (mg_info_buffers.gt64_dev, mg_ground_truth64).  No-op for gt_dim() == 0.
+    virtual void ground_truth64(double* /*gt64_dev*/, hipStream_t /*s*/) {}
     // device-side error bits accumulated since the last call (0 = none); synchronises
     virtual int poll_errors() { return 0; }
     // the same bits as seen right now, without synchronising or clearing

@@ -662,6 +662,15 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
 }
 
 // Debug view: the frame descriptors of the current frames with (a) the glyph the reference's CLONE of the display schedule
+// info["ground_truth"] in float64: target tile / 5.0 (endless_mortar_mayhem.py:259,358,362)
+__global__ __launch_bounds__(256) void mortar_gt64_kernel(int n, const MortarState* state, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MortarState s = state[i];
+    out[2 * i] = s.tx / 5.0;
+    out[2 * i + 1] = s.ty / 5.0;
+}
+
 // yields -- its next entry, popped (dbg_pops, the only state a debug render changes), only while the real schedule still
 // holds entries (oracle/mgo_mortar.c mm_debug) -- and (b) the ring around the target tile.
 __global__ __launch_bounds__(256) void mortar_debug_desc_kernel(MortarParams P0, int n, MortarIO io, MortarDesc* out) {
@@ -881,6 +890,11 @@ class MortarFamily : public Family {
     }
 
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+    void ground_truth64(double* out, hipStream_t s) override {
+        if (!gt_dim() || !out) return;
+        hipLaunchKernelGGL(mortar_gt64_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, state_.p, out);
+        MG_HIP(hipGetLastError());
+    }
     int poll_errors() override {
         MG_HIP(hipDeviceSynchronize());
         return err_.take();

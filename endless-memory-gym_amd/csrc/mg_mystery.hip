@@ -196,6 +196,16 @@ struct MysteryDebugComposerT {
 typedef MysteryDebugComposerT<false> MysteryDebugComposer;
 typedef MysteryDebugComposerT<true> MysteryDebugBigComposer;
 
+// info["ground_truth"] in float64: the one-hot direction of the next path tile (endless_mystery_path.py:92-97)
+__global__ __launch_bounds__(256) void mystery_gt64_kernel(int n, const MysteryCore* core, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MysteryCore s = load_core(core + i);
+    out[3 * i + 0] = (double)s.td[0];
+    out[3 * i + 1] = (double)s.td[1];
+    out[3 * i + 2] = (double)s.td[2];
+}
+
 struct MysteryIO {
     MysteryCore* core;
     uint8_t* segs;      // endless: [N][MAX_SEG][SEG_STRIDE]; node byte = x_rel | y<<3 | rvis<<6 | svis<<7
@@ -2119,6 +2129,11 @@ class MysteryFamily : public Family {
         return v;
     }
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+    void ground_truth64(double* out, hipStream_t s) override {
+        if (!gt_dim() || !out) return;
+        hipLaunchKernelGGL(mystery_gt64_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, core_.p, out);
+        MG_HIP(hipGetLastError());
+    }
     int poll_errors() override {
         MG_HIP(hipDeviceSynchronize());
         return err_.take();

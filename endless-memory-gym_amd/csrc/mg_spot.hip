@@ -892,6 +892,18 @@ __device__ __forceinline__ void spot_reset(const SpotParams& P, const SpotIO& io
     }
 }
 
+// info["ground_truth"] in float64: agent and coin position / screen size (endless_searing_spotlights.py:407,496)
+__global__ __launch_bounds__(256) void spot_gt64_kernel(SpotParams P0, SpotIO io, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P0.n) return;
+    const SpotParams& P = io.set_of ? io.sets[set_index(io.set_of, i)] : P0;
+    const SpotCore s = io.core[i];
+    out[4 * i + 0] = (double)s.ax / SCREEN;
+    out[4 * i + 1] = (double)s.ay / SCREEN;
+    out[4 * i + 2] = P.coin_enabled ? (double)s.coin_x / SCREEN : 0.0;
+    out[4 * i + 3] = P.coin_enabled ? (double)s.coin_y / SCREEN : 0.0;
+}
+
 __global__ __launch_bounds__(256) void spot_init_kernel(int n, SpotCore* core) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1722,6 +1734,12 @@ class SpotFamily : public Family {
         return v;
     }
     void debug_rng(int i, uint64_t out[6]) override { rng_.debug(i, out); }
+    void ground_truth64(double* out, hipStream_t s) override {
+        if (!gt_dim() || !out) return;
+        upload_sets(s);
+        hipLaunchKernelGGL(spot_gt64_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), out);
+        MG_HIP(hipGetLastError());
+    }
     int poll_errors() override {
         MG_HIP(hipDeviceSynchronize());
         return err_.take();

@@ -19,7 +19,12 @@ MG_MAX_OPTION_SETS = 8
 
 class InfoBuffers(C.Structure):
     _fields_ = [("struct_size", C.c_size_t), ("ep_reward_dev", C.c_void_p), ("ep_length_dev", C.c_void_p), ("aux_dev", C.c_void_p * MG_INFO_SLOTS),
-                ("final_obs_dev", C.c_void_p), ("reward64_dev", C.c_void_p)]
+                ("final_obs_dev", C.c_void_p), ("reward64_dev", C.c_void_p), ("gt64_dev", C.c_void_p)]
+
+
+class SingleIO(C.Structure):  # include/memgym.h: mg_single_io (host addresses of pinned, device-mapped buffers)
+    _fields_ = [("struct_size", C.c_size_t), ("obs", C.c_void_p), ("vec", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("gt", C.c_void_p), ("ep_reward", C.c_void_p), ("ep_length", C.c_void_p), ("aux", C.c_void_p * MG_INFO_SLOTS)]
 
 
 class ObsAllocInfo(C.Structure):
@@ -71,6 +76,11 @@ def _load():
     L.mg_obs_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(ObsAllocInfo)]
     L.mg_obs_free.argtypes = [C.c_void_p]
     L.mg_obs_debug_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    if hasattr(L, "mg_single_open"):  # round 5
+        L.mg_ground_truth64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mg_single_open.argtypes = [C.c_void_p, C.POINTER(SingleIO)]
+        L.mg_single_reset.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.mg_single_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     if hasattr(L, "mg_obs_set_search_ms"):  # (absent from builds of earlier rounds that tools/ A/B against through MEMGYM_HIP_LIB)
         L.mg_obs_set_search_ms.argtypes = [C.c_double]
         L.mg_store_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]

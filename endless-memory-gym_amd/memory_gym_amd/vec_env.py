@@ -118,7 +118,7 @@ class VecMemoryGym:
                    "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
     def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False,
-                 obs_buffer=None, obs_placement=None, groups=1):
+                 obs_buffer=None, obs_placement=None, groups=1, ground_truth64=False):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -186,6 +186,9 @@ class VecMemoryGym:
         self.reward64 = torch.zeros(N, dtype=torch.float64, device=dev)  # the reference's Python float, unrounded
         self.done_u8 = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.gt = torch.zeros((N, max(self.gt_dim, 1)), dtype=torch.float32, device=dev)
+        # ground_truth64=True: info["ground_truth"] is the reference's float64 array (endless_mortar_mayhem.py:259,358: 0.6, not
+        # float32's 0.60000002), computed by one more small launch per call (include/memgym.h: gt64_dev); default: float32
+        self.gt64 = torch.zeros((N, max(self.gt_dim, 1)), dtype=torch.float64, device=dev) if (ground_truth64 and self.gt_dim) else None
         self.ep_reward = torch.zeros(N, dtype=torch.float64, device=dev)
         self.ep_length = torch.zeros(N, dtype=torch.int32, device=dev)
         self.info_names = []
@@ -204,6 +207,7 @@ class VecMemoryGym:
             self._info.aux_dev[k] = t.data_ptr()
         self._info.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
         self._info.reward64_dev = self.reward64.data_ptr()
+        self._info.gt64_dev = self.gt64.data_ptr() if self.gt64 is not None else None
         self.reset_params = process_reset_params(env_id, None)
         self._applied = dict(DEFAULTS[env_id])
         self._set_params = [self._applied]  # what each option set of the handle holds (set 0 = the handle-wide one)
@@ -338,8 +342,10 @@ class VecMemoryGym:
             _native.check(_native.LIB.mg_reset(self._h, None if s is None else s.data_ptr(),
                                                None if m is None else m.data_ptr(), self.obs.data_ptr(),
                                                self.gt.data_ptr() if self.gt_dim else None, self._stream()), "mg_reset")
+            if self.gt64 is not None:
+                _native.check(_native.LIB.mg_ground_truth64(self._h, self.gt64.data_ptr(), self._stream()), "mg_ground_truth64")
             self._seeded = True
-        info = {"ground_truth": self.gt} if self.gt_dim else {}
+        info = {"ground_truth": self.gt if self.gt64 is None else self.gt64} if self.gt_dim else {}
         return self._obs(), info
 
     def step(self, actions):
@@ -359,7 +365,7 @@ class VecMemoryGym:
         for nm, t in zip(self.info_names, self.aux):
             info[nm] = t
         if self.gt_dim:
-            info["ground_truth"] = self.gt
+            info["ground_truth"] = self.gt if self.gt64 is None else self.gt64
         if self.final_obs is not None and self.autoreset:  # rows valid where done_mask is set
             info["final_observation"] = self.final_obs
         return self._obs(), self.reward, done, self._truncated, info
@@ -513,7 +519,13 @@ class MemoryGymEnv(_EnvBase):
     """Single-instance environment with the reference's exact signatures (reset -> (obs, info); step -> 5-tuple of numpy
     obs, Python float reward, bool, False, dict) -- what `gymnasium.make(id)` returns.  Subclasses gymnasium.Env when
     gymnasium is importable; without it the same protocol surface (`unwrapped`, `spec`, `np_random`, `metadata`,
-    `render_mode`, spaces) is provided here, so code written against the reference runs either way."""
+    `render_mode`, spaces) is provided here, so code written against the reference runs either way.
+
+    Round 5: the single-instance fast path of the C ABI (include/memgym.h: mg_single_open / mg_single_reset / mg_single_step).
+    Observation, reward, done, ground truth and the end-of-episode record live in pinned host memory that is mapped into the
+    device; the kernels read the action from it and store their results straight into it, so step() is ONE native call (store the
+    action, enqueue the step's launches, wait for the stream) and a copy of the 21-KB frame -- no torch operation.  (Rounds 1-4: an
+    H2D action copy, two indexing kernels, three D2H copies and a stream synchronisation per step: 14 k steps/s.)"""
 
     metadata = {"render_modes": ["rgb_array", "debug_rgb_array"], "render_fps": 25}
     spec = None
@@ -530,12 +542,26 @@ class MemoryGymEnv(_EnvBase):
             self.ground_truth_space = self.vec.ground_truth_space
         self.render_mode = render_mode
         self._np_random = None
-        # one device->host round trip per call: pinned staging buffers, asynchronous copies, a single stream sync
-        self._h_obs = torch.empty(self.vec.obs.shape[1:], dtype=self.vec.obs.dtype).pin_memory()
-        self._h_rd = torch.empty(2, dtype=torch.float64).pin_memory()
-        self._h_gt = torch.empty(max(self.vec.gt_dim, 1), dtype=torch.float32).pin_memory()
-        self._h_vec = torch.empty(self.vec.vec_dim, dtype=torch.float32).pin_memory() if self.vec.vec_dim else None
-        self._d_rd = torch.empty(2, dtype=torch.float64, device=self.vec.device)
+        io = _native.SingleIO()
+        io.struct_size = C.sizeof(_native.SingleIO)
+        with torch.cuda.device(self.vec.device):
+            _native.check(_native.LIB.mg_single_open(self.vec._h, C.byref(io)), "mg_single_open")
+        self._io = io
+
+        def view(ptr, ctype, shape):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=shape)
+        self._obs_host = view(io.obs, C.c_uint8, (84, 84, 3))
+        self._vec_host = view(io.vec, C.c_float, (self.vec.vec_dim,)) if self.vec.vec_dim else None
+        self._reward_host = view(io.reward, C.c_double, (1,))
+        self._done_host = view(io.done, C.c_uint8, (1,))
+        self._gt_host = view(io.gt, C.c_double, (max(self.vec.gt_dim, 1),))
+        self._ep_reward_host = view(io.ep_reward, C.c_double, (1,))
+        self._ep_length_host = view(io.ep_length, C.c_int32, (1,))
+        self._aux_host = [view(io.aux[k], C.c_float, (1,)) for k in range(len(self.vec.info_names))]
+        self._two_actions = self.vec.action_dim == 2
+        self._stream = C.c_void_p(torch.cuda.current_stream(self.vec.device).cuda_stream)
+        self._step_fn, self._h, self._errword = _native.LIB.mg_single_step, self.vec._h, self.vec._err
+        self._peek = _native.LIB.mg_peek_errors
 
     # ---- gymnasium.Env protocol surface that exists with or without gymnasium
     @property
@@ -554,22 +580,10 @@ class MemoryGymEnv(_EnvBase):
     def np_random(self, value):
         self._np_random = value
 
-    def _fetch(self, obs, reward=None, done=None):
-        """Copies obs (+ reward, done, ground truth) of the single instance to the host with one synchronisation."""
-        vis = obs["visual_observation"] if isinstance(obs, dict) else obs
-        self._h_obs.copy_(vis[0], non_blocking=True)
-        if self._h_vec is not None:
-            self._h_vec.copy_(obs["vector_observation"][0], non_blocking=True)
-        if reward is not None:
-            self._d_rd[0] = self.vec.reward64[0]
-            self._d_rd[1] = done[0]
-            self._h_rd.copy_(self._d_rd, non_blocking=True)
-        if self.vec.gt_dim:
-            self._h_gt.copy_(self.vec.gt[0], non_blocking=True)
-        torch.cuda.current_stream(self.vec.device).synchronize()
-        o = self._h_obs.numpy().copy()
-        if self._h_vec is not None:
-            o = {"visual_observation": o, "vector_observation": self._h_vec.numpy().copy()}
+    def _observation(self):
+        o = self._obs_host.copy()
+        if self._vec_host is not None:
+            o = {"visual_observation": o, "vector_observation": self._vec_host.copy()}
         return o
 
     @property
@@ -579,30 +593,51 @@ class MemoryGymEnv(_EnvBase):
     def reset(self, seed=None, return_info=True, options=None):
         if seed is not None:  # gymnasium.Env.reset(seed): the host-side generator follows the same seed
             self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(seed))))
-        obs, info = self.vec.reset(seed=seed, options=options)
-        o = self._fetch(obs)
+        v = self.vec
+        with torch.cuda.device(v.device):
+            v._apply_options(options)
+            if seed is None and not v._seeded:  # first reset without a seed: OS entropy, like gymnasium's np_random(None)
+                seed = int(np.random.SeedSequence().generate_state(1, np.uint64)[0] >> np.uint64(1))
+            self._stream = C.c_void_p(torch.cuda.current_stream(v.device).cuda_stream)
+            _native.check(_native.LIB.mg_single_reset(self._h, 0 if seed is None else int(seed), 0 if seed is None else 1, self._stream), "mg_single_reset")
+            v._seeded = True
         out = {}
-        if "ground_truth" in info:
-            out["ground_truth"] = self._h_gt.numpy().astype(np.float64)
-        return o, out
+        if v.gt_dim:
+            out["ground_truth"] = self._gt_host[:v.gt_dim].copy()
+        return self._observation(), out
 
     def step(self, action):
-        a = np.atleast_1d(np.asarray(action)).reshape(1, -1)
-        obs, reward, done, _, info = self.vec.step(a)
-        o = self._fetch(obs, reward, done)
-        r, d = float(self._h_rd[0]), bool(self._h_rd[1] != 0)  # r: the reference's Python float, bit for bit
+        if self._two_actions:
+            a0, a1 = int(action[0]), int(action[1])
+        else:
+            a0 = a1 = int(action)
+        rc = self._step_fn(self._h, a0, a1, self._stream)
+        if rc != 0:
+            _native.check(rc, "mg_single_step")
+        self._peek(self._h, C.byref(self._errword))  # host-mapped word: no synchronisation
+        if self._errword.value:
+            self.vec.check_errors()
+        r, d = float(self._reward_host[0]), bool(self._done_host[0])  # r: the reference's Python float, bit for bit
         out = {}
         if d:  # end of episode (rare): the reference's terminal info dict
-            out["reward"] = float(info["reward"][0].item())
-            out["length"] = int(info["length"][0].item())
-            for nm in self.vec.info_names:
-                out[nm] = float(info[nm][0].item())
-        if "ground_truth" in info:
-            out["ground_truth"] = self._h_gt.numpy().astype(np.float64)
-        return o, r, d, False, out
+            out["reward"] = float(self._ep_reward_host[0])
+            out["length"] = int(self._ep_length_host[0])
+            for nm, a in zip(self.vec.info_names, self._aux_host):
+                out[nm] = float(a[0])
+        if self.vec.gt_dim:
+            out["ground_truth"] = self._gt_host[:self.vec.gt_dim].copy()
+        return self._observation(), r, d, False, out
 
     def render(self):
-        return self.vec.render()[0].cpu().numpy()
+        if self.render_mode == "debug_rgb_array":
+            return self.vec.render_debug()[0].cpu().numpy()
+        return self._obs_host.transpose(1, 0, 2).copy()  # mortar_mayhem_grid.py:401-402
+
+    def state_dict(self):
+        return self.vec.state_dict()
+
+    def load_state_dict(self, sd):
+        self.vec.load_state_dict(sd)
 
     def close(self):
         self.vec.close()

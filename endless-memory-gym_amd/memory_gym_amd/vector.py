@@ -28,7 +28,9 @@ except Exception:  # gymnasium is not a dependency of the hot path
 
 class GymnasiumVectorEnv(_Base):
     def __init__(self, env_id, num_envs, device=None, obs_format="u8_xyc", as_numpy=False):
-        self.env = VecMemoryGym(env_id, num_envs=num_envs, device=device, obs_format=obs_format, final_observation=True)
+        # as_numpy: gymnasium's host-side layout with the reference's dtypes -- rewards and info["ground_truth"] as float64
+        self.env = VecMemoryGym(env_id, num_envs=num_envs, device=device, obs_format=obs_format, final_observation=True,
+                                ground_truth64=bool(as_numpy))
         self.as_numpy = bool(as_numpy)
         done = False
         if _Base is not object:  # gymnasium 0.29: VectorEnv.__init__(num_envs, observation_space, action_space) batches the spaces
@@ -88,7 +90,7 @@ class GymnasiumVectorEnv(_Base):
                 fobs[i] = rows[j]
                 finfo[i] = {k: (int(v[i]) if k == "length" else float(v[i])) for k, v in host_ep.items()}
             out.update(final_observation=fobs, _final_observation=d.copy(), final_info=finfo, _final_info=d.copy())
-        return self._host(obs), reward.cpu().numpy().astype(np.float64), d, trunc.cpu().numpy(), out
+        return self._host(obs), self.env.reward64.cpu().numpy(), d, trunc.cpu().numpy(), out  # (the reference's Python floats: doubles)
 
     # gymnasium.vector.VectorEnv API surface used by trainers
     def step_async(self, actions):

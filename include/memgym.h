@@ -48,6 +48,10 @@ typedef struct mg_info_buffers {
     /* Optional: the step reward of every instance as the reference computes it -- a Python float, i.e. a double
      * (e.g. mortar_mayhem_grid.py:288-352) -- next to reward_dev's float32 rounding of it; [num_envs]. */
     double* reward64_dev;
+    /* Optional (round 5): info["ground_truth"] as the reference returns it -- a float64 array (endless_mortar_mayhem.py:259,358,362,
+     * endless_searing_spotlights.py:407,496, endless_mystery_path.py:92-97) -- [num_envs][mg_gt_dim]; gt_dev is its float32
+     * rounding (0.6 -> 0.60000002).  Costs one small launch behind the step's; see also mg_ground_truth64. */
+    double* gt64_dev;
 } mg_info_buffers;
 
 /* gymnasium.make(id) + Env.__init__  (memory_gym/__init__.py:13-61; e.g. mortar_mayhem_grid.py:55-90).
@@ -162,6 +166,36 @@ int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream);
  * hold the first observation of the new episode; the finished episode's info is in `info`. */
 int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* reward_dev, uint8_t* done_dev,
             float* gt_dev, const mg_info_buffers* info, int autoreset, void* stream);
+
+/* The float64 ground truth of every instance from the CURRENT state (what the last mg_reset / mg_step left), [num_envs][mg_gt_dim]
+ * on the device: the doubles the reference puts into info["ground_truth"] after reset() as well as after step().  Enqueued on
+ * `stream`; a no-op for env ids without ground truth. */
+int mg_ground_truth64(mg_env* env, double* gt64_dev, void* stream);
+
+/* The single-instance fast path (BASELINE config C1: gym.make(id), one instance, numpy in / numpy out -- the reference's own loop,
+ * /root/reference/bench.py:12-30).  For a handle with num_envs == 1, mg_single_open allocates every per-call buffer in pinned,
+ * device-mapped HOST memory and returns the host addresses: the kernels read the action from it and store observation, reward,
+ * done, ground truth and the end-of-episode record straight into it (21 KB over PCIe), so that one call = store the action,
+ * enqueue the step's launches, wait for the stream -- no copy operation, no allocation, no indexing kernel.
+ *   mg_single_reset(env, seed, has_seed, stream)   Env.reset(seed) + wait; options through mg_set_option as ever
+ *   mg_single_step(env, a0, a1, stream)            Env.step(action) WITHOUT auto-reset (the caller resets, like the reference's
+ *                                                  loop) + wait; results are in the buffers of mg_single_io when it returns
+ * `obs` has the handle's observation format; `gt` holds mg_gt_dim doubles; `vec` the MortarMayhemB vector observation or NULL.
+ * The buffers live as long as the handle.  Same results as the batched path with one instance (tests/test_gpu_single_instance.py). */
+typedef struct mg_single_io {
+    size_t struct_size;   /* in: sizeof(mg_single_io) of the caller's header */
+    void* obs;
+    float* vec;
+    double* reward;       /* the step reward as the reference's Python float */
+    uint8_t* done;
+    double* gt;
+    double* ep_reward;    /* valid when *done: info["reward"], info["length"], aux[k] (mg_info_name) */
+    int32_t* ep_length;
+    float* aux[MG_INFO_SLOTS];
+} mg_single_io;
+int mg_single_open(mg_env* env, mg_single_io* io);
+int mg_single_reset(mg_env* env, int64_t seed, int has_seed, void* stream);
+int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream);
 
 /* Checkpoint hooks (the reference cannot serialise an env; SoA state makes it free).  Synchronous.
  * mg_state_size: bytes needed.  The blob starts with a 64-byte header {magic "MGSTATE1", MG_STATE_VERSION, num_envs,
