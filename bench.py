@@ -188,15 +188,17 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     # the collective path is taken whenever a process group exists -- also at world size 1 (RCCL on one GPU: the plumbing
     # test of tests/test_gpu_rccl_world1.py)
     dist_on = dist.is_available() and dist.is_initialized()
-    gatherer = ObsGatherer(env) if (gather == "rccl" and dist_on) else None  # double-buffered: gather t beside step t + 1
+    gatherer = ObsGatherer(env) if (gather == "rccl" and dist_on) else None  # double-buffered: gather t (frames + rewards / dones) beside step t + 1
+    if peer is not None:  # the step's rewards / dones (5 B per instance) ride on the collective that orders the streams
+        peer.bind_scalars(env)
 
     def one_step(k):
         if gatherer is not None:
             gatherer.step(acts[k % n_act_bufs])
             return
         env.step(acts[k % n_act_bufs])
-        if peer is not None:  # the frames are already in rank 0's memory; one 4-byte all-reduce orders the streams
-            peer.fence()
+        if peer is not None:  # the frames are already in rank 0's memory; the gather of the packed rewards / dones orders the streams
+            peer.fence_with_scalars()
 
     def fence():
         if gatherer is not None:
@@ -280,7 +282,7 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     # the timed region -- a linear 16-byte fill (the memory system's store ceiling here) and the raster's store shape without
     # any compose work (include/memgym.h: mg_store_probe).  Best and median of 9 launches each after 3 warm-ups.
     box = None
-    if obs_format == "u8_xyc" and peer is None and hasattr(memory_gym_amd._native.LIB, "mg_store_probe"):
+    if obs_format == "u8_xyc" and peer is None and gatherer is None and hasattr(memory_gym_amd._native.LIB, "mg_store_probe"):  # (a gatherer's buffers are checked below)
         import ctypes as C
         box = {}
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -337,8 +339,11 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
            "logic_avg_ms": logic_ms / logic_n if logic_n else None, "event_region": region,
            "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if dist_on else None, "note": note}
     if gatherer is not None and rank == 0:  # the frames rank 0 received in the last step equal the ranks' own (rank 0's: checked here)
-        got = gatherer.gathered()
-        out["gather_check"] = bool(torch.equal(got[0], gatherer.bufs[(gatherer.t - 1) & 1]))
+        got, grew, gdone = gatherer.gathered_step()
+        k_last = (gatherer.t - 1) & 1
+        out["gather_check"] = bool(torch.equal(got[0], gatherer.bufs[k_last]) and torch.equal(grew[0], gatherer.packed[k_last][1])
+                                   and torch.equal(gdone[0], gatherer.packed[k_last][2].view(torch.bool)))
+        out["gathered"] = "obs + reward (f32) + done (u8): %d + 5 B per instance" % (got[0][0].numel() * got[0].element_size())
     env.close()
     del env, gatherer, peer
     torch.cuda.empty_cache()
@@ -610,7 +615,7 @@ def main():
                                    "actions generated on device%s" % (env_id, n_local, world, args.obs_format, gather_txt),
                        "env_id": env_id, "envs_per_gpu": n_local, "envs_total": r["n_total"],
                        "parallelism": "env-sharded x%d, no data-path collective" % world if not r["gather"] else
-                       "env-sharded x%d + %s(obs)->rank0" % (world, "peer-mapped stores" if r["gather"] == "peer" else "gather")},
+                       "env-sharded x%d + %s(obs + reward + done)->rank0" % (world, "peer-mapped stores / packed gather" if r["gather"] == "peer" else "gather")},
             "per_gpu_value": r["value"] / world, "timing": r["timing"], "wall_ms_per_step": r["wall_ms_per_step"],
             # five consecutive windows of K steps each right behind the timed one (this rank's share x N for N > 1): the spread a
             # K-step headline carries
@@ -620,6 +625,7 @@ def main():
             out["note"] = r["note"]
         if "gather_check" in r:
             out["gather_check"] = r["gather_check"]
+            out["gathered"] = r.get("gathered")
         if r["raster_launches"]:
             avg_ms = r["raster_avg_ms"]
             # Algorithmic bytes of the timed launch per instance-step.  Mortar family: the step's workgroups ride in front of the
@@ -671,7 +677,11 @@ def main():
                 q = run_workload("Endless-MortarMayhem-v0", 32768, 100, 20, args.settle, world, rank, dev, "u8_xyc", gm, not args.no_events, args.event_stride)
                 c5[label] = {"value": q["value"], "unit": "env steps/s", "per_gpu_value": q["value"] / world, "ms_per_step": q["ms_per_step"],
                              "timing": q["timing"], "wall_ms_per_step": q["wall_ms_per_step"],
-                             "raster_avg_ms_rank0": q["raster_avg_ms"], "note": q["note"]}
+                             "raster_avg_ms_rank0": q["raster_avg_ms"], "note": q["note"],
+                             # what rank 0 holds after a step of this leg ("obs (+reward, done)")
+                             "gathered": (None if gm is None else q.get("gathered") if q["gather"] == "rccl" else
+                                          "obs by peer-mapped stores + reward (f32) + done (u8) by one packed gather: 21168 + 5 B per instance"),
+                             "gather_check": q.get("gather_check")}
             except Exception as e:  # keep the headline line alive
                 c5[label] = "failed: %s" % (str(e)[:200],)
         if rank == 0:

@@ -8,7 +8,8 @@ The only (optional) exchange is BASELINE config 5's gather of observations/rewar
 single-learner rollout.  Two forms with the same result on rank 0:
 
     gather_to_rank0   a torch.distributed gather (RCCL send/recv): every rank writes its frames locally, then ships them;
-    ObsGatherer       the same collective, double-buffered: the gather of step t runs beside step t + 1;
+    ObsGatherer       the same collective, double-buffered: the gather of step t (frames, and the step's rewards / dones as
+                      one packed 5-B-per-instance tensor) runs beside step t + 1;
     PeerObsBuffer     rank 0's [N_total, ...] observation tensor is mapped into every rank (HIP IPC, peer access over
                       xGMI) and handed to VecMemoryGym as `obs_buffer`: the raster kernels store their frames straight
                       into rank 0's HBM -- no second copy, no collective on the data path (only a barrier per step).
@@ -49,57 +50,98 @@ def gather_to_rank0(tensor, dst=0, group=None):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
 
 
-class ObsGatherer:
-    """BASELINE config 5's optional exchange, double-buffered: the gather of step t's observations to rank `dst` runs BESIDE
-    step t + 1 (hard part 6).
+def packed_scalars(n, device):
+    """The 5 B / instance that travel with a step's frames ("gather of obs (+reward, done)"): ONE flat
+    uint8 tensor of 4 n + n bytes (padded to 16) and two views of it -- `reward` float32 [n] over the first 4 n bytes, `done`
+    uint8 [n] behind it.  The step kernels store into the views (VecMemoryGym.use_step_buffers), one collective ships the flat
+    tensor.  Returns (flat, reward, done)."""
+    n = int(n)
+    flat = torch.zeros((5 * n + 15) // 16 * 16, dtype=torch.uint8, device=device)
+    return flat, flat[:4 * n].view(torch.float32), flat[4 * n:5 * n]
 
-    The environment alternates between two observation buffers (VecMemoryGym.use_obs_buffer); after step t has been
-    enqueued, the gather of its buffer is issued as an asynchronous collective (RCCL runs it on its own stream, ordered
-    behind the step's kernels), and only the step that is about to OVERWRITE that buffer -- step t + 2 -- waits for it.
-    Rank dst keeps two sets of receive buffers as well; `gathered(t)` joins the gather of step t and returns its W per-rank
-    tensors (rank dst; None elsewhere).  Shards must be equal-sized (N_total % W == 0, what the bench uses).
+
+def unpack_scalars(flat, n):
+    """(reward float32 [n], done bool [n]) views of a flat tensor laid out by packed_scalars()."""
+    n = int(n)
+    return flat[:4 * n].view(torch.float32), flat[4 * n:5 * n].view(torch.bool)
+
+
+class ObsGatherer:
+    """BASELINE config 5's optional exchange, double-buffered: the gather of step t's observations AND of its rewards / dones
+    (5 B per instance, one small collective behind the frames') to rank `dst` runs BESIDE step t + 1 (hard
+    part 6; section 8e: "gather obs (+ reward/done, 5 B/env) to rank 0").
+
+    The environment alternates between two observation buffers (VecMemoryGym.use_obs_buffer) and two packed reward / done
+    buffers (use_step_buffers); after step t has been
+    enqueued, the gather of its buffers is issued as asynchronous collectives (RCCL runs them on its own stream, ordered
+    behind the step's kernels), and only the step that is about to OVERWRITE those buffers -- step t + 2 -- waits for them.
+    Rank dst keeps two sets of receive buffers as well; `gathered()` joins the gather of the latest step and returns its W
+    per-rank observation tensors, `gathered_step()` those plus the W reward and done tensors (rank dst; None elsewhere).
+    Shards must be equal-sized (N_total % W == 0, what the bench uses).
 
         g = ObsGatherer(env)                 # env: VecMemoryGym, after reset()
         for t in range(T):
             obs, rew, done, _, info = g.step(actions[t])      # gather of step t starts, step t - 1's may still run
-            frames = g.gathered()            # rank dst: list of W tensors of the LATEST step (joins it); else None
+            frames, rewards, dones = g.gathered_step()        # rank dst: three lists of W tensors of the LATEST step; else None
     """
 
-    def __init__(self, env, dst=0, group=None):
+    def __init__(self, env, dst=0, group=None, scalars=True):
         self.env, self.dst, self.group = env, dst, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.bufs = [env.obs, env.new_obs_buffer() if hasattr(env, "new_obs_buffer") else torch.empty_like(env.obs)]
         self.recv = [[torch.empty_like(env.obs) for _ in range(self.world)] for _ in range(2)] if self.rank == dst else [None, None]
         self.work = [None, None]
+        # reward + done: two packed buffers the step kernels store into, two sets of receive buffers on dst
+        self.scalars = bool(scalars) and hasattr(env, "use_step_buffers")
+        self.n = int(env.obs.shape[0])
+        if self.scalars:
+            self.packed = [packed_scalars(self.n, env.obs.device) for _ in range(2)]
+            self.recv_packed = ([[torch.empty_like(self.packed[0][0]) for _ in range(self.world)] for _ in range(2)]
+                                if self.rank == dst else [None, None])
+        self.work_packed = [None, None]
         self.t = 0
+
+    def _join(self, k):
+        for w in (self.work, self.work_packed):
+            if w[k] is not None:
+                w[k].wait()
+                w[k] = None
 
     def step(self, actions):
         k = self.t & 1
-        if self.work[k] is not None:  # the gather that still reads this buffer (step t - 2): the launch stream waits for it
-            self.work[k].wait()
-            self.work[k] = None
+        self._join(k)  # the gathers that still read these buffers (step t - 2): the launch stream waits for them
         self.env.use_obs_buffer(self.bufs[k])
+        if self.scalars:
+            self.env.use_step_buffers(self.packed[k][1], self.packed[k][2])
         out = self.env.step(actions)
         self.work[k] = dist.gather(self.bufs[k], self.recv[k], dst=self.dst, group=self.group, async_op=True)
+        if self.scalars:
+            self.work_packed[k] = dist.gather(self.packed[k][0], self.recv_packed[k], dst=self.dst, group=self.group, async_op=True)
         self.t += 1
         return out
 
     def gathered(self):
         """Join the gather of the latest step; rank dst gets its W per-rank observation tensors (valid until the step
         after next), the other ranks None."""
-        k = (self.t - 1) & 1
         if self.t == 0:
             return None
-        if self.work[k] is not None:
-            self.work[k].wait()
-            self.work[k] = None
+        k = (self.t - 1) & 1
+        self._join(k)
         return self.recv[k]
+
+    def gathered_step(self):
+        """Like gathered(), with the step's rewards and dones: rank dst gets (frames, rewards, dones), three lists of W per-rank
+        tensors (uint8 frames, float32 [n], bool [n]; valid until the step after next), the other ranks None."""
+        frames = self.gathered()
+        if frames is None or not self.scalars:
+            return None if frames is None else (frames, None, None)
+        k = (self.t - 1) & 1
+        pairs = [unpack_scalars(f, self.n) for f in self.recv_packed[k]]
+        return frames, [p[0] for p in pairs], [p[1] for p in pairs]
 
     def drain(self):
         for k in range(2):
-            if self.work[k] is not None:
-                self.work[k].wait()
-                self.work[k] = None
+            self._join(k)
 
 
 class PeerObsBuffer:
@@ -175,3 +217,30 @@ class PeerObsBuffer:
             dist.barrier(group=self.group)
         else:
             dist.all_reduce(self._token, group=self.group)
+
+    def bind_scalars(self, env):
+        """Route `env`'s step rewards and dones (5 B per instance) into a packed buffer that fence_with_scalars() ships to dst:
+        the frames travel as the raster kernels' own stores over xGMI, the scalars as ONE small collective that orders the
+        streams at the same time (it takes the place of fence()'s 4-byte all-reduce)."""
+        self.n_local = int(env.num_envs)
+        self._packed = packed_scalars(self.n_local, self.device)
+        env.use_step_buffers(self._packed[1], self._packed[2])
+        self._recv_packed = [torch.empty_like(self._packed[0]) for _ in range(self.world)] if self.rank == self.dst else None
+
+    def fence_with_scalars(self):
+        """After it returns on dst (stream-ordered on nccl), every rank's frames of the step are in `full` and dst holds every
+        rank's rewards and dones: returns (rewards, dones), two lists of W per-rank tensors, on dst; None elsewhere.  Equal-sized
+        shards (N_total % W == 0)."""
+        if dist.get_backend(self.group) != "nccl":  # (gloo gathers host tensors only: the two-process test on one GPU)
+            torch.cuda.synchronize(self.device)
+            host = [torch.empty(self._packed[0].shape, dtype=torch.uint8) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(self._packed[0].cpu(), host, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for d, h in zip(self._recv_packed, host):
+                    d.copy_(h)
+        else:
+            dist.gather(self._packed[0], self._recv_packed, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        pairs = [unpack_scalars(f, self.n_local) for f in self._recv_packed]
+        return [p[0] for p in pairs], [p[1] for p in pairs]

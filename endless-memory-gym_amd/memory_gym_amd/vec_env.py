@@ -392,6 +392,17 @@ class VecMemoryGym:
         self.obs = tensor
         self._swapped = True
 
+    def use_step_buffers(self, reward, done_u8):
+        """Make `reward` (float32 [N]) and `done_u8` (uint8 [N]) the tensors the NEXT step stores its rewards / dones into (mg_step
+        takes both per call) -- e.g. two views of one packed buffer that is shipped to another rank with the frames
+        (memory_gym_amd.dist.ObsGatherer: BASELINE config 5's "obs (+reward, done)")."""
+        for t, dt in ((reward, torch.float32), (done_u8, torch.uint8)):
+            if tuple(t.shape) != (self.num_envs,) or t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                raise ValueError("use_step_buffers: need contiguous float32 [N] / uint8 [N] tensors on the handle's device")
+        if reward.data_ptr() % 4:
+            raise ValueError("use_step_buffers: the reward tensor must be 4-byte aligned")
+        self.reward, self.done_u8 = reward, done_u8
+
     def _obs(self):
         if self.vector_obs is None:
             return self.obs

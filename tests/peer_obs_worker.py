@@ -22,18 +22,25 @@ def main():
     env = memory_gym_amd.make(env_id, num_envs=hi - lo, device=0, obs_buffer=buf.local)
     env.reset(seed=shard_seeds(n_total, rank, world, base_seed=0, device="cuda:0"))
     buf.fence()
+    buf.bind_scalars(env)  # the step's rewards / dones ride on the collective that orders the streams
     frames = [buf.full.clone()] if rank == 0 else None
+    rewards, dones = [], []
     g = torch.Generator(device="cuda").manual_seed(5)
     adim = env.action_dim
     for t in range(steps):
         a_all = torch.randint(0, 4 if adim == 1 else 3, (n_total,) if adim == 1 else (n_total, 2), device="cuda", generator=g, dtype=torch.int32)
         env.step(a_all[lo:hi].contiguous())
-        buf.fence()
+        got = buf.fence_with_scalars()
         if rank == 0:
             frames.append(buf.full.clone())
+            rewards.append(torch.cat(got[0]).clone())
+            dones.append(torch.cat(got[1]).clone())
+        else:
+            assert got is None
         dist.barrier()  # rank 0 has copied the step's frames before anyone overwrites them
     if rank == 0:
         torch.save(torch.stack(frames).cpu(), out)
+        torch.save((torch.stack(rewards).cpu(), torch.stack(dones).cpu()), out + ".scalars")
     env.close()
     dist.barrier()
     dist.destroy_process_group()

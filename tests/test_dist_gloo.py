@@ -76,21 +76,37 @@ def test_gather_world2_even_and_ragged(tmp_path):
         assert (d / "ok").exists()
 
 
+def _reward_for(lo, hi, t):
+    return torch.arange(lo, hi, dtype=torch.float32) * 0.125 + 0.1 * t
+
+
+def _done_for(lo, hi, t):
+    return ((torch.arange(lo, hi) + t) % 3 == 0).to(torch.uint8)
+
+
 class _FakeEnv:
-    """What ObsGatherer needs of a VecMemoryGym: `obs`, use_obs_buffer(), step() writing the frames of step t of this rank's
-    instances into the buffer in use."""
+    """What ObsGatherer needs of a VecMemoryGym: `obs`, use_obs_buffer(), use_step_buffers(), step() writing the frames, rewards
+    and dones of step t of this rank's instances into the buffers in use."""
 
     def __init__(self, lo, hi):
         self.lo, self.hi, self.t = lo, hi, 0
         self.obs = torch.zeros((hi - lo, 84, 84, 3), dtype=torch.uint8)
+        self.reward = torch.zeros(hi - lo, dtype=torch.float32)
+        self.done_u8 = torch.zeros(hi - lo, dtype=torch.uint8)
 
     def use_obs_buffer(self, t):
         self.obs = t
 
+    def use_step_buffers(self, reward, done_u8):
+        assert reward.dtype == torch.float32 and done_u8.dtype == torch.uint8 and reward.shape == done_u8.shape == (self.hi - self.lo,)
+        self.reward, self.done_u8 = reward, done_u8
+
     def step(self, actions):
         self.obs.copy_((_frames_for(self.lo, self.hi).to(torch.int64) + 3 * self.t + int(actions)).remainder(256).to(torch.uint8))
+        self.reward.copy_(_reward_for(self.lo, self.hi, self.t))
+        self.done_u8.copy_(_done_for(self.lo, self.hi, self.t))
         self.t += 1
-        return self.obs, None, None, None, {}
+        return self.obs, self.reward, self.done_u8.view(torch.bool), None, {}
 
 
 def _gatherer_worker(rank, world, port, n_total, out_dir):
@@ -103,17 +119,25 @@ def _gatherer_worker(rank, world, port, n_total, out_dir):
     g = m.ObsGatherer(env)
     assert g.bufs[0] is not g.bufs[1]
     for t in range(7):
-        obs, *_ = g.step(t % 3)
+        obs, rew, done, *_ = g.step(t % 3)
         assert obs is g.bufs[t & 1]  # the environment alternates between the two buffers
+        assert rew.data_ptr() == g.packed[t & 1][1].data_ptr() and done.data_ptr() == g.packed[t & 1][2].data_ptr()  # ... and the two packed reward / done buffers
+        assert torch.equal(rew, _reward_for(lo, hi, t)) and torch.equal(done, _done_for(lo, hi, t).bool())
         if t >= 1:  # step t - 1's frames are still intact in the other buffer while their gather may be running
             want_prev = (_frames_for(lo, hi).to(torch.int64) + 3 * (t - 1) + (t - 1) % 3).remainder(256).to(torch.uint8)
             assert torch.equal(g.bufs[(t - 1) & 1], want_prev)
+            assert torch.equal(g.packed[(t - 1) & 1][1], _reward_for(lo, hi, t - 1))
         if t % 2 == 0 or t == 6:  # join only some steps: the others are overtaken by the wait inside step t + 2
-            got = g.gathered()
+            got = g.gathered_step()
             if rank == 0:
-                full = torch.cat(got, 0)
+                frames, rewards, dones = got
+                full = torch.cat(frames, 0)
                 want = (_frames_for(0, n_total).to(torch.int64) + 3 * t + t % 3).remainder(256).to(torch.uint8)
                 assert torch.equal(full, want), "gathered frames of step %d differ" % t
+                # "gather of obs (+reward, done)"
+                assert torch.equal(torch.cat(rewards), _reward_for(0, n_total, t)), "gathered rewards of step %d differ" % t
+                assert dones[0].dtype == torch.bool and torch.equal(torch.cat(dones), _done_for(0, n_total, t).bool()), "gathered dones of step %d differ" % t
+                assert g.gathered() is frames
             else:
                 assert got is None
     g.drain()
@@ -124,8 +148,22 @@ def _gatherer_worker(rank, world, port, n_total, out_dir):
 
 
 def test_double_buffered_gatherer_world2(tmp_path):
-    mp.spawn(_gatherer_worker, args=(2, _free_port(), 8, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok").exists()
+    for n_total in (8, 6):  # (6: 3 instances per rank -- the packed reward / done tensor is padded to 16 bytes)
+        d = tmp_path / ("n%d" % n_total)
+        d.mkdir()
+        mp.spawn(_gatherer_worker, args=(2, _free_port(), n_total, str(d)), nprocs=2, join=True)
+        assert (d / "ok").exists()
+
+
+def test_packed_scalars_layout():
+    m = _load_dist_module()
+    for n in (1, 3, 16, 1000):
+        flat, rew, done = m.packed_scalars(n, "cpu")
+        assert flat.numel() % 16 == 0 and flat.numel() >= 5 * n and rew.shape == (n,) and done.shape == (n,)
+        rew.copy_(torch.arange(n, dtype=torch.float32) + 0.5)
+        done.copy_((torch.arange(n) % 2).to(torch.uint8))
+        r2, d2 = m.unpack_scalars(flat.clone(), n)
+        assert torch.equal(r2, rew) and d2.dtype == torch.bool and torch.equal(d2, done.bool())
 
 
 def test_bench_self_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):

@@ -31,9 +31,16 @@ def test_two_ranks_write_into_rank0_memory(env_id, tmp_path):
     env = memory_gym_amd.make(env_id, num_envs=n_total, device=0)
     obs, _ = env.reset(seed=0)
     want = [obs.cpu().clone()]
+    want_r, want_d = [], []
     g = torch.Generator(device="cuda").manual_seed(5)
     for t in range(steps):
         a = torch.randint(0, 4 if env.action_dim == 1 else 3, (n_total,) if env.action_dim == 1 else (n_total, 2), device="cuda", generator=g, dtype=torch.int32)
-        want.append(env.step(a)[0].cpu().clone())
+        o, r, d, _, _ = env.step(a)
+        want.append(o.cpu().clone())
+        want_r.append(r.cpu().clone())
+        want_d.append(d.cpu().clone())
     env.close()
     assert torch.equal(got, torch.stack(want))
+    # rank 0 also holds every rank's rewards and dones of each step ("obs (+reward, done)")
+    got_r, got_d = torch.load(out + ".scalars")
+    assert torch.equal(got_r, torch.stack(want_r)) and got_d.dtype == torch.bool and torch.equal(got_d, torch.stack(want_d))

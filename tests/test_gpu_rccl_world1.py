@@ -44,10 +44,12 @@ for t in range(40):
     o, r, d, _, _ = gat.step(a)
     o2, r2, d2, _, _ = ref.step(a)
     want = o2.clone()
-    got = gat.gathered()
+    got, grew, gdone = gat.gathered_step()
     torch.cuda.synchronize()
     assert len(got) == 1 and torch.equal(got[0], want), "gathered frames of step %%d differ" %% t
     assert torch.equal(r, r2) and torch.equal(d, d2)
+    # the step's rewards and dones travel with the frames (BASELINE.md section 3, C5; one packed 5-B-per-instance collective)
+    assert torch.equal(grew[0], r2) and gdone[0].dtype == torch.bool and torch.equal(gdone[0], d2), "gathered rewards / dones of step %%d differ" %% t
     if prev is not None:  # the other buffer still holds step t - 1's frames: the step did not write into it
         assert torch.equal(gat.bufs[(t - 1) & 1], prev)
     prev = want
