@@ -561,6 +561,8 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-instance C1 leg")
+    ap.add_argument("--config5-envs", type=int, default=32768, help="instances per GPU of the config-5 legs of an N > 1 run (BASELINE: 32,768)")
+    ap.add_argument("--config5-steps", type=int, default=100)
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every N-th step with HIP events (each bracketed step costs ~15 us)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only for plumbing tests with all ranks on one GPU)")
@@ -674,7 +676,7 @@ def main():
         c5 = {}
         for label, gm in (("no_gather", None), ("gather_rccl", "rccl"), ("gather_peer", "peer")):
             try:
-                q = run_workload("Endless-MortarMayhem-v0", 32768, 100, 20, args.settle, world, rank, dev, "u8_xyc", gm, not args.no_events, args.event_stride)
+                q = run_workload("Endless-MortarMayhem-v0", args.config5_envs, args.config5_steps, 20, args.settle, world, rank, dev, "u8_xyc", gm, not args.no_events, args.event_stride)
                 c5[label] = {"value": q["value"], "unit": "env steps/s", "per_gpu_value": q["value"] / world, "ms_per_step": q["ms_per_step"],
                              "timing": q["timing"], "wall_ms_per_step": q["wall_ms_per_step"],
                              "raster_avg_ms_rank0": q["raster_avg_ms"], "note": q["note"],
@@ -685,7 +687,7 @@ def main():
             except Exception as e:  # keep the headline line alive
                 c5[label] = "failed: %s" % (str(e)[:200],)
         if rank == 0:
-            out["config5"] = {"workload": "Endless-MortarMayhem-v0, 32768 envs/GPU x %d GPU (%d envs)" % (world, 32768 * world), **c5}
+            out["config5"] = {"workload": "Endless-MortarMayhem-v0, %d envs/GPU x %d GPU (%d envs)" % (args.config5_envs, world, args.config5_envs * world), **c5}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

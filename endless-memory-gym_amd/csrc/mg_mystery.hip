@@ -32,6 +32,12 @@ constexpr int MAX_SEG = 128;
 constexpr int MAX_FALL = 128;
 constexpr int ST_CROSS = 8;
 constexpr int TILE = SCREEN / G;   // 12 px
+// Endless: AUX_WORDS words per instance.  The first 128-byte line holds what a step may need besides the state and segment records,
+// so that ONE batch of loads fetches it (emp_step_b): words 0..19 the EMP_PRE record (0..12 the segment record, SEG_STRIDE bytes; 13
+// the stream's buffered half; 14 = has_buffered | end_y << 8; 16..19 the stream's 128-bit state behind the segment's draws, low word
+// first), words 20..31 the first twelve fall-off keys; the list goes on behind them (MAX_FALL keys: x | y << 16, y biased by 1024).
+constexpr int AUX_FALL = 20, AUX_WORDS = 160;
+static_assert(AUX_FALL + MAX_FALL <= AUX_WORDS && AUX_WORDS % 32 == 0, "the fall-off list must fit behind the record");
 constexpr int STAMINA_W = 4;      // int(16 * SCALE)
 
 struct MysteryParams {
@@ -43,6 +49,7 @@ struct MysteryParams {
     int lazy;           // Endless: a reset generates ONE of its three initial segments, the other two are owed (see EMP_OWED)
     int path_help;      // frame workgroups help with long path queues (MEMGYM_PATH_HELP=0: the 128 dedicated workgroups alone, round 2)
     int bg_coop;        // Endless, fused launch: owed segments as queue entries of the service waves (small launches), not one per lane of frame workgroups
+    int pre;            // Endless, lazy: the NEXT episode's first segment is generated ahead of time as a background job (see EMP_PRE)
     OptList cardinal;
     double r_goal, r_fall, r_progress, r_dense, r_step;
 };
@@ -63,6 +70,8 @@ struct __attribute__((aligned(16))) MysteryCore {
     uint8_t bg;           // endless: -bg_scroll, the scrolling background's phase in pixels (< tile)
 };
 static_assert(sizeof(MysteryCore) == 96, "MysteryCore must be 96 bytes");
+#define EMP_OWED(s) ((s).path_len)  // endless: segments the instance is owed ("lazy initial segments" below)
+#define EMP_PRE(s) ((s).ex)         // endless: io.aux[i] holds the next episode's first segment (ex / ey: the finite variants' goal)
 // The whole record as six 16-byte loads issued together.  Field by field the compiler split it into eleven odd-sized loads
 // and issued three of them only after the first uses: a second memory round trip (3-4 us on a cold state array) at the head
 // of the one-lane-per-instance step kernel (profiles/r03_emp.md, section 7).
@@ -209,24 +218,26 @@ __global__ __launch_bounds__(256) void mystery_gt64_kernel(int n, const MysteryC
 struct MysteryIO {
     MysteryCore* core;
     uint8_t* segs;      // endless: [N][MAX_SEG][SEG_STRIDE]; node byte = x_rel | y<<3 | rvis<<6 | svis<<7
-    uint32_t* falloff;  // endless: [N][MAX_FALL]  (x | y<<16, y biased by 1024)
     RngSoA rng;
     MysteryDesc* desc;
     int* err;
     int* queue;  // endless: instances waiting for a reset, filled by the step / enqueue kernels, drained by emp_serve_kernel
     uint64_t* walls;  // finite: [N] wall cells of the current path generation (bit x*7+y), read by the debug view only
     int* qctr;   // QC_COUNT entries, QC_HEAD pops beyond the static first round, QC_LEFT workgroups that left emp_serve_kernel
-    int* bgq;    // endless: instances that are owed a segment nobody waits for yet (QC_BG_COUNT entries; lane-per-path service)
+    int* bgq;    // endless, bg_coop: instances that are owed a segment nobody waits for yet (QC_BG_COUNT entries, popped by the service waves)
+    uint8_t* bgflag;  // endless, larger launches: [N] 1 = the instance has a background job in this step's raster launch (lane-per-path service)
+    uint32_t* aux;  // endless: [N][AUX_WORDS] the next episode's first segment, generated ahead of time (EMP_PRE), and the fall-off list
     const uint4* jump;  // [64][2] PCG64 jump constants {A^(k+1), S_(k+1)} (WaveRng)
     // telemetry of the finite variants' path generation inside the step's launches (bench.py: C3's measured reset share):
     // [0] wave-ticks (real-time clock, 10 ns) spent generating paths, [1] paths generated; mg_debug_counter "path_gen_ticks" / "path_gen_paths"
+    // endless: [2] resets a step did itself from a record generated ahead of time (counted by the lab build only), [3] such records generated
     unsigned long long* stats;
     // per-instance option sets (mg_set_option_set / mg_bind_option_sets): instance i runs under sets[set_of[i]]; both NULL while the
     // handle has one set.  Read by the <PS = true> forms of the reset / step / queue-server kernels only.
     const struct MysteryParams* sets;
     const int32_t* set_of;
 };
-constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_BG_COUNT = 96, QC_BG_LEFT = 128, QC_WORDS = 160;  // one 128-byte line each
+constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_BG_COUNT = 96, QC_WORDS = 160;  // one 128-byte line each
 // MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
 // the fused launch, drawn by the workgroup that served it).  Only emp_raster_serve_kernel's frame workgroups tell 1 from 2 / 3.
 constexpr uint8_t DESC_QUEUED = 2, DESC_SERVED = 3;
@@ -767,6 +778,7 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
             g = bg;
             s.have_start = 1;
             s.end_y = (int8_t)ey;
+            EMP_PRE(s) = 0;  // the stream has moved: a record generated ahead of time no longer continues it
             if (s.num_seg >= MAX_SEG) raise_error(io.err, 4);
             else s.num_seg++;
             todo_n--;
@@ -869,7 +881,17 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
 // and discarded, before the new episode's first), and every look at the state (Family::sync_state: checkpoints, RNG words,
 // the debug view).  The instance's random numbers are consumed in exactly the reference's order; nothing else draws from
 // the stream of an Endless Mystery Path instance.
-#define EMP_OWED(s) ((s).path_len)
+// ---- the next episode's first segment, ahead of time (round 5) ------------------------------------------------------------
+// With lazy resets a step's queue still held one entry per finishing instance (~1,200 of 32,768 per step under random
+// actions): one path of the wave-cooperative generator each, ~30 us of a wave's time and the reason the fused launch needs ~200
+// registers per lane.  But nothing draws from an Endless-MysteryPath instance's stream except its segments, so once an episode's
+// segments exist the stream stands exactly where the NEXT reset will find it -- unless the agent reaches the last-but-one segment
+// first and a new one is appended.  P.pre: an instance that is owed nothing and has no such record generates the next episode's
+// first segment as one more background job (lane-per-path generator, beside the frames, from a COPY of its stream) into
+// io.aux[i], with the stream as it stands behind it; EMP_PRE(s) says the record is there.  A step that ends the episode then
+// resets the instance itself (emp_step_b<true>): the record becomes segment 0, the instance's stream becomes the record's, two
+// segments are owed -- the same draws in the same order as the reference's reset, and no queue entry.  Whatever advances
+// the stream first (a due segment, any other reset path) clears the flag; the record is never looked at without it.
 
 // EndlessMysteryPathEnv.reset (endless_mystery_path.py:195-280) around the three initial segments (serve_emp)
 __device__ __forceinline__ void emp_pre_reset(MysteryCore& s) {
@@ -878,12 +900,13 @@ __device__ __forceinline__ void emp_pre_reset(MysteryCore& s) {
     s.ep_len = 0;
     s.num_seg = 0;
     s.have_start = 0;
+    EMP_PRE(s) = 0;
 }
-__device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, MysteryDesc& d, float* gt) {
-    uint8_t* s0 = seg_ptr(io, i, 0);
-    s0[1] |= 1u << 6;  // the first node of the path shall not yield any reward
-    s.sx = (uint8_t)node_x(0, s0[1]);
-    s.sy = (uint8_t)node_y(s0[1]);
+// everything of the reset behind the segments except the frame descriptor; R: segment 0's record, its first node flagged
+__device__ __forceinline__ void emp_post_reset_state(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, float* gt, SegRec& R) {
+    const uint8_t b1 = R.byte(1);
+    s.sx = (uint8_t)node_x(0, b1);
+    s.sy = (uint8_t)node_y(b1);
     s.camera_x = P.camera_offset;
     s.bg = 0;
     s.ax = (int16_t)(s.sx * P.tile + P.agent_radius);
@@ -891,8 +914,6 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
     s.rot8 = 6;  // 270 degrees
     s.cur_node_seg = 0;
     s.cur_node_idx = 0;
-    SegRec R;
-    R.seg = -1;
     emp_direction(io, i, s, gt, R);
     s.off = 0;
     s.cross_on = 0;
@@ -905,6 +926,14 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
     s.stamina = P.stamina_level;
     s.max_x = 0;
     s.tiles_visited = 0;
+}
+__device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, MysteryDesc& d, float* gt) {
+    SegRec R;
+    R.seg = -1;
+    R.load(io, i, 0);
+    R.w[0] |= 0x4000u;  // the first node of the path shall not yield any reward (bit 6 of byte 1)
+    *reinterpret_cast<uint32_t*>(seg_ptr(io, i, 0)) = R.w[0];
+    emp_post_reset_state(P, io, i, s, gt, R);
     SegRec none;
     none.seg = -1;
     emp_fill_desc(P, io, i, s, d, s.ax / P.tile, R, none);
@@ -954,9 +983,16 @@ static __device__ unsigned long long g_lab_step_clock[12 * 4096];
 #define LAB_STEP_CLOCK(slot) do { } while (0)
 #endif
 
-// second part; returns true if the instance finished and is to be reset in this call
+// second part; returns true if the instance finished and is to be reset in this call by somebody else (a queue entry).
+// OWN_RESET (emp_step_kernel): an instance whose next episode's first segment exists already (EMP_PRE) is reset right here, and
+// everything the step can need from memory -- the segment records AND the instance's aux line (that record, the head of the
+// fall-off list) -- is requested in ONE batch: the kernel is a chain of dependent memory round trips on 512 waves (~2 us each on a
+// memory system the observation stream has just swept; rounds 3-4: records, then the fall-off list, then the stamina flags'
+// records, then the queue's counter), not a matter of bytes (profiles/r03_emp.md section 7, r05_emp.md).
+template <bool OWN_RESET>
 __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
                            uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
+    typedef uint32_t q4 __attribute__((ext_vector_type(4)));
     double reward = 0.0;
     bool done = false;
     const int seg = s.cur_seg;
@@ -970,28 +1006,51 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     // and waited for it before the two records were even requested)
     const int nxt_seg = seg + 1 < s.num_seg ? seg + 1 : -1;
     const int nxt_safe = nxt_seg >= 0 ? nxt_seg : 0;
-    const uint32_t nxt_w0 = *reinterpret_cast<const uint32_t*>(seg_ptr(io, i, nxt_safe));
-    if (seg >= 1 && seg - 1 < s.num_seg) Rprev.load(io, i, seg - 1);
+    uint32_t* const aux = io.aux + (size_t)i * AUX_WORDS;
+    uint32_t nxt_w0 = *reinterpret_cast<const uint32_t*>(seg_ptr(io, i, nxt_safe));
+    // (both records unconditionally too, from clamped indices -- segment 0's slot always exists: behind a branch the compiler waits
+    // for a load where the branches join, i.e. before the next request is issued)
+    const bool have_prev = seg >= 1 && seg - 1 < s.num_seg, have_cur = seg >= 0 && seg < s.num_seg;
+    Rprev.load(io, i, have_prev ? seg - 1 : 0);
+    R.load(io, i, have_cur ? seg : 0);
+    Rprev.seg = have_prev ? seg - 1 : -1;
+    R.seg = have_cur ? seg : -1;
+    q4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, f0 = a0, f1 = a0, f2 = a0;
+    if (OWN_RESET) {
+        const q4* aq = reinterpret_cast<const q4*>(aux);
+        a0 = aq[0]; a1 = aq[1]; a2 = aq[2]; a3 = aq[3]; a4 = aq[4];  // the record generated ahead of time
+        f0 = aq[5]; f1 = aq[6]; f2 = aq[7];                          // fall-off keys 0..11
+        asm volatile("" : "+v"(f2));  // (a use the compiler cannot move: every request above is issued before the first wait)
+    }
+    asm volatile("" : "+v"(nxt_w0));
+    LAB_STEP_CLOCK(5);
     bool on_path = false;
     if (seg < s.num_seg) {
         uint8_t* sp = seg_ptr(io, i, seg);
-        R.load(io, i, seg);
-        LAB_STEP_CLOCK(5);
         const uint32_t* w = R.w;
         const int n = (int)(w[0] & 0xFFu);
         const int dx = nx - seg * (G + 1);
         const bool addressable = (unsigned)dx < 8u && (unsigned)ny < 8u;  // node bytes hold x_rel and y in 3 bits each
         const uint32_t target = (uint32_t)(dx & 7) | ((uint32_t)(ny & 7) << 3);
+        // first node (list order) on the agent's tile, four node bytes per word at once (round 5; byte by byte the search was
+        // 2.7 us of every wave's 17): a byte's low six bits equal the target iff they XOR to zero, and in (x - 0x01..) & ~x &
+        // 0x80.. the LOWEST flag marks the lowest zero byte exactly.  Bytes behind the list are zero and can only match behind
+        // every real node: a first match beyond the node count means there is none.
         int hit = 0;
         uint32_t hb = 0;
+        const uint32_t t4 = target * 0x01010101u;
 #pragma unroll
-        for (int p = 1; p < SEG_STRIDE; ++p) {  // first node (list order) on the agent's tile
-            const uint32_t b = (w[p >> 2] >> (8 * (p & 3))) & 0xFFu;
-            if (hit == 0 && p <= n && addressable && (b & 0x3Fu) == target) {
-                hit = p;
-                hb = b;
+        for (int j = SEG_STRIDE / 4 - 1; j >= 0; --j) {  // (downwards: the lowest word with a match is taken last)
+            uint32_t x = (w[j] & 0x3F3F3F3Fu) ^ t4;
+            if (j == 0) x |= 0xFFu;  // byte 0 is the node count
+            const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
+            if (z) {
+                const int k = (__ffs((int)z) - 1) >> 3;
+                hit = 4 * j + k;
+                hb = (w[j] >> (8 * k)) & 0xFFu;
             }
         }
+        if (!(addressable && hit >= 1 && hit <= n)) hit = 0;
         if (hit) {
             uint8_t b = (uint8_t)hb;
             on_path = true;
@@ -1022,13 +1081,20 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
         if (nx < s.max_x) {
             done = true;
         } else {
-            uint32_t* fl = io.falloff + (size_t)i * MAX_FALL;
+            uint32_t* fl = aux + AUX_FALL;
             uint32_t key = (uint32_t)(nx & 0xFFFF) | ((uint32_t)(ny + 1024) << 16);
+            const int nf = s.n_falloff;
             bool found = false;
-            for (int k = 0; k < s.n_falloff; k += 4) {  // four entries per load; slots >= n_falloff hold stale keys
+            int k0 = 0;
+            if (OWN_RESET) {  // the first twelve keys came with the batch above; slots >= n_falloff hold stale keys
+                found = (0 < nf && f0.x == key) || (1 < nf && f0.y == key) || (2 < nf && f0.z == key) || (3 < nf && f0.w == key) ||
+                        (4 < nf && f1.x == key) || (5 < nf && f1.y == key) || (6 < nf && f1.z == key) || (7 < nf && f1.w == key) ||
+                        (8 < nf && f2.x == key) || (9 < nf && f2.y == key) || (10 < nf && f2.z == key) || (11 < nf && f2.w == key);
+                k0 = 12;
+            }
+            for (int k = k0; k < nf; k += 4) {  // four entries per load
                 const uint4 v = reinterpret_cast<const uint4*>(fl)[k >> 2];
-                found = found || v.x == key || (k + 1 < s.n_falloff && v.y == key) || (k + 2 < s.n_falloff && v.z == key) ||
-                        (k + 3 < s.n_falloff && v.w == key);
+                found = found || v.x == key || (k + 1 < nf && v.y == key) || (k + 2 < nf && v.z == key) || (k + 3 < nf && v.w == key);
             }
             if (found) done = true;
             if (!found) {
@@ -1037,12 +1103,21 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
             }
         }
         // reset all stamina flags -- only segments visited since the last reset can hold any; whole records at a time
-        // (bytes past the node count are unused)
+        // (bytes past the node count are unused).  The agent's segment and the one before it are in registers already, as they
+        // are in memory (no node was flagged in this step: the agent is not on the path).
         for (int q = s.gx; q <= (int)s.gy && q < s.num_seg; ++q) {
             uint32_t* wp = reinterpret_cast<uint32_t*>(seg_ptr(io, i, q));
             uint32_t w[SEG_STRIDE / 4];
+            if (q == R.seg) {
 #pragma unroll
-            for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = wp[j];
+                for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = R.w[j];
+            } else if (q == Rprev.seg) {
+#pragma unroll
+                for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = Rprev.w[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < SEG_STRIDE / 4; ++j) w[j] = wp[j];
+            }
             wp[0] = w[0] & 0x7F7F7FFFu;  // byte 0 is the node count
 #pragma unroll
             for (int j = 1; j < SEG_STRIDE / 4; ++j) wp[j] = w[j] & 0x7F7F7F7Fu;
@@ -1078,8 +1153,39 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
     LAB_STEP_CLOCK(9);
-    if (done && autoreset) return true;
+    bool fresh = false;
+    if (done && autoreset) {
+        if (!(OWN_RESET && P.lazy && EMP_PRE(s) && EMP_OWED(s) == 0)) return true;
+        // EndlessMysteryPathEnv.reset (endless_mystery_path.py:195-280) with the first segment taken from the record that was
+        // generated ahead of time; the stream continues behind that segment's draws, the other two segments are owed
+        emp_pre_reset(s);
+        R.w[0] = a0.x | 0x4000u;  // the first node of the path shall not yield any reward
+        R.w[1] = a0.y; R.w[2] = a0.z; R.w[3] = a0.w;
+        R.w[4] = a1.x; R.w[5] = a1.y; R.w[6] = a1.z; R.w[7] = a1.w;
+        R.w[8] = a2.x; R.w[9] = a2.y; R.w[10] = a2.z; R.w[11] = a2.w;
+        R.w[12] = a3.x;
+        R.seg = 0;
+        Rprev.seg = -1;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(seg_ptr(io, i, 0));
+#pragma unroll
+        for (int j = 0; j < SEG_STRIDE / 4; ++j) dst[j] = R.w[j];
+        io.rng.s_lo[i] = (uint64_t)a4.x | ((uint64_t)a4.y << 32);
+        io.rng.s_hi[i] = (uint64_t)a4.z | ((uint64_t)a4.w << 32);
+        io.rng.buf[i] = (uint64_t)a3.y | ((uint64_t)(a3.z & 1u) << 32);
+        s.num_seg = 1;
+        s.have_start = 1;
+        s.end_y = (int8_t)((a3.z >> 8) & 0xFFu);
+        EMP_OWED(s) = 2;
+        if (LAB_BUILD && io.stats) atomicAdd(io.stats + 2, 1ull);  // mg_debug_counter "emp_own_resets" (lab build: tests)
+        emp_post_reset_state(P, io, i, s, gt, R);
+        nx = s.ax / P.tile;
+        fresh = true;
+    }
     emp_fill_desc(P, io, i, s, d, nx, R, Rprev);
+    if (fresh) {
+        d.cross_on = 0;
+        if (P.show_stamina) d.stamina_red = 0;
+    }
     LAB_STEP_CLOCK(10);
     return false;
 }
@@ -1264,6 +1370,8 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P0.n) return;
+    // (fewer instance-carrying lanes per wave -- 32 / 16 / 8, as the finite variants' kernel has them -- measured slower: 34-40 us
+    // against 25-29, profiles/r05_emp.md)
     const MysteryParams& P = PS ? io.sets[set_index(io.set_of, i)] : P0;  // (PS: per-instance option sets)
     LAB_STEP_CLOCK(0);
     int act = actions[i];  // requested together with the state record ...
@@ -1272,24 +1380,35 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
     int nx = 0, ny = 0;
     const int due = emp_step_a(P, i, s, act, nx, ny);
     LAB_STEP_CLOCK(1);
-    if (due) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
-        io.core[i] = s;
-        queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
-        io.desc[i].valid = DESC_QUEUED;  // (the rest of the descriptor is last step's)
-        return;
-    }
     MysteryDesc d;
-    const bool q = emp_step_b(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
-    LAB_STEP_CLOCK(2);
-    if (q) {
-        queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
-        d.valid = DESC_QUEUED;
-    } else if (P.lazy && EMP_OWED(s) > 0) {  // one owed segment per step, as a job nobody waits for
-        queue_push(io.bgq, &io.qctr[QC_BG_COUNT], P.n, i, io.err);
+    bool q = false, bg = false;
+    if (due) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
+        queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
+    } else {
+        q = emp_step_b<!PS>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+        LAB_STEP_CLOCK(2);
+        if (q) {
+            queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
+            d.valid = DESC_QUEUED;
+        } else {
+            // one owed segment per step -- or, when nothing is owed, the next episode's first (EMP_PRE) -- as a job nobody waits for
+            bg = P.lazy && (EMP_OWED(s) > 0 || (P.pre && !EMP_PRE(s)));
+        }
     }
     LAB_STEP_CLOCK(3);
     io.core[i] = s;
-    io.desc[i] = d;
+    if (due) io.desc[i].valid = DESC_QUEUED;  // (the rest of the descriptor is last step's)
+    else io.desc[i] = d;
+    // Background jobs.  Small launches (bg_coop): entries of a queue the service waves pop behind the step's own entries.  The others:
+    // a FLAG per instance, collected by the background workgroups of the raster launch (round 5; rounds 3-4 pushed there too -- one more
+    // atomic on a counter all 512 waves share, ~1.5 us in every wave's path).
+    if (P.lazy) {
+        if (P.bg_coop) {
+            if (bg) queue_push(io.bgq, &io.qctr[QC_BG_COUNT], P.n, i, io.err);
+        } else {
+            io.bgflag[i] = bg ? 1 : 0;
+        }
+    }
     LAB_STEP_CLOCK(4);
 }
 
@@ -1341,8 +1460,8 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
             return;
         }
         if (me)
-            reset_me = emp_step_b(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
-                                  gti, info, autoreset, d) ? 1 : 0;
+            reset_me = emp_step_b<false>(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
+                                         gti, info, autoreset, d) ? 1 : 0;
         reset_me = bcast(reset_me, 0);
     }
     if (reset_me) {
@@ -1504,9 +1623,10 @@ __device__ int lane_path(Pcg& g, const LaneWS& W, int sx, int sy, int ex, int ey
     }
 }
 
-// EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604) by one lane
-__device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, MysteryCore& s, Pcg& g) {
-    const int sy = s.have_start ? (int)s.end_y : g.integers(0, G);
+// EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604) by one lane: the draws and the path; the record goes to dst
+// (13 dwords: byte 0 = node count, then the path START first, then the transition node, see serve_emp).  Returns the end row.
+__device__ int lane_segment_record(const MysteryIO& io, const LaneWS& W, bool have_start, int end_y, Pcg& g, uint32_t* dst) {
+    const int sy = have_start ? end_y : g.integers(0, G);
     const int ey = g.integers(0, G);
     uint64_t pm = 0, wl = 0;
     int len = lane_path(g, W, 0, sy, G - 1, ey, pm, wl);
@@ -1514,8 +1634,7 @@ __device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, Myster
         raise_error(io.err, 2);
         len = 0;
     }
-    if (s.num_seg < MAX_SEG) {  // byte 0 = node count, then the path START first, then the transition node (see serve_emp)
-        uint32_t* dst = reinterpret_cast<uint32_t*>(seg_ptr(io, i, s.num_seg));
+    if (dst) {
         for (int j = 0; j < SEG_STRIDE / 4; ++j) {
             uint32_t word = 0;
 #pragma unroll
@@ -1531,12 +1650,17 @@ __device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, Myster
             }
             dst[j] = word;
         }
-        s.num_seg++;
-    } else {
-        raise_error(io.err, 4);
     }
+    return ey;
+}
+__device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, MysteryCore& s, Pcg& g) {
+    const bool room = s.num_seg < MAX_SEG;
+    const int ey = lane_segment_record(io, W, s.have_start != 0, (int)s.end_y, g, room ? reinterpret_cast<uint32_t*>(seg_ptr(io, i, s.num_seg)) : nullptr);
+    if (room) s.num_seg++;
+    else raise_error(io.err, 4);
     s.have_start = 1;
     s.end_y = (int8_t)ey;
+    EMP_PRE(s) = 0;  // the stream has moved: a record generated ahead of time no longer continues it
 }
 
 // The queued resets of a deferred step are served INSIDE the raster launch: its first PATH_WGS workgroups do not draw frames
@@ -1663,14 +1787,41 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
     }
 }
 
-// One background job by one lane: the instance's next owed segment (lazy initial segments, EMP_OWED)
-__device__ __forceinline__ void lane_owed_segment(const MysteryIO& io, const LaneWS& W, int i, int how_many) {
+// One background job by one lane: the instance's next owed segment (lazy initial segments, EMP_OWED) -- or, ahead = true and
+// nothing owed, the NEXT episode's first segment from a copy of the stream (EMP_PRE).  (One call site of the generator for both:
+// with two the compiler turns it into a real function call, 1,300 B of stack per lane in the fused launch.)
+__device__ __forceinline__ void lane_owed_segment(const MysteryIO& io, const LaneWS& W, int i, int how_many, bool ahead = false) {
     MysteryCore s = io.core[i];
     int owed = EMP_OWED(s);
-    if (owed <= 0) return;
+    const bool pre_job = owed <= 0;
+    if (pre_job && (!ahead || EMP_PRE(s))) return;
     Pcg g;
     g.load(io.rng, i);
-    for (int k = 0; k < how_many && owed > 0; ++k, --owed) lane_segment(io, W, i, s, g);
+    uint32_t* const rec = io.aux + (size_t)i * AUX_WORDS;
+    for (int k = 0; k < how_many && (owed > 0 || pre_job); ++k) {
+        const bool room = s.num_seg < MAX_SEG;
+        uint32_t* dst = pre_job ? rec : (room ? reinterpret_cast<uint32_t*>(seg_ptr(io, i, s.num_seg)) : nullptr);
+        // (a reset's first segment draws its start row)
+        const int ey = lane_segment_record(io, W, !pre_job && s.have_start != 0, (int)s.end_y, g, dst);
+        if (pre_job) {
+            rec[13] = g.buf;
+            rec[14] = (g.has ? 1u : 0u) | ((uint32_t)ey << 8);
+            rec[16] = (uint32_t)g.state;
+            rec[17] = (uint32_t)(g.state >> 32);
+            rec[18] = (uint32_t)(g.state >> 64);
+            rec[19] = (uint32_t)(g.state >> 96);
+            EMP_PRE(s) = 1;  // (the instance's own stream stays where it is)
+            io.core[i] = s;
+            if (io.stats) atomicAdd(io.stats + 3, 1ull);  // mg_debug_counter "emp_ahead_records"
+            return;
+        }
+        if (room) s.num_seg++;
+        else raise_error(io.err, 4);
+        s.have_start = 1;
+        s.end_y = (int8_t)ey;
+        EMP_PRE(s) = 0;
+        --owed;
+    }
     // only the fields a segment changes: the instance's record belongs to nobody else between its step and its next step
     EMP_OWED(s) = (uint8_t)owed;
     io.core[i] = s;
@@ -1764,7 +1915,7 @@ __global__ __launch_bounds__(256) void emp_serve_kernel(MysteryParams P, Mystery
 #define MG_LAB_EMP_SVC 256  // round 4, with non-temporal frame stores (round 3: 384, with lazy initial segments: profiles/r03_emp.md)
 #endif
 #ifndef MG_LAB_EMP_LB
-#define MG_LAB_EMP_LB 5
+#define MG_LAB_EMP_LB 6  // (round 5; rounds 3-4: 5)
 #endif
 #ifndef MG_LAB_EMP_SVC_SMALL
 #define MG_LAB_EMP_SVC_SMALL 768
@@ -1775,19 +1926,27 @@ constexpr int EMP_SVC_WGS = MG_LAB_EMP_SVC, EMP_SVC_WGS_SMALL = MG_LAB_EMP_SVC_S
 // nt); beside the path service the plain stream takes 149-152 us and the non-temporal one still 129-136 us -- it does not push the
 // service waves' working set (segment stores, queue, the generator's spills) out of the L2.  183-190 -> 203-209 M env-steps/s at
 // 32,768 instances; buffer-addressed stores, 4 / 6 workgroups per CU, 256 / 512 / 768 service workgroups: all within 2 % of it
-// (profiles/r04_emp.md).  -DMG_LAB_EMP_NT=0: plain stores (measurement builds).
-#ifdef MG_LAB_EMP_NT
-constexpr bool EMP_NT = MG_LAB_EMP_NT != 0;
-#else
-constexpr bool EMP_NT = true;
+// (profiles/r04_emp.md).  Lab switch MEMGYM_EMP_NT=0 / 1 forces plain / non-temporal stores.
+// Round 5: with the next episode's first segment generated ahead of time (EMP_PRE) the service queue is all but empty (a due segment
+// now and then) and the PLAIN stream is the faster one again: same box, 32,768 instances, fused launch 123.5-123.9 us plain against
+// 142-161 us non-temporal (without EMP_PRE: 159 plain, 128 non-temporal); 64 service workgroups instead of 256: 121.7 us.  The
+// kernel therefore exists in both forms and the host picks (profiles/r05_emp.md).
+#ifndef MG_LAB_EMP_SVC_PRE
+#define MG_LAB_EMP_SVC_PRE 64
 #endif
+constexpr int EMP_SVC_WGS_PRE = MG_LAB_EMP_SVC_PRE;
 #ifdef MG_LAB_EMP_CLOCK  // measurement builds only: per-workgroup start / end of service / end, constant-rate clock (10 ns)
 static __device__ unsigned long long g_lab_emp_clock[3 * 16384];
 #define LAB_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_emp_clock[3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
 #else
 #define LAB_CLOCK(slot) do { } while (0)
 #endif
-constexpr int EMP_BG_WGS = 512;  // frame workgroups that may carry background jobs (64 each: all 32,768 instances at once)
+constexpr int EMP_BG_WGS = 512;  // at most so many workgroups behind the service workgroups take background jobs (EMP_BG_SPAN instances' flags each)
+#ifndef MG_LAB_EMP_BG_SPAN
+#define MG_LAB_EMP_BG_SPAN 256
+#endif
+constexpr int EMP_BG_SPAN = MG_LAB_EMP_BG_SPAN;
+static_assert(EMP_BG_SPAN <= 256 || EMP_BG_SPAN % 256 == 0, "a background workgroup reads its span's flags 256 at a time");
 static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
 // (Round 4 tried the service and background workgroups as a launch of their own on a side stream beside a plain raster launch:
 // bit-exact, 185 M env-steps/s against 189-192 M for this fused launch -- the raster alone takes 110 us, beside the service
@@ -1795,10 +1954,10 @@ static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must f
 // struct form that helped the spotlight family's fused kernel (service loop reading them through an opaque pointer where it uses
 // them): scratch 672 -> 624 B only -- the path generator wants ~200 VGPRs whatever the scalar side does -- and the launch got
 // SLOWER, 149-151 -> 156-164 us.)
-template <int FMT>
+template <int FMT, bool EMP_NT>
 __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
                                                                   MysteryParams P, MysteryIO io, float* reward_out, uint8_t* done_out,
-                                                                  float* gt, mg_info_buffers info, int autoreset, int svc) {
+                                                                  float* gt, mg_info_buffers info, int autoreset, int svc, int bgw, int turn) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ MysteryDesc sdesc[4];
     __shared__ int served[4];
@@ -1829,7 +1988,9 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
             int inst = -1;
             if (idx < count + bg) {
                 const int entry = idx < count ? bcast(io.queue[idx], 0) : (bcast(io.bgq[idx - count], 0) | EMP_Q_OWED);
+#ifndef MG_LAB_EMP_NOSVC  // (measurement builds: what the launch costs without the cooperative generator's registers; entries are dropped)
                 emp_serve_entry(P, io, W, entry, nullptr, reward_out, done_out, gt, info, autoreset, &sdesc[wv]);
+#endif
                 if (!(entry & EMP_Q_OWED)) inst = entry & EMP_Q_INST;
                 if (me) idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
                 idx = bcast(idx, 0);
@@ -1861,31 +2022,59 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
         LAB_CLOCK(2);
         return;
     }
-    // Background jobs (owed segments, lazy initial segments): wave 0 of the first ceil(count / 64) FRAME workgroups takes 64
-    // of them, one per lane, with the lane-per-path generator in the workgroup's frame buffer, then the workgroup starts on
-    // its frames; ~105 us that run beside the other workgroups' frames, and nothing of this launch depends on them.  The
-    // last participant clears the counter (participants read it before that can happen, see mystery_raster_paths_kernel).
-    if ((int)blockIdx.x - svc < EMP_BG_WGS && !P.bg_coop) {
-        const int bg = queue_count(&io.qctr[QC_BG_COUNT], n);
-        const int busy = min(EMP_BG_WGS, (bg + 63) / 64);
+    // Background jobs (owed segments, lazy initial segments; records ahead of time, EMP_PRE): the `bgw` workgroups behind the service
+    // workgroups.  Workgroup b looks at the flags of instances b * EMP_BG_SPAN .. (emp_step_kernel wrote them), compacts the flagged
+    // ones (~30 of 256 under random actions) into a list in LDS and its wave 0 takes up to 64 of them, one per lane, with the
+    // lane-per-path generator in the workgroup's frame buffer; ~105 us that run beside the other workgroups' frames, and nothing of
+    // this launch depends on them.  What does not fit a wave waits for the instance's next step (its flag is set again; the
+    // list is entered at a position that moves with the launches, so no instance waits for ever): a workgroup that generates paths
+    // holds a frame workgroup's slot for the whole launch and costs the store stream in proportion -- the same launch 124 us with
+    // 128 such workgroups, 111 us with the jobs moved out of it (profiles/r05_emp.md) -- so they are few and full.  These workgroups
+    // draw no frames (rounds 3-4: frame workgroups carried the jobs and went on to the frames of their stride afterwards).
+    const int fb = svc + bgw;  // first frame workgroup
+    if ((int)blockIdx.x < fb) {
+        // (the list lives behind the lane generator's workspace in the frame buffer: 1 KB more of static LDS and the seventh workgroup
+        // no longer fits a CU)
+        int* const bg_jobs = reinterpret_cast<int*>(smem + LW_BYTES);
+        int* const bg_cnt = bg_jobs + EMP_BG_SPAN;
+        static_assert(LW_BYTES + EMP_BG_SPAN * 4 + 16 <= v1::RASTER_LDS && LW_BYTES % 16 == 0, "the job list must fit behind the lane generator's workspace");
         const int b = (int)blockIdx.x - svc;
-        if (b < busy) {
-            lane_ws_init(smem);
+#ifdef MG_LAB_EMP_NOBG  // (measurement builds: what the launch costs without the background jobs; owed segments are never generated here)
+        if (b >= 0) return;
+#endif
+        bool ws = false;
+        for (int base = b * EMP_BG_SPAN; base < n; base += bgw * EMP_BG_SPAN) {
+            int total = 0;
+            for (int c = 0; c < EMP_BG_SPAN; c += 256) {  // the span's flags, 256 at a time
+                const int inst = base + c + tid;
+                const bool want = c + tid < EMP_BG_SPAN && inst < n && io.bgflag[inst] != 0;
+                const uint64_t m = __ballot(want);
+                if ((tid & 63) == 0) bg_cnt[tid >> 6] = __popcll(m);
+                __syncthreads();
+                int off = total;
+                for (int w = 0; w < (tid >> 6); ++w) off += bg_cnt[w];
+                total += bg_cnt[0] + bg_cnt[1] + bg_cnt[2] + bg_cnt[3];
+                if (want) bg_jobs[off + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = inst;
+                __syncthreads();  // (the counts are rewritten by the next chunk; the list is complete behind the last one)
+            }
+            if (total && !ws) {
+                lane_ws_init(smem);
+                ws = true;
+            }
             if (tid < 64) {
+                if (P.svc_prio) __builtin_amdgcn_s_setprio(3);  // a long dependent chain next to memory-bound raster waves
                 const LaneWS LW{smem, tid};
-                for (int idx = b * 64 + tid; idx < bg; idx += busy * 64) lane_owed_segment(io, LW, io.bgq[idx], 1);
+                const int rot = total > 64 ? (int)((unsigned)turn * 61u % (unsigned)total) : 0;
+                if (tid < total) lane_owed_segment(io, LW, bg_jobs[(tid + rot) % total], 1, P.pre != 0);
             }
-            __syncthreads();
-            if (tid == 0 && atomicAdd(&io.qctr[QC_BG_LEFT], 1) == busy - 1) {
-                io.qctr[QC_BG_COUNT] = 0;
-                io.qctr[QC_BG_LEFT] = 0;
-            }
-            __syncthreads();
-            LAB_CLOCK(1);
+            __syncthreads();  // (the list is rewritten by the next round)
         }
+        LAB_CLOCK(1);
+        LAB_CLOCK(2);
+        return;
     }
-    const int stride = (int)gridDim.x - svc;
-    for (int env = (int)blockIdx.x - svc; env < n; env += stride) {
+    const int stride = (int)gridDim.x - fb;
+    for (int env = (int)blockIdx.x - fb; env < n; env += stride) {
         const MysteryDesc* d = descs + env;
         if (d->valid != 1) continue;  // masked, or drawn by the workgroup that serves its queue entry
         MysteryComposer::compose(d, R);
@@ -1915,6 +2104,9 @@ class MysteryFamily : public Family {
         P_.path_help = [] { const char* e = lab_env("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
         P_.bg_coop = lab_int("MEMGYM_EMP_BG_COOP", n <= 20480 ? 1 : 0);
         lazy_wanted_ = endless && [] { const char* e = lab_env("MEMGYM_EMP_LAZY"); return e ? atoi(e) != 0 : true; }();
+        // the next episode's first segment ahead of time (EMP_PRE): with the lane-per-path background jobs of the larger launches
+        // (as entries of the service queue -- bg_coop -- a record ahead of time costs the path it saves)
+        pre_wanted_ = endless && !P_.bg_coop && lab_int("MEMGYM_EMP_PRE", 1) != 0;
         P_.r_fall = 0.0; P_.r_progress = 0.1; P_.r_step = 0.0;
         if (endless) {
             P_.max_steps = -1; P_.show_past_path = 1; camera_offset_scale_ = 5.0; P_.stamina_level = 20;
@@ -1931,6 +2123,7 @@ class MysteryFamily : public Family {
         err_.alloc();
         queue_.alloc((size_t)n + 32 + QC_WORDS);
         bgq_.alloc(endless ? (size_t)n : 1);
+        bgflag_.alloc(endless ? (size_t)n : 1);
         {   // WaveRng: s_k = A^k s_0 + S_k inc for k = 1 .. 64 (PCG64's 128-bit LCG, multiplier as in mg_device.hpp Pcg::advance)
             const u128 A = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
             std::vector<uint4> jt(128);
@@ -1946,10 +2139,10 @@ class MysteryFamily : public Family {
         }
         if (endless) {
             segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
-            falloff_.alloc((size_t)n * MAX_FALL);
+            aux_.alloc((size_t)n * AUX_WORDS);
         } else {
             segs_.alloc(16);
-            falloff_.alloc(4);
+            aux_.alloc(4);
         }
         sets_dev_.alloc(MG_MAX_OPTION_SETS);
         hipLaunchKernelGGL(mystery_init_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, core_.p);
@@ -2031,6 +2224,7 @@ class MysteryFamily : public Family {
             mg_info_buffers none;
             memset(&none, 0, sizeof(none));
             P_.lazy = 0;  // an explicit reset generates all three segments (whatever an old episode is owed comes first)
+            P_.pre = 0;
             upload_sets(s);
             if (mask) {
                 hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
@@ -2071,6 +2265,7 @@ class MysteryFamily : public Family {
             // (per-instance option sets: the plain arrangement -- step kernel, queue server, raster -- whose kernels have a <PS> form)
             const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC && !ps && !big_sprites_;
             P_.lazy = (fused && lazy_wanted_) ? 1 : 0;
+            P_.pre = (P_.lazy && pre_wanted_) ? 1 : 0;
             if (!P_.lazy && owed_possible_) flush_owed(s);
             if (P_.lazy) owed_possible_ = true;
             upload_sets(s);
@@ -2080,12 +2275,28 @@ class MysteryFamily : public Family {
             if (fused) {  // the queue is served inside the raster launch
                 end_logic(s);
                 prof.begin(1, s);
-                const int svc = P_.bg_coop ? EMP_SVC_WGS_SMALL : EMP_SVC_WGS;  // (small launches: the owed segments are entries too)
-                const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + svc;
-                hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
-                                   P_, io(), reward, done, gt, ib, autoreset, svc);
+                // (small launches: the owed segments are entries too; with records ahead of time: next to no entries)
+                const int svc = P_.bg_coop ? EMP_SVC_WGS_SMALL : (P_.pre ? EMP_SVC_WGS_PRE : EMP_SVC_WGS);
+                static const int nt_forced = lab_int("MEMGYM_EMP_NT", -1);
+                const bool nt = nt_forced >= 0 ? nt_forced != 0 : !P_.pre;
+                int bgw = P_.bg_coop ? 0 : std::min(EMP_BG_WGS, (n_ + EMP_BG_SPAN - 1) / EMP_BG_SPAN);   // background workgroups: EMP_BG_SPAN instances' flags each
+                ++turn_;
+                // lab: MEMGYM_EMP_BG_SEPARATE=1 runs the background jobs as a launch of their own BEHIND the raster (what they cost it)
+                static const int bg_separate = lab_int("MEMGYM_EMP_BG_SEPARATE", 0);
+                const int bgw_later = bg_separate ? bgw : 0;
+                if (bg_separate) bgw = 0;
+                const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + svc + bgw;  // (service, background, frames)
+                if (nt)
+                    hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, true>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                       P_, io(), reward, done, gt, ib, autoreset, svc, bgw, turn_);
+                else
+                    hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, false>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                       P_, io(), reward, done, gt, ib, autoreset, svc, bgw, turn_);
                 MG_HIP(hipGetLastError());
                 prof.end(1, s);
+                if (bgw_later)  // (grid = service + background workgroups only: no frames; the queue is empty by now)
+                    hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, false>), dim3(svc + bgw_later), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                       P_, io(), reward, done, gt, ib, autoreset, svc, bgw_later, turn_);
 #ifdef MG_LAB_EMP_CLOCK  // diagnosis: is the next logic kernel slow because the L2 is full of dirty observation lines?
                 static const int wb = [] { const char* e = lab_env("MEMGYM_LAB_WBL2"); return e ? atoi(e) : 0; }();
                 if (wb) hipLaunchKernelGGL(lab_wbl2_kernel, dim3(wb), dim3(64), 0, s);
@@ -2123,7 +2334,8 @@ class MysteryFamily : public Family {
     }
 
     std::vector<std::pair<void*, size_t>> state_blobs() override {
-        std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {segs_.p, segs_.bytes()}, {falloff_.p, falloff_.bytes()},
+        // (aux: fall-off lists, and the records generated ahead of time -- they belong to the state: the EMP_PRE flags travel in `core`)
+        std::vector<std::pair<void*, size_t>> v = {{core_.p, core_.bytes()}, {segs_.p, segs_.bytes()}, {aux_.p, aux_.bytes()},
                                                   {walls_.p, walls_.bytes()}};
         rng_.blobs(v);
         return v;
@@ -2140,7 +2352,7 @@ class MysteryFamily : public Family {
     }
     int peek_errors() override { return err_.peek(); }
     bool debug_counter(const std::string& name, int64_t* out) override {
-        const int k = name == "path_gen_ticks" ? 0 : (name == "path_gen_paths" ? 1 : -1);
+        const int k = name == "path_gen_ticks" ? 0 : (name == "path_gen_paths" ? 1 : (name == "emp_own_resets" ? 2 : (name == "emp_ahead_records" ? 3 : -1)));
         if (k < 0 || !stats_.p) return false;
         unsigned long long v = 0;
         MG_HIP(hipMemcpy(&v, stats_.p + k, sizeof v, hipMemcpyDeviceToHost));
@@ -2216,7 +2428,6 @@ class MysteryFamily : public Family {
         MysteryIO o;
         o.core = core_.p;
         o.segs = segs_.p;
-        o.falloff = falloff_.p;
         o.rng = rng_.view();
         o.desc = desc_.p;
         o.err = err_.dev;
@@ -2224,6 +2435,8 @@ class MysteryFamily : public Family {
         o.walls = P_.endless ? nullptr : walls_.p;
         o.qctr = queue_.p + ((n_ + 31) & ~31);
         o.bgq = bgq_.p;
+        o.bgflag = bgflag_.p;
+        o.aux = aux_.p;
         o.jump = jump_.p;
         o.stats = stats_.p;
         o.sets = per_set() ? sets_dev_.p : nullptr;
@@ -2240,7 +2453,7 @@ class MysteryFamily : public Family {
     static void copy_geometry(MysteryParams& d, const MysteryParams& s) {
         d.endless = s.endless; d.grid = s.grid; d.n = s.n; d.depth = s.depth; d.agent_radius = s.agent_radius; d.sprite_dim = s.sprite_dim;
         d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.tile = s.tile; d.cross_dim = s.cross_dim; d.camera_offset = s.camera_offset;
-        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help; d.bg_coop = s.bg_coop;
+        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help; d.bg_coop = s.bg_coop; d.pre = s.pre;
     }
     bool per_set() const { return set_of_ != nullptr && !extra_.empty(); }
     // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)
@@ -2343,11 +2556,13 @@ class MysteryFamily : public Family {
     std::unique_ptr<Atlas> atlas_;
     DevArray<MysteryCore> core_;
     DevArray<uint8_t> segs_;
-    DevArray<uint32_t> falloff_;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
-    DevArray<int> bgq_;    // endless: background jobs (owed segments)
-    bool lazy_wanted_ = false, owed_possible_ = false;
+    DevArray<int> bgq_;    // endless: background jobs (owed segments), small launches
+    DevArray<uint8_t> bgflag_;  // ... larger launches: one flag per instance
+    bool lazy_wanted_ = false, owed_possible_ = false, pre_wanted_ = false;
+    int turn_ = 0;  // fused launches so far (where a background workgroup enters an over-long job list)
+    DevArray<uint32_t> aux_;  // endless: per instance, the next episode's first segment + the stream behind it (EMP_PRE) and the fall-off list
     DevArray<uint4> jump_;  // WaveRng jump constants
     DevArray<unsigned long long> stats_;  // MysteryIO::stats
     DevArray<uint64_t> walls_;  // finite: wall cells of every instance's path generation (debug view)

@@ -202,7 +202,7 @@ int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream);
  * payload bytes, FNV-1a of the env id, groups}; the layout behind it is private to one MG_STATE_VERSION.  mg_set_state refuses
  * (-1, message in mg_last_error) a blob whose magic, version, env id, num_envs or payload size differ from the handle's
  * instead of mis-assigning it. */
-#define MG_STATE_VERSION 5u
+#define MG_STATE_VERSION 6u
 size_t mg_state_size(const mg_env* env);
 int mg_get_state(mg_env* env, void* host_buf, size_t size);
 int mg_set_state(mg_env* env, const void* host_buf, size_t size);

@@ -18,7 +18,7 @@ def _check_vec(env_id, vec, ref, where):
         env_id, where, np.nonzero((got != want).any(1))[0][:8])
 
 
-def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1, seed0=3):
+def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1, seed0=3, want_counters=()):
     import memory_gym_amd
     import oracle_lib
 
@@ -73,6 +73,8 @@ def run_parity(env_id, options, n, steps, policy=None, n_policy=0, check_every=1
     for i in sorted({0, min(1, n - 1), n // 2, n - 1}):
         assert np.array_equal(env.rng_words(i), ref.envs[i].rng_words()), "RNG stream of env %d diverged" % i
     env.check_errors()
+    for name in want_counters:  # the arrangement under test really ran (mg_debug_counter)
+        assert env.debug_counter(name) > 0, "%s: counter %s is zero after %d steps" % (env_id, name, steps)
     env.close()
     ref.close()
     return n_done

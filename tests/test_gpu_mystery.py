@@ -88,19 +88,21 @@ EMP_OPTS = [
 
 @pytest.mark.parametrize("opt_idx", range(len(MP_OPTS)))
 def test_finite_parity(opt_idx):
-    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=540 if opt_idx != 1 else 200, policy=path_follower, n_policy=64)
+    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=540 if opt_idx != 1 else 200, policy=path_follower, n_policy=64,
+                        check_every=1 if opt_idx == 1 else 2)  # (the 540-step runs compare frames every other step, everything else every step)
     assert n_done > 0
 
 
 @pytest.mark.parametrize("opt_idx", range(len(GRID_OPTS)))
 def test_grid_parity(opt_idx):
-    n_done = run_parity("MysteryPath-Grid-v0", GRID_OPTS[opt_idx], n=160, steps=300, policy=grid_follower, n_policy=64)
+    n_done = run_parity("MysteryPath-Grid-v0", GRID_OPTS[opt_idx], n=160, steps=300, policy=grid_follower, n_policy=64, check_every=2)
     assert n_done > 0
 
 
 @pytest.mark.parametrize("opt_idx", range(len(EMP_OPTS)))
 def test_endless_parity(opt_idx):
-    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=260, policy=endless_follower, n_policy=64)
+    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=260, policy=endless_follower, n_policy=64,
+                        check_every=1 if opt_idx == 0 else 2)
     assert n_done > 0
 
 
@@ -140,4 +142,57 @@ def test_full_size_sample():
             assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t)
     for i in sample:
         assert np.array_equal(env.rng_words(i), refs[i].rng_words())
+    env.close()
+
+
+def test_endless_full_size_sample():
+    """32,768 Endless-MysteryPath instances -- the launch size at which a reset's segments are owed (lazy), the owed ones are
+    generated one per lane beside the frames, and the NEXT episode's first segment is generated ahead of time so that a finishing
+    instance is reset by its own step (EMP_PRE) -- against single-instance oracles for a sample of instances:
+    frames, rewards, dones and ground truth at every step, the generator's words at the end and after a checkpoint round trip."""
+    import memory_gym_amd
+    import oracle_lib
+    import torch
+
+    n = 32768
+    env = memory_gym_amd.make("Endless-MysteryPath-v0", num_envs=n, device=0)
+    obs, _ = env.reset(seed=0)
+    sample = [0, 1, 63, 64, 255, 4095, 16384, 20000, 32767]
+    refs = {i: oracle_lib.OracleEnv("Endless-MysteryPath-v0") for i in sample}
+    first = obs[sample].cpu().numpy()
+    for k, i in enumerate(sample):
+        assert np.array_equal(first[k], refs[i].reset(i)), "reset frame of instance %d differs" % i
+    g = torch.Generator(device="cuda").manual_seed(0)
+    episodes = 0
+
+    def run(steps, t0):
+        nonlocal episodes
+        for t in range(steps):
+            a = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32)
+            obs, rew, done, _, info = env.step(a)
+            ac = a[sample].cpu().numpy()
+            got, gr, gd = obs[sample].cpu().numpy(), rew[sample].cpu().numpy(), done[sample].cpu().numpy()
+            ggt = info["ground_truth"][sample].cpu().numpy()
+            for k, i in enumerate(sample):
+                o, r, d = refs[i].step(int(ac[k]))
+                assert bool(gd[k]) == bool(d) and gr[k] == np.float32(r), "instance %d: reward / done differ at step %d" % (i, t0 + t)
+                if d:
+                    o = refs[i].reset(None)
+                    episodes += 1
+                assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t0 + t)
+                assert np.array_equal(ggt[k], np.asarray(refs[i].gt(), dtype=np.float32)), "instance %d: ground truth differs at step %d" % (i, t0 + t)
+
+    run(150, 0)
+    assert episodes >= 20
+    assert env.debug_counter("emp_ahead_records") > n  # more than one episode per instance began with a record made ahead of time
+    for i in sample:  # (looks at the state: what is owed is generated first; records ahead of time stay)
+        assert np.array_equal(env.rng_words(i), refs[i].rng_words()), "RNG stream of instance %d diverged" % i
+    sd = env.state_dict()
+    env.close()
+    env = memory_gym_amd.make("Endless-MysteryPath-v0", num_envs=n, device=0)
+    env.load_state_dict(sd)
+    run(60, 150)
+    for i in sample:
+        assert np.array_equal(env.rng_words(i), refs[i].rng_words()), "RNG stream of instance %d diverged after the checkpoint" % i
+    env.check_errors()
     env.close()

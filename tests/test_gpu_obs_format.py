@@ -61,3 +61,37 @@ def test_masked_reset_leaves_other_frames():
     assert (o[[1, 2, 4, 5, 6, 7]] == -1.0).all()
     assert (o[[0, 3]] >= 0).all() and (o[[0, 3]] <= 1).all()
     env.close()
+
+
+@pytest.mark.parametrize("env_id,n_act", [("MortarMayhem-Grid-v0", 4), ("MysteryPath-v0", 3), ("Endless-MysteryPath-v0", 4),
+                                          ("SearingSpotlights-v0", 3), ("Endless-SearingSpotlights-v0", 3)])
+def test_float_formats_match_the_oracle(env_id, n_act):
+    """The float formats against the ORACLE's frames, not against this library's own uint8 output (the test
+    above is a self-comparison by construction): float32 [c][y][x] == oracle uint8 [x][y][c] / 255 within north_star's 1e-5 --
+    and exactly, the division being correctly rounded -- at every step of a lock-step run through resets."""
+    import memory_gym_amd
+    import oracle_lib
+
+    n, steps = 64, 40
+    ref = oracle_lib.OracleBatch(env_id, n)
+    seeds = np.arange(n, dtype=np.int64) + 77
+    envs = {f: memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format=f) for f in ("f32_chw", "f16_chw")}
+    obs = {f: e.reset(seed=seeds)[0] for f, e in envs.items()}
+    want_u8 = ref.reset(seeds)
+    prng = np.random.Generator(np.random.PCG64(5))
+    disc = envs["f32_chw"].action_dim == 1
+    for t in range(steps + 1):
+        want = want_u8.transpose(0, 3, 2, 1).astype(np.float32) / np.float32(255)
+        got = obs["f32_chw"].cpu().numpy()
+        assert np.abs(got - want).max() <= TOL, "float32 frames differ from the oracle's by more than 1e-5 at step %d" % t
+        assert np.array_equal(got, want), "float32 frames differ from the oracle's at step %d" % t
+        assert np.array_equal(obs["f16_chw"].cpu().numpy(), want.astype(np.float16)), "float16 frames differ from the oracle's at step %d" % t
+        a = (prng.integers(0, n_act, n) if disc else prng.integers(0, n_act, (n, 2))).astype(np.int32)
+        outs = {f: e.step(a) for f, e in envs.items()}
+        obs = {f: o[0] for f, o in outs.items()}
+        want_u8, r2, d2 = ref.step(a, autoreset=True)
+        assert np.array_equal(outs["f32_chw"][2].cpu().numpy(), d2.astype(bool)) and np.array_equal(outs["f32_chw"][1].cpu().numpy(), r2.astype(np.float32))
+    for e in envs.values():
+        e.check_errors()
+        e.close()
+    ref.close()

@@ -19,7 +19,8 @@ def test_odd_batch_sizes(env_id, n):
 # instance against the oracle.
 @pytest.mark.parametrize("env_id,n", [
     ("Endless-SearingSpotlights-v0", 16385), ("Endless-SearingSpotlights-v0", 24577),
-    ("SearingSpotlights-v0", 16385), ("SearingSpotlights-v0", 65536), ("SearingSpotlights-v0", 65537),
+    ("SearingSpotlights-v0", 16385), ("SearingSpotlights-v0", 65536),
+    pytest.param("SearingSpotlights-v0", 65537, marks=pytest.mark.slow),  # (the other side of FUSE_MAX: the same kernels as 65,536 / 16,385)
 ])
 def test_spotlight_launch_size_switches(env_id, n):
     if n > 60000:  # (every instance truncated in steps 8 and 16: the resets of both arrangements at their largest / smallest size)

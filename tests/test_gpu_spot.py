@@ -174,3 +174,51 @@ def test_every_instance_truncated_in_the_same_step(n):
     the kernel from the queue's length: csrc/mg_spot.hip SpotServeArgs): with max_steps = 9 every instance is truncated in steps 9,
     18 and 27 -- n resets at once, two and eight per workgroup, several rounds for the larger batch."""
     run_parity("SearingSpotlights-v0", dict(max_steps=9), n=n, steps=30, check_every=3)
+
+
+@pytest.mark.parametrize("env_id", ["SearingSpotlights-v0", "Endless-SearingSpotlights-v0"])
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 5])
+def test_reset_spotlights_from_one_batch_of_outputs(env_id, count):
+    """new_spots_at_reset (csrc/mg_spot.hip): a reset's `initial_spawns` spotlights come from the generator's next 16 outputs at once
+    (PCG64 jump-ahead across the instance's 16 lanes), and which half of which output feeds which draw depends on whether the stream
+    arrives with a buffered 32-bit half.  Both layouts, every count the batch form takes (1..5): with `sample_agent_position` on, the
+    seeded reset draws one more 32-bit number in front of the spotlights than with it off, so the two settings reach the spotlights in
+    opposite buffer states; the auto-resets of the run arrive in either.  Checked: every reset frame (the spotlights are drawn), the
+    generator's words of EVERY instance right after the seeded reset and at the end."""
+    import memory_gym_amd
+    import oracle_lib
+
+    n, steps = 64, 40
+    for sample in (True, False):
+        opts = dict(initial_spawns=count, sample_agent_position=sample, agent_health=6)  # (short episodes: many auto-resets)
+        env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+        ref = oracle_lib.OracleBatch(env_id, n, options=opts)
+        seeds = np.arange(n, dtype=np.int64) * 13 + 5 * count
+        obs, _ = env.reset(seed=seeds, options=opts)
+        assert np.array_equal(obs.cpu().numpy(), ref.reset(seeds)), "reset frames differ (count %d, sample_agent_position %s)" % (count, sample)
+        buffered = 0
+        for i in range(n):
+            w = ref.envs[i].rng_words()
+            assert np.array_equal(env.rng_words(i), w), "instance %d: generator differs right after the seeded reset" % i
+            buffered += int(w[4])
+        assert buffered in (0, n)  # the seeded reset's draw count is fixed by the options ...
+        if sample:
+            first = buffered
+        else:
+            assert buffered != first  # ... and differs by one between the two settings: both buffer states are covered
+        prng = np.random.Generator(np.random.PCG64(17 + count))
+        n_done = 0
+        for t in range(steps):
+            a = prng.integers(0, 3, (n, 2)).astype(np.int32)
+            obs, rew, done, _, _ = env.step(a)
+            o2, r2, d2 = ref.step(a, autoreset=True)
+            d = done.cpu().numpy()
+            assert np.array_equal(d, d2.astype(bool)) and np.array_equal(rew.cpu().numpy(), r2.astype(np.float32)), "step %d" % t
+            assert np.array_equal(obs.cpu().numpy(), o2), "frames differ at step %d (count %d, sample_agent_position %s)" % (t, count, sample)
+            n_done += int(d.sum())
+        assert n_done > 0 or count < 3  # (auto-resets arrive in either buffer state; with one or two spotlights an agent may outlive the run)
+        for i in range(n):
+            assert np.array_equal(env.rng_words(i), ref.envs[i].rng_words()), "instance %d: generator diverged" % i
+        env.check_errors()
+        env.close()
+        ref.close()

@@ -17,6 +17,9 @@ CASES = [
     ("MEMGYM_EMP_FUSE", "0", "Endless-MysteryPath-v0", 160, 150),          # queue server as a launch of its own
     ("MEMGYM_EMP_RESET_LANES", "0", "Endless-MysteryPath-v0", 1024, 30),    # full reset one wave per instance (lanes: n >= 1,024)
     ("MEMGYM_EMP_BG_COOP", "0", "Endless-MysteryPath-v0", 640, 120),       # owed segments one per lane of frame workgroups (the default above ~20,000 instances)
+    # the next episode's first segment ahead of time (the default above ~20,000 instances; it rides on the lane-per-path jobs) ...
+    ("MEMGYM_EMP_BG_COOP=0 MEMGYM_SWITCH_WORKER_WANT=emp_own_resets MEMGYM_EMP_PRE", "1", "Endless-MysteryPath-v0", 640, 200),
+    ("MEMGYM_EMP_BG_COOP=0 MEMGYM_EMP_PRE", "0", "Endless-MysteryPath-v0", 640, 120),  # ... and without it
     ("MEMGYM_MYSTERY_DEFER", "1", "MysteryPath-v0", 160, 150),              # reset paths inside the raster launch
     ("MEMGYM_MYSTERY_DEFER", "0", "MysteryPath-Grid-v0", 160, 150),         # ... and not, for the grid variant
     ("MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 200),    # resets inside the raster launch

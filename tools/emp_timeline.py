@@ -31,7 +31,7 @@ c = buf.reshape(16384, 3).astype(np.float64)
 live = c[:, 0] > 0
 t0 = c[live, 0].min()
 us = (c - t0) / 100.0
-svc, bg = 256, 512
+svc, bg = 64, 128  # (round 5: 64 service workgroups, one background workgroup per 256 instances)
 
 
 def stats(name, rows, col):
