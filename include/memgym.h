@@ -294,7 +294,11 @@ int mg_enable_peer_access(int device, int peer_device);
 
 /* Test / telemetry hook: named counters of a handle.  "one_launch_rescues" (mortar family): 64-instance slots of the one-launch
  * step that a frame wave stepped itself because the step workgroup's wave had not claimed them in time (0 on a GPU that
- * dispatches the step workgroups first; tests/test_gpu_one_launch.py forces the other order).  Unknown name: -1.  Synchronous. */
+ * dispatches the step workgroups first; tests/test_gpu_one_launch.py forces the other order).  "path_gen_ticks" / "path_gen_paths"
+ * (finite Mystery Path: wave-ticks and paths of the A* generation inside the step's launches).  "emp_ahead_records"
+ * (Endless-MysteryPath: first segments of NEXT episodes generated ahead of time, which a finishing instance's own step turns into its
+ * reset -- EndlessMysteryPathEnv.reset, endless_mystery_path.py:195-280, without a queue entry); "emp_own_resets" (such resets; counted
+ * by the lab build only).  Unknown name: -1.  Synchronous. */
 int mg_debug_counter(mg_env* env, const char* name, int64_t* value);
 
 /* Test hook: copy the numpy-compatible PCG64 words of instance i to host:

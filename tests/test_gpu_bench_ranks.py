@@ -16,17 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_self_launched_two_ranks():
     env = dict(os.environ, MEMGYM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "12", "--warmup", "3",
-                          "--settle", "30", "--envs-per-gpu", "8192", "--config5-envs", "8192", "--config5-steps", "40"], env=env, capture_output=True, text=True, timeout=900)
+                          "--settle", "30", "--envs-per-gpu", "4096", "--config5-envs", "4096", "--config5-steps", "24"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line, from rank 0: %r" % out.stdout[-500:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["config"]["envs_total"] == 16384 and j["config"]["envs_per_gpu"] == 8192
-    assert j["value"] > 1e6 and abs(j["per_gpu_value"] * 2 - j["value"]) < 1e-3 * j["value"] and j["scaling"] == "weak"
+    assert j["n_gpus"] == 2 and j["config"]["envs_total"] == 8192 and j["config"]["envs_per_gpu"] == 4096
+    assert j["value"] > 5e5 and abs(j["per_gpu_value"] * 2 - j["value"]) < 1e-3 * j["value"] and j["scaling"] == "weak"
     assert "cpu_baseline" not in j  # rank 0, N = 1 only
     c5 = j["config5"]
-    assert c5["workload"].startswith("Endless-MortarMayhem-v0, 8192 envs/GPU x 2")  # (--config5-envs: the default is BASELINE's 32,768)
-    assert c5["no_gather"]["value"] > 1e6
+    assert c5["workload"].startswith("Endless-MortarMayhem-v0, 4096 envs/GPU x 2")  # (--config5-envs: the default is BASELINE's 32,768)
+    assert c5["no_gather"]["value"] > 5e5
     assert isinstance(c5["gather_peer"], dict) and c5["gather_peer"]["value"] > 1e5, c5["gather_peer"]  # peer-mapped stores (same device here)
     # gather_rccl needs the nccl backend (gloo has no CUDA gather): under this test it must fail softly, not take the line down
     assert isinstance(c5["gather_rccl"], (dict, str))

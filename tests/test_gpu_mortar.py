@@ -221,3 +221,10 @@ def test_a_display_schedule_beyond_16_bits_is_refused():
         env.reset(seed=0, options=dict(command_count=[32], command_show_duration=[2000], command_show_delay=[100]))
     env.reset(seed=0, options=dict(command_count=[1], command_show_duration=[60000], command_show_delay=[5000]))
     env.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("env_id", MORTAR)
+def test_long_runs(env_id):
+    """MEMGYM_SLOW=1: long lock-step runs of the default options, every frame compared."""
+    assert run_parity(env_id, OPTION_SETS[env_id][0], n=192, steps=800, skill_envs=48) > 0

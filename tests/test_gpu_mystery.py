@@ -196,3 +196,12 @@ def test_endless_full_size_sample():
         assert np.array_equal(env.rng_words(i), refs[i].rng_words()), "RNG stream of instance %d diverged after the checkpoint" % i
     env.check_errors()
     env.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("env_id,opts,policy,steps", [("MysteryPath-v0", MP_OPTS[0], path_follower, 1100), ("MysteryPath-Grid-v0", GRID_OPTS[0], grid_follower, 600),
+                                                      ("Endless-MysteryPath-v0", EMP_OPTS[0], endless_follower, 700), ("Endless-MysteryPath-v0", EMP_OPTS[1], endless_follower, 700)])
+def test_long_runs(env_id, opts, policy, steps):
+    """MEMGYM_SLOW=1: one long lock-step run per variant, every frame compared (rare paths -- a long episode, owed and new
+    segments falling into one step -- need many steps to occur)."""
+    assert run_parity(env_id, opts, n=160, steps=steps, policy=policy, n_policy=64) > 0
