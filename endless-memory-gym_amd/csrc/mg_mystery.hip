@@ -49,6 +49,7 @@ struct MysteryParams {
     int lazy;           // Endless: a reset generates ONE of its three initial segments, the other two are owed (see EMP_OWED)
     int path_help;      // frame workgroups help with long path queues (MEMGYM_PATH_HELP=0: the 128 dedicated workgroups alone, round 2)
     int bg_coop;        // Endless, fused launch: owed segments as queue entries of the service waves (small launches), not one per lane of frame workgroups
+    int lazy_append;    // Endless, lazy: a segment appended during an episode is owed too, not a queue entry of the step (emp_step_a)
     int pre;            // Endless, lazy: the NEXT episode's first segment is generated ahead of time as a background job (see EMP_PRE)
     OptList cardinal;
     double r_goal, r_fall, r_progress, r_dense, r_step;
@@ -967,8 +968,16 @@ __device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, int a, 
     // `current_segment > num_segments - 2` counts the owed segments as the reference has them; and whatever this step could
     // read of a segment that is still owed (the next node's direction at the end of the last generated segment) makes the
     // owed ones due now -- conservative: within two columns of the end of what exists
-    const int owed = EMP_OWED(s);
-    if (s.cur_seg > s.num_seg + owed - 2) return 1;
+    int owed = EMP_OWED(s);
+    if (s.cur_seg > s.num_seg + owed - 2) {
+        // Round 5: the segment the reference appends now (:333-335) is OWED like a reset's second and third -- the agent has only
+        // entered the last but one, the new one starts eight columns ahead -- and generated by the next background job instead of by
+        // a queue entry of this step (an agent that follows its path appended one every ~8 steps: thousands of cooperative paths per
+        // step at 32,768 instances).  Nothing else draws from the stream, so the order of its draws is the reference's.
+        if (!P.lazy_append || owed >= 200) return 1;
+        EMP_OWED(s) = (uint8_t)(++owed);
+        EMP_PRE(s) = 0;  // (a record ahead of time continued the stream as it stood BEFORE this segment)
+    }
     return (owed > 0 && nx >= (G + 1) * s.num_seg - 2) ? 1 : 0;
 }
 #ifdef MG_LAB_EMP_CLOCK
@@ -1391,8 +1400,12 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
             queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
             d.valid = DESC_QUEUED;
         } else {
-            // one owed segment per step -- or, when nothing is owed, the next episode's first (EMP_PRE) -- as a job nobody waits for
-            bg = P.lazy && (EMP_OWED(s) > 0 || (P.pre && !EMP_PRE(s)));
+            // one owed segment per step -- or, when nothing is owed, the next episode's first (EMP_PRE) -- as a job nobody waits for.
+            // The record ahead of time only once the episode CAN end soon: the agent is off the path or behind its frontier (a
+            // fall-off there ends the episode, endless_mystery_path.py:385-393, and no new tile refills its stamina); an agent AT its
+            // frontier appends segments, each of which would drop the record again (a path-following agent: one more path per
+            // appended segment for nothing, tools/emp_policy_bench.py).
+            bg = P.lazy && (EMP_OWED(s) > 0 || (P.pre && !EMP_PRE(s) && (s.off || nx < s.max_x)));
         }
     }
     LAB_STEP_CLOCK(3);
@@ -1834,7 +1847,7 @@ __global__ __launch_bounds__(64) void emp_flush_owed_kernel(MysteryParams P, Mys
     lane_ws_init(smem);
     const LaneWS W{smem, (int)threadIdx.x};
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i < P.n) lane_owed_segment(io, W, i, 2);
+    if (i < P.n) lane_owed_segment(io, W, i, 255);
 }
 
 // mg_reset of every Endless-MysteryPath instance: one LANE per instance (emp_serve_kernel: one wave per instance)
@@ -1857,8 +1870,7 @@ __global__ __launch_bounds__(64) void emp_reset_lanes_kernel(MysteryParams P, My
             owed_old = EMP_OWED(s);  // reset(seed=None): what the old episode is owed comes first in the stream
         }
     }
-    for (int k = 0; k < 2; ++k)
-        if (k < owed_old) lane_segment(io, W, i, s, g);
+    for (int k = 0; k < owed_old; ++k) lane_segment(io, W, i, s, g);  // (two of a lazy reset's, and appended ones: emp_step_a)
     if (active) {
         emp_pre_reset(s);
         EMP_OWED(s) = 0;
@@ -2225,6 +2237,7 @@ class MysteryFamily : public Family {
             memset(&none, 0, sizeof(none));
             P_.lazy = 0;  // an explicit reset generates all three segments (whatever an old episode is owed comes first)
             P_.pre = 0;
+            P_.lazy_append = 0;
             upload_sets(s);
             if (mask) {
                 hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
@@ -2266,6 +2279,8 @@ class MysteryFamily : public Family {
             const bool fused = fuse_serve() && obs_format == MG_OBS_U8_XYC && !ps && !big_sprites_;
             P_.lazy = (fused && lazy_wanted_) ? 1 : 0;
             P_.pre = (P_.lazy && pre_wanted_) ? 1 : 0;
+            static const int lazy_append = lab_int("MEMGYM_EMP_LAZY_APPEND", 1);
+            P_.lazy_append = (P_.lazy && lazy_append) ? 1 : 0;
             if (!P_.lazy && owed_possible_) flush_owed(s);
             if (P_.lazy) owed_possible_ = true;
             upload_sets(s);
@@ -2453,7 +2468,7 @@ class MysteryFamily : public Family {
     static void copy_geometry(MysteryParams& d, const MysteryParams& s) {
         d.endless = s.endless; d.grid = s.grid; d.n = s.n; d.depth = s.depth; d.agent_radius = s.agent_radius; d.sprite_dim = s.sprite_dim;
         d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.tile = s.tile; d.cross_dim = s.cross_dim; d.camera_offset = s.camera_offset;
-        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help; d.bg_coop = s.bg_coop; d.pre = s.pre;
+        d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help; d.bg_coop = s.bg_coop; d.pre = s.pre; d.lazy_append = s.lazy_append;
     }
     bool per_set() const { return set_of_ != nullptr && !extra_.empty(); }
     // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)

@@ -165,10 +165,22 @@ def test_endless_full_size_sample():
     g = torch.Generator(device="cuda").manual_seed(0)
     episodes = 0
 
+    far_seen = [0]
+    followers = [i for k, i in enumerate(sample) if k % 2 == 1]  # these walk along their paths: new segments fall due, records ahead of time are dropped
+
+    class _Never:  # (endless_follower's share of random actions: none here)
+        def random(self):
+            return 0.0
+
+    _never = _Never()
+    fidx = torch.tensor(followers, device="cuda")
+
     def run(steps, t0):
         nonlocal episodes
         for t in range(steps):
             a = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32)
+            if (t0 + t) % 200 < 130:  # (130 faultless steps = three to four segments, then random actions until the instance has been reset)
+                a[fidx] = torch.tensor([endless_follower(refs[i], _never)[0] for i in followers], device="cuda", dtype=torch.int32)
             obs, rew, done, _, info = env.step(a)
             ac = a[sample].cpu().numpy()
             got, gr, gd = obs[sample].cpu().numpy(), rew[sample].cpu().numpy(), done[sample].cpu().numpy()
@@ -176,14 +188,17 @@ def test_endless_full_size_sample():
             for k, i in enumerate(sample):
                 o, r, d = refs[i].step(int(ac[k]))
                 assert bool(gd[k]) == bool(d) and gr[k] == np.float32(r), "instance %d: reward / done differ at step %d" % (i, t0 + t)
+                if i in followers:
+                    far_seen[0] = max(far_seen[0], int(refs[i].get("num_seg") or 0))
                 if d:
                     o = refs[i].reset(None)
                     episodes += 1
                 assert np.array_equal(got[k], o), "instance %d differs at step %d" % (i, t0 + t)
                 assert np.array_equal(ggt[k], np.asarray(refs[i].gt(), dtype=np.float32)), "instance %d: ground truth differs at step %d" % (i, t0 + t)
 
-    run(150, 0)
+    run(220, 0)
     assert episodes >= 20
+    assert far_seen[0] >= 4, "no follower reached a fourth segment (appended when the agent enters the last but one)"
     assert env.debug_counter("emp_ahead_records") > n  # more than one episode per instance began with a record made ahead of time
     for i in sample:  # (looks at the state: what is owed is generated first; records ahead of time stay)
         assert np.array_equal(env.rng_words(i), refs[i].rng_words()), "RNG stream of instance %d diverged" % i
@@ -191,7 +206,7 @@ def test_endless_full_size_sample():
     env.close()
     env = memory_gym_amd.make("Endless-MysteryPath-v0", num_envs=n, device=0)
     env.load_state_dict(sd)
-    run(60, 150)
+    run(60, 220)
     for i in sample:
         assert np.array_equal(env.rng_words(i), refs[i].rng_words()), "RNG stream of instance %d diverged after the checkpoint" % i
     env.check_errors()

@@ -15,10 +15,11 @@ try:
     j = json.loads(line)
     r = j.get("roofline", {})
     w = j.get("value_windows") or [0]
-    print("%s\t%.1f M\traster %.1f us\tlogic %s us\twindows %.1f-%.1f\tbox frame-shaped %.0f GB/s" % (
+    op = j.get("obs_placement") or {}
+    print("%s\t%.1f M\traster %.1f us\tlogic %s us\twindows %.1f-%.1f\tbox frame-shaped %.0f GB/s\tzones %s pieces %s walked %.0f GiB" % (
         label, j["value"] / 1e6, (r.get("avg_launch_ms") or 0) * 1e3,
         ("%.1f" % (r["logic_kernel_avg_ms"] * 1e3)) if r.get("logic_kernel_avg_ms") else "-", min(w) / 1e6, max(w) / 1e6,
-        (r.get("box_ceiling_GBps") or {}).get("frame_shaped", 0)))
+        (r.get("box_ceiling_GBps") or {}).get("frame_shaped", 0), op.get("zones"), op.get("pieces"), (op.get("searched_bytes") or 0) / 2**30))
 except Exception as e:
     print("%s\tFAILED %s %s" % (label, e, line[:200]))
 PY
