@@ -35,17 +35,18 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: the long variant of a lock-step run whose shorter form is in the default suite (MEMGYM_SLOW=1 runs them)")
+    config.addinivalue_line("markers", "slow: the long variant of a lock-step run whose shorter form is in the suite as well (MEMGYM_FAST=1 leaves them out)")
 
 
 def pytest_collection_modifyitems(config, items):
-    """The default GPU suite stays under the driver's step limit: every family keeps long lock-step runs in it, the longer
-    duplicates are marked `slow` and run with MEMGYM_SLOW=1 (ADVICE r4; VERDICT r4 weak #11)."""
+    """Tests marked `slow` are the long variants of lock-step runs whose shorter form is in the suite as well (rare paths
+    need long runs).  They run by default -- with the oracle on one OpenMP thread per usable CPU the whole GPU suite takes ~5
+    minutes -- and MEMGYM_FAST=1 leaves them out."""
     import pytest
 
-    if os.environ.get("MEMGYM_SLOW"):
+    if not os.environ.get("MEMGYM_FAST"):
         return
-    skip = pytest.mark.skip(reason="slow variant: set MEMGYM_SLOW=1")
+    skip = pytest.mark.skip(reason="slow variant: unset MEMGYM_FAST")
     for it in items:
         if "slow" in it.keywords:
             it.add_marker(skip)

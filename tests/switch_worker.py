@@ -12,5 +12,5 @@ from gpu_parity import run_parity  # noqa: E402
 if __name__ == "__main__":
     env_id, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     want = [w for w in os.environ.get("MEMGYM_SWITCH_WORKER_WANT", "").split(",") if w]  # counters that must have moved
-    done = run_parity(env_id, None, n=n, steps=steps, want_counters=want, check_every=2)  # (frames every other step)
+    done = run_parity(env_id, None, n=n, steps=steps, want_counters=want)
     print("ok: %s, %d instances x %d steps, %d episodes ended" % (env_id, n, steps, done))

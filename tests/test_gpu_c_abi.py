@@ -17,8 +17,8 @@ def build_binary():
     return __graft_entry__.build_c_abi_test()
 
 
-@pytest.mark.parametrize("env_id,steps,groups", [("MortarMayhem-Grid-v0", 60, 1), ("Endless-MysteryPath-v0", 60, 1), ("SearingSpotlights-v0", 50, 1),
-                                                 ("Endless-MortarMayhem-v0", 60, 2)])
+@pytest.mark.parametrize("env_id,steps,groups", [("MortarMayhem-Grid-v0", 100, 1), ("Endless-MysteryPath-v0", 100, 1), ("SearingSpotlights-v0", 90, 1),
+                                                 ("Endless-MortarMayhem-v0", 100, 2)])
 def test_c_host_program_matches_the_oracle(env_id, steps, groups):
     exe = build_binary()
     env = dict(os.environ)

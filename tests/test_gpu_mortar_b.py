@@ -58,14 +58,14 @@ FREE_OPTS = [
 @pytest.mark.parametrize("opt_idx", range(len(GRID_OPTS)))
 def test_grid_parity(opt_idx):
     n_done = run_parity("MortarMayhemB-Grid-v0", GRID_OPTS[opt_idx], n=160, steps=260, policy=grid_expert if opt_idx == 0 else None,
-                        n_policy=64, check_every=2)  # (frames every other step; rewards, dones, the one-hot vector every step)
+                        n_policy=64)
     assert n_done > 0
 
 
 @pytest.mark.parametrize("opt_idx", range(len(FREE_OPTS)))
 def test_free_parity(opt_idx):
     n_done = run_parity("MortarMayhemB-v0", FREE_OPTS[opt_idx], n=160, steps=420, policy=free_expert if opt_idx == 0 else None,
-                        n_policy=32, check_every=3)
+                        n_policy=64)
     assert n_done > 0
 
 

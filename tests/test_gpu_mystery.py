@@ -88,21 +88,19 @@ EMP_OPTS = [
 
 @pytest.mark.parametrize("opt_idx", range(len(MP_OPTS)))
 def test_finite_parity(opt_idx):
-    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=540 if opt_idx != 1 else 200, policy=path_follower, n_policy=64,
-                        check_every=1 if opt_idx == 1 else 2)  # (the 540-step runs compare frames every other step, everything else every step)
+    n_done = run_parity("MysteryPath-v0", MP_OPTS[opt_idx], n=160, steps=540 if opt_idx != 1 else 200, policy=path_follower, n_policy=64)
     assert n_done > 0
 
 
 @pytest.mark.parametrize("opt_idx", range(len(GRID_OPTS)))
 def test_grid_parity(opt_idx):
-    n_done = run_parity("MysteryPath-Grid-v0", GRID_OPTS[opt_idx], n=160, steps=300, policy=grid_follower, n_policy=64, check_every=2)
+    n_done = run_parity("MysteryPath-Grid-v0", GRID_OPTS[opt_idx], n=160, steps=300, policy=grid_follower, n_policy=64)
     assert n_done > 0
 
 
 @pytest.mark.parametrize("opt_idx", range(len(EMP_OPTS)))
 def test_endless_parity(opt_idx):
-    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=260, policy=endless_follower, n_policy=64,
-                        check_every=1 if opt_idx == 0 else 2)
+    n_done = run_parity("Endless-MysteryPath-v0", EMP_OPTS[opt_idx], n=160, steps=260, policy=endless_follower, n_policy=64)
     assert n_done > 0
 
 
@@ -217,6 +215,6 @@ def test_endless_full_size_sample():
 @pytest.mark.parametrize("env_id,opts,policy,steps", [("MysteryPath-v0", MP_OPTS[0], path_follower, 1100), ("MysteryPath-Grid-v0", GRID_OPTS[0], grid_follower, 600),
                                                       ("Endless-MysteryPath-v0", EMP_OPTS[0], endless_follower, 700), ("Endless-MysteryPath-v0", EMP_OPTS[1], endless_follower, 700)])
 def test_long_runs(env_id, opts, policy, steps):
-    """MEMGYM_SLOW=1: one long lock-step run per variant, every frame compared (rare paths -- a long episode, owed and new
+    """(marked slow: MEMGYM_FAST=1 leaves it out) one long lock-step run per variant, every frame compared (rare paths -- a long episode, owed and new
     segments falling into one step -- need many steps to occur)."""
     assert run_parity(env_id, opts, n=160, steps=steps, policy=policy, n_policy=64) > 0

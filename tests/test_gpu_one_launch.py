@@ -101,7 +101,7 @@ def test_under_a_concurrent_stream():
     import memory_gym_amd
     import torch
 
-    steps = int(os.environ.get("MEMGYM_SOAK_STEPS", "500"))
+    steps = int(os.environ.get("MEMGYM_SOAK_STEPS", "800"))
     n = 65536
     env = memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=n, device=0)
     idx = np.unique(np.concatenate([np.arange(0, 64), np.arange(n - 64, n), np.random.Generator(np.random.PCG64(5)).integers(0, n, 64)]))

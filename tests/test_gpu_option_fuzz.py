@@ -20,14 +20,14 @@ def test_random_option_sets(env_id, gen):
     import memory_gym_amd
 
     # MEMGYM_FUZZ_TRIALS / MEMGYM_FUZZ_SEED: one-off hunts with more and other draws
-    trials = int(os.environ.get("MEMGYM_FUZZ_TRIALS", "5"))
+    trials = int(os.environ.get("MEMGYM_FUZZ_TRIALS", "6"))
     rng = np.random.Generator(np.random.PCG64(sum(map(ord, env_id)) + int(os.environ.get("MEMGYM_FUZZ_SEED", "0"))))
     tried = 0
     for trial in range(trials):
         options = gen(rng, env_id)
         try:  # ranges the build rejects raise from both sides alike; skip those draws (they are errors, not mismatches)
             memory_gym_amd.reset_params.process_reset_params(env_id, options)
-            run_parity(env_id, options, n=64, steps=140, seed0=11 + trial, check_every=2)
+            run_parity(env_id, options, n=64, steps=140, seed0=11 + trial)
         except NotImplementedError:
             continue
         tried += 1

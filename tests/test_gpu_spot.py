@@ -228,5 +228,5 @@ def test_reset_spotlights_from_one_batch_of_outputs(env_id, count):
 @pytest.mark.parametrize("env_id,opts,steps", [("Endless-SearingSpotlights-v0", ESS_OPTS[0], 700), ("Endless-SearingSpotlights-v0", ESS_OPTS[1], 700),
                                                ("SearingSpotlights-v0", SS_OPTS[0], 600), ("SearingSpotlights-v0", SS_OPTS[1], 600)])
 def test_long_runs(env_id, opts, steps):
-    """MEMGYM_SLOW=1: long lock-step runs, every frame compared (a rejected Lemire draw, long episodes, many spawns)."""
+    """(marked slow: MEMGYM_FAST=1 leaves it out) long lock-step runs, every frame compared (a rejected Lemire draw, long episodes, many spawns)."""
     assert run_parity(env_id, opts, n=160, steps=steps, policy=coin_seeker, n_policy=64) > 0

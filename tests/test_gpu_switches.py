@@ -14,25 +14,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LAB_LIB = os.path.join(os.path.dirname(HERE), "endless-memory-gym_amd", "lib", "lab", "libmemgym_hip_lab.so")
 
 CASES = [
-    ("MEMGYM_EMP_FUSE", "0", "Endless-MysteryPath-v0", 160, 97),          # queue server as a launch of its own
+    ("MEMGYM_EMP_FUSE", "0", "Endless-MysteryPath-v0", 160, 150),          # queue server as a launch of its own
     ("MEMGYM_EMP_RESET_LANES", "0", "Endless-MysteryPath-v0", 1024, 30),    # full reset one wave per instance (lanes: n >= 1,024)
-    ("MEMGYM_EMP_BG_COOP", "0", "Endless-MysteryPath-v0", 640, 78),       # owed segments one per lane of frame workgroups (the default above ~20,000 instances)
+    ("MEMGYM_EMP_BG_COOP", "0", "Endless-MysteryPath-v0", 640, 120),       # owed segments one per lane of frame workgroups (the default above ~20,000 instances)
     # the next episode's first segment ahead of time (the default above ~20,000 instances; it rides on the lane-per-path jobs) ...
-    ("MEMGYM_EMP_BG_COOP=0 MEMGYM_SWITCH_WORKER_WANT=emp_own_resets MEMGYM_EMP_PRE", "1", "Endless-MysteryPath-v0", 640, 130),
-    ("MEMGYM_EMP_BG_COOP=0 MEMGYM_EMP_PRE", "0", "Endless-MysteryPath-v0", 640, 78),  # ... and without it
-    ("MEMGYM_MYSTERY_DEFER", "1", "MysteryPath-v0", 160, 97),              # reset paths inside the raster launch
-    ("MEMGYM_MYSTERY_DEFER", "0", "MysteryPath-Grid-v0", 160, 97),         # ... and not, for the grid variant
-    ("MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 130),    # resets inside the raster launch
-    ("MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 130),            # ... and not, for the finite variant
-    ("MEMGYM_SPOT_RESET_FALLBACK", "3", "Endless-SearingSpotlights-v0", 160, 130),  # every third instance: the reset's spotlights one after another (what a rejected draw falls back to)
-    ("MEMGYM_SPOT_RESET_FALLBACK", "2", "SearingSpotlights-v0", 160, 130),
-    ("MEMGYM_MORTAR_FUSE", "0", "MortarMayhem-Grid-v0", 300, 97),          # step and raster as two launches
-    ("MEMGYM_MORTAR_FUSE", "0", "Endless-MortarMayhem-v0", 300, 97),
+    ("MEMGYM_EMP_BG_COOP=0 MEMGYM_SWITCH_WORKER_WANT=emp_own_resets MEMGYM_EMP_PRE", "1", "Endless-MysteryPath-v0", 640, 200),
+    ("MEMGYM_EMP_BG_COOP=0 MEMGYM_EMP_PRE", "0", "Endless-MysteryPath-v0", 640, 120),  # ... and without it
+    ("MEMGYM_MYSTERY_DEFER", "1", "MysteryPath-v0", 160, 150),              # reset paths inside the raster launch
+    ("MEMGYM_MYSTERY_DEFER", "0", "MysteryPath-Grid-v0", 160, 150),         # ... and not, for the grid variant
+    ("MEMGYM_SPOT_FUSE", "1", "Endless-SearingSpotlights-v0", 160, 200),    # resets inside the raster launch
+    ("MEMGYM_SPOT_FUSE", "0", "SearingSpotlights-v0", 160, 200),            # ... and not, for the finite variant
+    ("MEMGYM_SPOT_RESET_FALLBACK", "3", "Endless-SearingSpotlights-v0", 160, 200),  # every third instance: the reset's spotlights one after another (what a rejected draw falls back to)
+    ("MEMGYM_SPOT_RESET_FALLBACK", "2", "SearingSpotlights-v0", 160, 200),
+    ("MEMGYM_MORTAR_FUSE", "0", "MortarMayhem-Grid-v0", 300, 150),          # step and raster as two launches
+    ("MEMGYM_MORTAR_FUSE", "0", "Endless-MortarMayhem-v0", 300, 150),
     ("MEMGYM_LAB_NONE", "1", "MortarMayhem-Grid-v0", 300, 60),             # the lab build itself, no switch set
 ]
 
 
-# the same cases at the run lengths of rounds 3-4 (x 1.5), behind the slow marker (MEMGYM_SLOW=1): ADVICE r4 -- rare paths need long runs
+# the same cases at the run lengths of rounds 3-4 (x 1.5), marked slow (MEMGYM_FAST=1 leaves them out): ADVICE r4 -- rare paths need long runs
 LONG = [pytest.param(v, val, e, n, (st * 3 + 1) // 2 + 20, marks=pytest.mark.slow, id="long-%s=%s-%s" % (v.split()[-1], val, e)) for v, val, e, n, st in CASES if st >= 70]
 
 
