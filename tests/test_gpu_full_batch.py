@@ -9,10 +9,16 @@ pytestmark = pytest.mark.gpu
 
 # (label, env id, instances, steps, compare frames every, options)
 CONFIGS = [
-    ("C2", "MortarMayhem-Grid-v0", 65536, 48, 12, None),
-    ("C3", "MysteryPath-v0", 32768, 40, 10, dict(max_steps=24)),          # short episodes: thousands of A* resets inside the run
-    ("C4", "Endless-SearingSpotlights-v0", 16384, 60, 15, None),
-    ("C5 per-GPU shard", "Endless-MortarMayhem-v0", 32768, 60, 15, None),
+    ("C2", "MortarMayhem-Grid-v0", 65536, 130, 26, None),
+    ("C3", "MysteryPath-v0", 32768, 120, 20, dict(max_steps=24)),          # short episodes: thousands of A* resets inside the run
+    ("C4", "Endless-SearingSpotlights-v0", 16384, 240, 30, None),
+    ("C5 per-GPU shard", "Endless-MortarMayhem-v0", 32768, 160, 32, None),
+    # the ids that are in no BASELINE config, at the sizes bench.py measures them ("other_workloads"); Endless-MysteryPath long enough
+    # for several episodes per instance: lazy segments, records ahead of time and the instances' own resets on every instance
+    ("Endless-MysteryPath", "Endless-MysteryPath-v0", 32768, 300, 30, None),
+    ("SearingSpotlights", "SearingSpotlights-v0", 16384, 200, 25, dict(max_steps=40)),      # (every instance is reset inside the raster launch)
+    ("MysteryPath-Grid", "MysteryPath-Grid-v0", 32768, 120, 20, dict(max_steps=24)),
+    ("MortarMayhem", "MortarMayhem-v0", 32768, 160, 32, None),
 ]
 
 
@@ -54,7 +60,7 @@ def test_every_instance(label, env_id, n, steps, every, options):
         n_done += int(dg.sum())
         if check:
             frames_equal("at step %d" % t)
-    for i in (0, 1, n // 2, 14335, 14336, n - 2, n - 1):  # around the persistent grid's size and at both ends
+    for i in (0, 1, n // 2, min(14335, n - 1), min(14336, n - 1), n - 2, n - 1):  # around the persistent grid's size and at both ends
         assert np.array_equal(env.rng_words(i), ref.envs[i].rng_words()), "%s: RNG words of instance %d" % (label, i)
     assert n_done > 0
     env.check_errors()

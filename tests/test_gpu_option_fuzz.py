@@ -20,7 +20,7 @@ def test_random_option_sets(env_id, gen):
     import memory_gym_amd
 
     # MEMGYM_FUZZ_TRIALS / MEMGYM_FUZZ_SEED: one-off hunts with more and other draws
-    trials = int(os.environ.get("MEMGYM_FUZZ_TRIALS", "6"))
+    trials = int(os.environ.get("MEMGYM_FUZZ_TRIALS", "10"))
     rng = np.random.Generator(np.random.PCG64(sum(map(ord, env_id)) + int(os.environ.get("MEMGYM_FUZZ_SEED", "0"))))
     tried = 0
     for trial in range(trials):
