@@ -109,6 +109,33 @@ __global__ __launch_bounds__(256) void store_probe_frames_kernel(u32x4* out, int
     }
 }
 
+// Pattern 2 (lab: tools/store_shapes.py): the frame walk with each lane writing PAIRS of adjacent vectors (32 contiguous bytes per lane:
+// a linear sweep of that kind is as fast as one vector per thread, profiles/r01g_store_patterns.md) -- three store rounds per frame
+// instead of six.  Pattern 3: pairs, and the workgroup's four waves write contiguous quarters of the frame.
+__global__ __launch_bounds__(256) void store_probe_frames_pairs_kernel(u32x4* out, int n, int wave_quarters) {
+    extern __shared__ unsigned char occupancy_pad[];
+    const int tid = threadIdx.x;
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        u32x4* dst = out + (size_t)f * 1323;
+        if (!wave_quarters) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int v = 2 * tid + 512 * j;
+                if (v < 1323) dst[v] = (u32x4)(0u);
+                if (v + 1 < 1323) dst[v + 1] = (u32x4)(0u);
+            }
+        } else {
+            const int w = tid >> 6, lane = tid & 63, lo = w * 332, hi = w == 3 ? 1323 : lo + 332;  // 332 vectors per wave (even)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int v = lo + 2 * lane + 128 * j;
+                if (v < hi) dst[v] = (u32x4)(0u);
+                if (v + 1 < hi) dst[v + 1] = (u32x4)(0u);
+            }
+        }
+    }
+}
+
 // Virtual ranges are NEVER handed back to the runtime.  Measured on ROCm 7.2 / MI355X (tools/vmm_stress.py, profiles/
 // r02_zones.md): when a range freed with hipMemAddressFree is reserved again and mapped onto other physical memory, stores
 // through it can land in the OLD physical pages (5 of 80 allocate-fill-verify-free cycles read back wrong, up to 95 % of a
@@ -330,16 +357,19 @@ int mg_obs_set_search_ms(double ms) {
 
 // bench.py's per-box control (see store_probe_*_kernel): one launch of `pattern` over n_frames x 21,168 bytes at `buf`, on `stream`.
 int mg_store_probe(void* buf, size_t n_frames, int pattern, hipStream_t stream) {
-    if (!buf || n_frames == 0 || n_frames > (1u << 30) || (pattern != 0 && pattern != 1)) {
+    if (!buf || n_frames == 0 || n_frames > (1u << 30) || pattern < 0 || pattern > 3) {
         mg::set_error("mg_store_probe: bad arguments");
         return -1;
     }
     if (pattern == 0) {
         const size_t nvec = n_frames * 1323;
         hipLaunchKernelGGL(store_probe_linear_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, stream, (u32x4*)buf, nvec);
-    } else {
+    } else if (pattern == 1) {
         const int grid = (int)std::min<size_t>(n_frames, PROBE_GRID);
         hipLaunchKernelGGL(store_probe_frames_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames);
+    } else {
+        const int grid = (int)std::min<size_t>(n_frames, PROBE_GRID);
+        hipLaunchKernelGGL(store_probe_frames_pairs_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames, pattern == 3 ? 1 : 0);
     }
     if (hipGetLastError() != hipSuccess) {
         mg::set_error("mg_store_probe: launch failed");

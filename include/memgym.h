@@ -281,7 +281,9 @@ int mg_obs_set_search_ms(double ms);  /* process-wide; >= 0 */
  * n_frames x 21,168 bytes at obs_dev on `stream`; the caller times it with events.  pattern 0 = linear fill, one 16-byte
  * store per thread (the memory system's ceiling for stores at this size and placement); pattern 1 = the raster's store
  * shape without compose work (persistent 256-lane workgroups writing whole frames; the raster's grid and residency) = the
- * ceiling of a frame-shaped stream.  Overwrites the buffer with zeros. */
+ * ceiling of a frame-shaped stream; patterns 2 / 3 = other frame-shaped streams measured in round 5 (pairs of adjacent vectors per
+ * lane; pairs + each wave a contiguous quarter of the frame: tools/store_shapes.py, profiles/r05_store_shapes.md).  Overwrites the
+ * buffer with zeros. */
 int mg_store_probe(void* obs_dev, size_t n_frames, int pattern, hipStream_t stream);
 /* Test hook: live buffers, pooled spare pieces, bytes of virtual address space reserved so far. */
 int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* reserved_va_bytes);
