@@ -217,10 +217,37 @@ class VecMemoryGym:
         self._seeded = False  # no instance has an RNG stream before the first reset (or load_state_dict)
         self._swapped = False  # use_obs_buffer() since the last call that wrote every row
         self._truncated = torch.zeros(N, dtype=torch.bool, device=dev)  # `truncation` is always False in the reference
+        self._n_actions = self.num_envs * self.action_dim
+        self._p_err = C.byref(self._err)
+        self._bind_step()
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self._raw_stream())
+
+    def _raw_stream(self):
+        """torch's CURRENT stream of the handle's device as a raw hipStream_t (it is looked up at every call: the caller may be inside
+        `with torch.cuda.stream(...)`)."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self.device.index)  # (~0.2 us; the public accessor builds a Stream object: ~2 us)
+        except AttributeError:
+            return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _bind_step(self):
+        """The arguments of mg_step that do not change from call to call, resolved once (pointers of the output tensors, the info
+        dictionary): at a few thousand instances a step lasts 20-30 us on the GPU and the host side of step() was as long
+        (round 5).  use_obs_buffer / use_step_buffers call it again."""
+        self._p_reward = self.reward.data_ptr()
+        self._p_done = self.done_u8.data_ptr()
+        self._p_gt = self.gt.data_ptr() if self.gt_dim else None
+        self._p_info = C.byref(self._info)
+        self._done_bool = self.done_u8.view(torch.bool)
+        info = {"done_mask": self._done_bool, "reward": self.ep_reward, "length": self.ep_length}
+        for nm, t in zip(self.info_names, self.aux):
+            info[nm] = t
+        if self.gt_dim:
+            info["ground_truth"] = self.gt if self.gt64 is None else self.gt64
+        self._info_dict = info
 
     def _write_set(self, set_id, params):
         """Bring option set `set_id` of the handle to `params` (only the keys that differ from what it holds are sent)."""
@@ -349,26 +376,30 @@ class VecMemoryGym:
         return self._obs(), info
 
     def step(self, actions):
-        with torch.cuda.device(self.device):
-            a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int32 and a.device == self.device and a.is_contiguous()):
+            a = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
             a = a.to(device=self.device, dtype=torch.int32).contiguous()
-            assert a.numel() == self.num_envs * self.action_dim, "actions must have shape [N] or [N, 2]"
-            _native.check(_native.LIB.mg_step(self._h, a.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
-                                              self.done_u8.data_ptr(), self.gt.data_ptr() if self.gt_dim else None,
-                                              C.byref(self._info), int(self.autoreset), self._stream()), "mg_step")
-            self._swapped = False  # a step writes every row
-        _native.LIB.mg_peek_errors(self._h, C.byref(self._err))  # host-mapped word: no synchronisation
+        assert a.numel() == self._n_actions, "actions must have shape [N] or [N, 2]"
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                self._launch_step(a)
+        else:
+            self._launch_step(a)
+        self._swapped = False  # a step writes every row
+        _native.LIB.mg_peek_errors(self._h, self._p_err)  # host-mapped word: no synchronisation
         if self._err.value:
             self.check_errors()
-        done = self.done_u8.view(torch.bool)
-        info = {"done_mask": done, "reward": self.ep_reward, "length": self.ep_length}
-        for nm, t in zip(self.info_names, self.aux):
-            info[nm] = t
-        if self.gt_dim:
-            info["ground_truth"] = self.gt if self.gt64 is None else self.gt64
+        info = dict(self._info_dict)
         if self.final_obs is not None and self.autoreset:  # rows valid where done_mask is set
             info["final_observation"] = self.final_obs
-        return self._obs(), self.reward, done, self._truncated, info
+        return self._obs(), self.reward, self._done_bool, self._truncated, info
+
+    def _launch_step(self, a):
+        rc = _native.LIB.mg_step(self._h, a.data_ptr(), self.obs.data_ptr(), self._p_reward, self._p_done, self._p_gt, self._p_info,
+                                 1 if self.autoreset else 0, self._raw_stream())
+        if rc != 0:
+            _native.check(rc, "mg_step")
 
     def new_obs_buffer(self):
         """A second observation buffer like `obs` (same shape, dtype, device and -- if `obs` came from mg_obs_alloc -- the same
@@ -391,6 +422,7 @@ class VecMemoryGym:
             raise ValueError("use_obs_buffer: need a contiguous tensor like env.obs")
         self.obs = tensor
         self._swapped = True
+        self._bind_step()
 
     def use_step_buffers(self, reward, done_u8):
         """Make `reward` (float32 [N]) and `done_u8` (uint8 [N]) the tensors the NEXT step stores its rewards / dones into (mg_step
@@ -402,6 +434,7 @@ class VecMemoryGym:
         if reward.data_ptr() % 4:
             raise ValueError("use_step_buffers: the reward tensor must be 4-byte aligned")
         self.reward, self.done_u8 = reward, done_u8
+        self._bind_step()
 
     def _obs(self):
         if self.vector_obs is None:
