@@ -32,8 +32,10 @@ CASES = [
 ]
 
 
-# the same cases at the run lengths of rounds 3-4 (x 1.5), marked slow (MEMGYM_FAST=1 leaves them out): ADVICE r4 -- rare paths need long runs
-LONG = [pytest.param(v, val, e, n, (st * 3 + 1) // 2 + 20, marks=pytest.mark.slow, id="long-%s=%s-%s" % (v.split()[-1], val, e)) for v, val, e, n, st in CASES if st >= 70]
+# the same cases 1.5 x as long (rare paths need long runs) -- each one more fresh process, i.e. one more `import torch`
+# (half a minute on a box with slow storage), so they are opt-in: MEMGYM_LONG_SWITCHES=1
+LONG = [pytest.param(v, val, e, n, (st * 3 + 1) // 2 + 20, marks=pytest.mark.slow, id="long-%s=%s-%s" % (v.split()[-1], val, e))
+        for v, val, e, n, st in CASES if st >= 70] if os.environ.get("MEMGYM_LONG_SWITCHES") else []
 
 
 @pytest.mark.parametrize("var,value,env_id,n,steps", CASES + LONG)
