@@ -19,6 +19,8 @@ CONFIGS = [
     ("SearingSpotlights", "SearingSpotlights-v0", 16384, 200, 25, dict(max_steps=40)),      # (every instance is reset inside the raster launch)
     ("MysteryPath-Grid", "MysteryPath-Grid-v0", 32768, 120, 20, dict(max_steps=24)),
     ("MortarMayhem", "MortarMayhem-v0", 32768, 160, 32, None),
+    ("MortarMayhemB-Grid", "MortarMayhemB-Grid-v0", 32768, 100, 25, None),  # (Dict observation: the visual part here, the one-hot vector in test_gpu_mortar_b.py)
+    ("MortarMayhemB", "MortarMayhemB-v0", 16384, 100, 25, None),
 ]
 
 
@@ -42,7 +44,11 @@ def test_every_instance(label, env_id, n, steps, every, options):
             bad = np.nonzero((got != want).reshape(n, -1).any(1))[0]
             raise AssertionError("%s %s: %d of %d frames differ %s; first instances %s" % (label, env_id, len(bad), n, where, bad[:10]))
 
+    def visual(o):
+        return o["visual_observation"] if isinstance(o, dict) else o
+
     obs, _ = env.reset(seed=seeds, options=options)
+    obs = visual(obs)
     ref.reset(seeds, out=want)
     frames_equal("after reset")
     g = torch.Generator(device="cuda").manual_seed(17)
@@ -51,6 +57,7 @@ def test_every_instance(label, env_id, n, steps, every, options):
     for t in range(steps):
         a = torch.randint(0, 4 if disc else 3, (n,) if disc else (n, 2), device="cuda", generator=g, dtype=torch.int32)
         obs, r, d, _, _ = env.step(a)
+        obs = visual(obs)
         check = (t + 1) % every == 0 or t == steps - 1
         ref.step(a.cpu().numpy(), autoreset=True, want_obs=check, out=(want, rew, done))
         dg = d.cpu().numpy()
