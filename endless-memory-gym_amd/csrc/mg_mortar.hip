@@ -901,6 +901,18 @@ class MortarFamily : public Family {
     }
     int peek_errors() override { return err_.peek(); }
     bool debug_counter(const std::string& name, int64_t* out) override {
+        if (name == "cmd_list_max" || name == "cmd_list_ge12") {  // the instances' command lists as they stand (a scan of the state records)
+            std::vector<MortarState> h(n_);
+            MG_HIP(hipDeviceSynchronize());
+            MG_HIP(hipMemcpy(h.data(), state_.p, sizeof(MortarState) * (size_t)n_, hipMemcpyDeviceToHost));
+            int64_t mx = 0, ge = 0;
+            for (const MortarState& s : h) {
+                mx = s.num_cmds > mx ? s.num_cmds : mx;
+                ge += s.num_cmds >= 12;
+            }
+            *out = name == "cmd_list_max" ? mx : ge;
+            return true;
+        }
         if (name != "one_launch_rescues") return false;  // 64-instance slots stepped by a frame wave since the handle was created
         uint32_t v = 0;
         MG_HIP(hipMemcpy(&v, rescues_.p, sizeof v, hipMemcpyDeviceToHost));

@@ -2367,6 +2367,19 @@ class MysteryFamily : public Family {
     }
     int peek_errors() override { return err_.peek(); }
     bool debug_counter(const std::string& name, int64_t* out) override {
+        if (name == "emp_segments_sum" || name == "emp_segments_max" || name == "emp_falloff_max") {  // a scan of the state records as they stand
+            std::vector<MysteryCore> h(n_);
+            MG_HIP(hipDeviceSynchronize());
+            MG_HIP(hipMemcpy(h.data(), core_.p, sizeof(MysteryCore) * (size_t)n_, hipMemcpyDeviceToHost));
+            int64_t sum = 0, mx = 0, fmx = 0;
+            for (const MysteryCore& c : h) {  // (segments generated so far; the ones still owed, EMP_OWED, are not counted)
+                sum += c.num_seg;
+                mx = c.num_seg > mx ? c.num_seg : mx;
+                fmx = c.n_falloff > fmx ? c.n_falloff : fmx;
+            }
+            *out = name == "emp_segments_sum" ? sum : (name == "emp_segments_max" ? mx : fmx);
+            return true;
+        }
         const int k = name == "path_gen_ticks" ? 0 : (name == "path_gen_paths" ? 1 : (name == "emp_own_resets" ? 2 : (name == "emp_ahead_records" ? 3 : -1)));
         if (k < 0 || !stats_.p) return false;
         unsigned long long v = 0;

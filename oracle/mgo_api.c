@@ -195,6 +195,44 @@ void mgo_batch_step(mgo_batch* b, const int32_t* actions, int autoreset, uint8_t
     }
 }
 
+/* The test's POLICY for lock-step runs under competent play (mgo_vtbl.expert): instance i plays its expert action, or -- with
+ * probability eps -- a uniformly random one.  The random numbers are a counter-based hash of (seed, step, i): they belong to
+ * the test, not to any instance's stream.  actions: int32 [n] (Discrete) or [n][2]. */
+static uint64_t mgo_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+int mgo_batch_expert(mgo_batch* b, double eps, uint64_t seed, uint64_t step, int32_t* actions) {
+    int disc = b->envs[0]->vt->discrete;
+    if (!b->envs[0]->vt->expert) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < b->n; i++) {
+        int a[2] = {0, 0};
+        uint64_t h = mgo_mix64(mgo_mix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (uint64_t)i);
+        if ((double)(h >> 11) * (1.0 / 9007199254740992.0) < eps) {
+            uint64_t h2 = mgo_mix64(h);
+            a[0] = (int)(h2 % (disc ? 4 : 3));
+            a[1] = disc ? 0 : (int)((h2 >> 20) % 3);
+        } else {
+            b->envs[i]->vt->expert(b->envs[i], a);
+        }
+        if (disc) actions[i] = a[0];
+        else { actions[2 * i] = a[0]; actions[2 * i + 1] = a[1]; }
+    }
+    return 0;
+}
+/* one named state field of every instance (mgo_get), for the run's statistics; NaN where the field does not apply */
+void mgo_batch_get(mgo_batch* b, const char* field, double* out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < b->n; i++) {
+        int ok = 0;
+        double v = b->envs[i]->vt->get(b->envs[i], field, &ok);
+        out[i] = ok ? v : NAN;
+    }
+}
+
 /* Test hook (tests/test_oracle_properties.py): pygame.draw.circle(surface, white, (cx, cy), radius, width) on a black dim x dim
  * surface; out[y * dim + x] = 1 where a pixel was drawn. */
 int mgo_test_circle(int dim, int cx, int cy, int radius, int width, uint8_t* out) {

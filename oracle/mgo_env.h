@@ -197,6 +197,11 @@ typedef struct mgo_vtbl {
      * family's own _draw_surfaces code.  Used to replay recordings of OTHER revisions of the reference frame by frame:
      * their dynamics differ, the drawing of a given scene does not.  NULL: not offered.  Requires one reset. */
     int (*scene)(struct mgo_env*, const double* v, int n);
+    /* Test hook (tests/test_gpu_full_batch.py, policy axis): a COMPETENT action for the instance's current state -- follow the
+     * command list / the path / go for the coins and the exit -- so that lock-step runs reach the states only a trained agent
+     * sees (long command lists, appended path segments, opened exits).  Deterministic, reads nothing but the instance's state,
+     * draws nothing from its stream.  Not part of the reference: it is the test's policy, computed where the state is. */
+    void (*expert)(struct mgo_env*, int action[2]);
 } mgo_vtbl;
 
 typedef struct mgo_env {

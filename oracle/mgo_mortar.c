@@ -543,12 +543,39 @@ static void mm_destroy(mgo_env* e) {
     free(m);
 }
 
+/* expert hook (mgo_env.h): wait while commands are shown and while the tiles are on, else move to the target tile */
+static void mm_expert(mgo_env* e, int a[2]) {
+    mm_t* m = (mm_t*)e->impl;
+    a[0] = a[1] = 0;
+    if (mm_vis_nonempty(m) || m->tiles_on) return;
+    if (MM_IS_GRID(m->variant)) {
+        int nx = m->agent.gx, ny = m->agent.gy, rot = m->agent.rotation;
+        if (nx == m->tx && ny == m->ty) return;
+        int want = m->tx > nx ? 270 : (m->tx < nx ? 90 : (m->ty < ny ? 0 : 180));
+        if (rot == want) { a[0] = 3; return; }
+        int d = ((want - rot) % 360 + 360) % 360;
+        a[0] = (d == 90 || d == 180) ? 1 : 2;
+        return;
+    }
+    int cx = (int)(m->arena_rect.x + m->tile_dim * m->tx + floor(m->tile_dim / 2));
+    int cy = (int)(m->arena_rect.y + m->tile_dim * m->ty + floor(m->tile_dim / 2));
+    int dx = cx - mgo_rect_cx(&m->agent.rect), dy = cy - mgo_rect_cy(&m->agent.rect);
+    if (m->variant == MM_ENDLESS) { /* the arena wraps: the shorter way round */
+        int w = e->screen_dim, h = w / 2;
+        dx = ((dx + h) % w + w) % w - h;
+        dy = ((dy + h) % w + w) % w - h;
+    }
+    int slack = (int)m->agent.speed;
+    a[0] = abs(dx) < slack ? 0 : (dx < 0 ? 1 : 2);
+    a[1] = abs(dy) < slack ? 0 : (dy < 0 ? 1 : 2);
+}
+
 static const mgo_vtbl MM_VT[5] = {
-    {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
-    {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
-    {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
-    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
-    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene},
+    {"MortarMayhem-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene, mm_expert},
+    {"MortarMayhem-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene, mm_expert},
+    {"Endless-MortarMayhem-v0", 0, 2, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene, mm_expert},
+    {"MortarMayhemB-Grid-v0", 1, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene, mm_expert},
+    {"MortarMayhemB-v0", 0, 0, mm_set_option, mm_reset, mm_step, mm_get, mm_get_list, mm_destroy, mm_debug, mm_scene, mm_expert},
 };
 
 int mgo_mortar_create(mgo_env* e, int variant) {

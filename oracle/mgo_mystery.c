@@ -704,10 +704,44 @@ static void mp_destroy(mgo_env* e) {
     free(m);
 }
 
+/* expert hooks (mgo_env.h): follow the path */
+static int mp_toward(int d) { return d == 0 ? 0 : (d < 0 ? 1 : 2); }
+static void mpf_expert(mgo_env* e, int a[2]) {
+    mp_t* m = (mp_t*)e->impl;
+    a[0] = a[1] = 0;
+    int idx = -1;
+    for (int i = 0; i < m->path_len; i++)
+        if (m->path[i].x == m->norm_x && m->path[i].y == m->norm_y) { idx = i; break; }
+    if (idx <= 0) return; /* off the path (the next step puts the agent back) or on the goal */
+    const pnode* nx = &m->path[idx - 1]; /* end-first list */
+    if (m->grid) {
+        int dx = nx->x - m->norm_x, dy = nx->y - m->norm_y, rot = m->agent.rotation;
+        int want = dx > 0 ? 270 : (dx < 0 ? 90 : (dy < 0 ? 0 : 180));
+        if (rot == want) { a[0] = 3; return; }
+        int d = ((want - rot) % 360 + 360) % 360;
+        a[0] = (d == 90 || d == 180) ? 1 : 2;
+        return;
+    }
+    int half = (int)floor(m->tile_dim / 2);
+    a[0] = mp_toward((int)(nx->x * m->tile_dim) + half - mgo_rect_cx(&m->agent.rect));
+    a[1] = mp_toward((int)(nx->y * m->tile_dim) + half - mgo_rect_cy(&m->agent.rect));
+}
+static void emp_expert(mgo_env* e, int a[2]) {
+    mp_t* m = (mp_t*)e->impl;
+    a[0] = a[1] = 0;
+    int k = m->cur_node, td = (int)m->tile_dim;
+    if (m->off || k + 1 >= m->epath_len) return;
+    int dx = m->epath[k + 1].x * td + td / 2 - mgo_rect_cx(&m->agent.rect);
+    int dy = m->epath[k + 1].y * td + td / 2 - mgo_rect_cy(&m->agent.rect);
+    if (dy < 0) a[0] = 2;
+    else if (dy > 0) a[0] = 3;
+    else if (dx > 0) a[0] = 1;
+}
+
 static const mgo_vtbl MP_VT[3] = {
-    {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug, mpf_scene},
-    {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy, emp_debug, NULL},
-    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug, mpf_scene},
+    {"MysteryPath-v0", 0, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug, mpf_scene, mpf_expert},
+    {"Endless-MysteryPath-v0", 1, 3, mp_set_option, emp_reset, emp_step, mp_get, mp_get_list, mp_destroy, emp_debug, NULL, emp_expert},
+    {"MysteryPath-Grid-v0", 1, 0, mp_set_option, mpf_reset, mpf_step, mp_get, mp_get_list, mp_destroy, mpf_debug, mpf_scene, mpf_expert},
 };
 
 int mgo_mystery_create(mgo_env* e, int variant) {

@@ -767,9 +767,32 @@ static void sp_destroy(mgo_env* e) {
     free(p);
 }
 
+/* expert hook (mgo_env.h): the (first remaining) coin, then the exit */
+static void sp_expert(mgo_env* e, int a[2]) {
+    sp_t* p = (sp_t*)e->impl;
+    int tx, ty;
+    a[0] = a[1] = 0;
+    if (p->endless) {
+        if (!p->coin_enabled) return;
+        tx = p->coin_x[0];
+        ty = p->coin_y[0];
+    } else if (p->num_coins > 0 && p->n_coins > 0) {
+        tx = p->coin_x[0];
+        ty = p->coin_y[0];
+    } else if (p->use_exit) {
+        tx = p->exit_x;
+        ty = p->exit_y;
+    } else {
+        return;
+    }
+    int dx = tx - mgo_rect_cx(&p->agent.rect), dy = ty - mgo_rect_cy(&p->agent.rect), slack = (int)p->agent.speed;
+    a[0] = abs(dx) < slack ? 0 : (dx < 0 ? 1 : 2);
+    a[1] = abs(dy) < slack ? 0 : (dy < 0 ? 1 : 2);
+}
+
 static const mgo_vtbl SP_VT[2] = {
-    {"SearingSpotlights-v0", 0, 0, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug, sp_scene},
-    {"Endless-SearingSpotlights-v0", 0, 4, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug, sp_scene},
+    {"SearingSpotlights-v0", 0, 0, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug, sp_scene, sp_expert},
+    {"Endless-SearingSpotlights-v0", 0, 4, sp_set_option, sp_reset, sp_step, sp_get, sp_get_list, sp_destroy, sp_debug, sp_scene, sp_expert},
 };
 
 int mgo_spot_create(mgo_env* e, int variant) {

@@ -47,6 +47,8 @@ def lib():
         L.mgo_batch_set_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.mgo_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mgo_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mgo_batch_expert.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.mgo_batch_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -167,6 +169,19 @@ class OracleBatch:
         if self.h:
             self.L.mgo_batch_destroy(self.h)
             self.h = None
+
+    def expert_actions(self, eps, seed, step, out=None):
+        """The test's policy (oracle/mgo_api.c mgo_batch_expert): every instance's competent action for its CURRENT state, a
+        uniformly random one with probability eps; int32 [n] or [n, 2]."""
+        a = np.empty((self.n,) if self.discrete else (self.n, 2), np.int32) if out is None else out
+        assert self.L.mgo_batch_expert(self.h, float(eps), int(seed), int(step), a.ctypes.data) == 0, "this family has no expert"
+        return a
+
+    def get_all(self, field):
+        """float64 [n]: one state field of every instance (NaN where it does not apply)"""
+        out = np.empty(self.n, np.float64)
+        self.L.mgo_batch_get(self.h, field.encode(), out.ctypes.data)
+        return out
 
     def reset(self, seeds=None, out=None):
         """`out`: a preallocated uint8 [n, dim, dim, 3] array to write the frames into (no allocation per call)."""

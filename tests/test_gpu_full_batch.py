@@ -1,7 +1,14 @@
 """GPU (-m gpu): EVERY instance of the BASELINE.json configurations against the CPU oracle -- rewards and dones after every
 step, all frames every few steps and at the end -- so that a mis-indexed tail workgroup or a wrong grid stride beyond
 the first few thousand instances cannot hide (round 1 compared 6-7 sampled instances at these sizes).  Instance i is
-seeded i; uniform random actions; same-step auto-reset on both sides."""
+seeded i; same-step auto-reset on both sides.  Two policies: uniform random actions (`test_every_instance`), under which
+episodes are short and shallow (three of four MortarMayhem-Grid episodes die at the first verification), and COMPETENT play
+(`test_every_instance_competent`, round 6: the oracle's expert action for every instance's current state, a random one with
+probability 0.1) -- ten-command successes, command lists of a dozen entries, path segments appended far beyond the initial
+three, opened exits -- on the launch arrangements that only exist at these sizes.  What the competent runs reached is asserted
+from the HIP side: the end-of-episode info the kernels wrote and mg_debug_counter scans of the device's state records."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,8 +31,9 @@ CONFIGS = [
 ]
 
 
-@pytest.mark.parametrize("label,env_id,n,steps,every,options", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_every_instance(label, env_id, n, steps, every, options):
+def _lock_step(label, env_id, n, steps, every, options, eps=None, stats=None):
+    """eps None: uniform random actions drawn on the device; else the oracle's expert actions with eps random ones.  `stats`:
+    a dict the run fills from the HIP side's end-of-episode info (sums / maxima over the finished episodes) and its counters."""
     import memory_gym_amd
     import oracle_lib
     import torch
@@ -41,6 +49,7 @@ def test_every_instance(label, env_id, n, steps, every, options):
         host.copy_(obs)
         got = host.numpy()
         if not np.array_equal(got, want):
+            env.check_errors()  # a capacity error flagged by the kernels explains a mismatch better than pixels do
             bad = np.nonzero((got != want).reshape(n, -1).any(1))[0]
             raise AssertionError("%s %s: %d of %d frames differ %s; first instances %s" % (label, env_id, len(bad), n, where, bad[:10]))
 
@@ -53,23 +62,88 @@ def test_every_instance(label, env_id, n, steps, every, options):
     frames_equal("after reset")
     g = torch.Generator(device="cuda").manual_seed(17)
     disc = env.action_dim == 1
+    a_host = np.empty((n,) if disc else (n, 2), np.int32)
     n_done = 0
+    acc = {}
     for t in range(steps):
-        a = torch.randint(0, 4 if disc else 3, (n,) if disc else (n, 2), device="cuda", generator=g, dtype=torch.int32)
-        obs, r, d, _, _ = env.step(a)
+        if eps is None:
+            a = torch.randint(0, 4 if disc else 3, (n,) if disc else (n, 2), device="cuda", generator=g, dtype=torch.int32)
+            a_np = a.cpu().numpy()
+        else:
+            a_np = ref.expert_actions(eps, 4711, t, out=a_host)
+            a = torch.from_numpy(a_np).to("cuda")
+        obs, r, d, _, info = env.step(a)
         obs = visual(obs)
         check = (t + 1) % every == 0 or t == steps - 1
-        ref.step(a.cpu().numpy(), autoreset=True, want_obs=check, out=(want, rew, done))
+        ref.step(a_np, autoreset=True, want_obs=check, out=(want, rew, done))
         dg = d.cpu().numpy()
         assert np.array_equal(dg, done.astype(bool)), "%s: done differs at step %d for instances %s" % (label, t, np.nonzero(dg != done.astype(bool))[0][:10])
         assert np.array_equal(env.reward64.cpu().numpy(), rew), "%s: reward differs at step %d for instances %s" % (
             label, t, np.nonzero(env.reward64.cpu().numpy() != rew)[0][:10])
         n_done += int(dg.sum())
+        if stats is not None and dg.any():  # what the finished episodes reached, as the kernels reported it
+            for name in env.info_names:
+                v = info[name][d].double()
+                s, m = acc.get(name, (0.0, -np.inf))
+                acc[name] = (s + float(v.sum()), max(m, float(v.max())))
         if check:
             frames_equal("at step %d" % t)
     for i in (0, 1, n // 2, min(14335, n - 1), min(14336, n - 1), n - 2, n - 1):  # around the persistent grid's size and at both ends
         assert np.array_equal(env.rng_words(i), ref.envs[i].rng_words()), "%s: RNG words of instance %d" % (label, i)
-    assert n_done > 0
     env.check_errors()
+    if stats is not None:
+        stats["episodes"] = n_done
+        for name, (s, m) in acc.items():
+            stats["sum_" + name], stats["max_" + name] = s, m
+        for name in stats.pop("counters", ()):
+            stats[name] = env.debug_counter(name)
     env.close()
     ref.close()
+    return n_done
+
+
+@pytest.mark.parametrize("label,env_id,n,steps,every,options", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_every_instance(label, env_id, n, steps, every, options):
+    assert _lock_step(label, env_id, n, steps, every, options) > 0
+
+
+# Competent play at the sizes bench.py measures.  (label, env id, instances, steps, compare frames every,
+# options, counters to read at the end, what the HIP side must report having reached)
+COMPETENT = [
+    ("C2", "MortarMayhem-Grid-v0", 65536, 170, 34, None, (),
+     lambda s, n: s["sum_success"] > n // 4),                                           # full ten-command episodes
+    ("C3", "MysteryPath-v0", 32768, 150, 30, None, (),
+     lambda s, n: s["sum_success"] > n),                                                # goals reached along the A* path
+    ("C4", "Endless-SearingSpotlights-v0", 16384, 260, 26, None, (),
+     lambda s, n: s["max_coins_collected"] >= 12 and s["sum_coins_collected"] > 4 * n),
+    ("C5 per-GPU shard", "Endless-MortarMayhem-v0", 32768, 560, 80, None, ("cmd_list_max",),
+     lambda s, n: s["cmd_list_max"] >= 6),                                              # (a dozen entries: the slow variant below)
+    ("Endless-MysteryPath", "Endless-MysteryPath-v0", 32768, 400, 40, None, ("emp_segments_sum", "emp_segments_max"),
+     lambda s, n: s["emp_segments_sum"] > 6 * n and s["emp_segments_max"] >= 10),       # > 3 n segments appended beyond the initial three
+    ("SearingSpotlights", "SearingSpotlights-v0", 16384, 200, 25, None, (),
+     lambda s, n: s["sum_success"] > 2 * n),                                            # every coin, then the opened exit
+    ("MysteryPath-Grid", "MysteryPath-Grid-v0", 32768, 120, 20, None, (),
+     lambda s, n: s["sum_success"] > 4 * n),                                            # ~2,000 finished paths per step: the lane generator inside the raster launch
+    ("MortarMayhem", "MortarMayhem-v0", 32768, 290, 58, None, (),
+     lambda s, n: s["sum_success"] > n // 2),
+]
+
+
+@pytest.mark.parametrize("label,env_id,n,steps,every,options,counters,reached", COMPETENT, ids=[c[0] for c in COMPETENT])
+def test_every_instance_competent(label, env_id, n, steps, every, options, counters, reached):
+    stats = {"counters": counters}
+    assert _lock_step(label, env_id, n, steps, every, options, eps=0.1, stats=stats) > 0 or env_id == "Endless-MysteryPath-v0"
+    assert reached(stats, n), "%s: the competent run stayed shallow: %s" % (label, stats)
+
+
+@pytest.mark.slow
+def test_endless_mortar_lists_of_a_dozen():
+    """Endless-MortarMayhem-v0 at the C5 shard size under competent play until command lists hold a dozen entries and more on over
+    1 % of the instances (endless_mortar_mayhem.py:311-333: every completed list grows by one command and is executed again from the
+    start -- 1,628 steps for the eleven lists before the twelfth with the default timings)."""
+    if os.environ.get("MEMGYM_FAST"):
+        pytest.skip("MEMGYM_FAST")
+    n = 32768
+    stats = {"counters": ("cmd_list_max", "cmd_list_ge12")}
+    _lock_step("C5 long", "Endless-MortarMayhem-v0", n, 1760, 220, None, eps=0.1, stats=stats)
+    assert stats["cmd_list_ge12"] > n // 100 and stats["max_max_command_sequence"] >= 11, stats
