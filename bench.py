@@ -110,6 +110,18 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    """the host CPU's model string next to `cores`"""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(env_id):
     """Single-thread and all-core rate of the CPU oracle on this host, each in its own subprocess so that the OpenMP
     runtime is configured before it loads (OMP_NUM_THREADS / OMP_PROC_BIND)."""
@@ -126,7 +138,7 @@ def cpu_baseline(env_id):
         if cores == 1:
             break
     one, allc = res[1], res[cores]
-    return {"value": allc["value"], "unit": "env steps/s", "cores": cores, "kind": "port",
+    return {"value": allc["value"], "unit": "env steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "cores_note": "usable CPUs = affinity mask (%d) capped by the cgroup CPU quota" % (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores),
             "single_thread": one["value"], "scaling_efficiency": allc["value"] / (cores * one["value"]),
             "sample": "%s, CPU oracle (C, incl. software raster, preallocated buffers): %d instances x %d steps on %d OpenMP "
@@ -160,8 +172,15 @@ def pygame_baseline(env_id, episodes=30):
 
 # ---------------------------------------------------------------------------------------------------------------- one workload
 def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8_xyc", gather=None, events=True, event_stride=8,
-                 count_done=False):
-    """Create the environments, settle, warm up, time K steps; returns a dict (identical on every rank)."""
+                 count_done=False, leg="headline", long_window=0, policy=None):
+    """Create the environments, settle, warm up, time K steps; returns a dict (identical on every rank).
+    long_window: after everything else, one more window of that many steps timed the same way (BASELINE.md section 3 asks for
+    >= 2,000 timed steps whatever K the caller chose) -> "value_long".
+    policy: None = uniform random actions from 64 pre-generated buffers; "follower:EPS" (ids with a ground truth that names the way,
+    Endless-MysteryPath-v0) = the action read off the info["ground_truth"] the previous step returned, a random one with probability
+    EPS -- three small torch kernels per step on the launch stream, INSIDE the timed region like a trainer's policy would be."""
+    if os.environ.get("MEMGYM_BENCH_FAKE"):
+        return fake_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format, gather, events, event_stride, count_done, leg, long_window, policy)
     import torch
     import torch.distributed as dist
 
@@ -192,7 +211,20 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
     if peer is not None:  # the step's rewards / dones (5 B per instance) ride on the collective that orders the streams
         peer.bind_scalars(env)
 
+    follow = None
+    if policy:
+        assert policy.startswith("follower:") and env.gt_dim == 3 and gatherer is None and peer is None, policy
+        eps = float(policy.split(":")[1])
+        way = torch.tensor([1.0, 2.0, 3.0], device=dev)  # ground truth one-hot (right, up, down) -> actions 1, 2, 3
+        rnd = [torch.rand(n_local, device=dev, generator=g) < eps for _ in range(n_act_bufs)]
+        follow = {"gt": env.gt.clone()}  # (reset() above filled env.gt)
+
     def one_step(k):
+        if follow is not None:
+            a = torch.where(rnd[k % n_act_bufs], acts[k % n_act_bufs], (follow["gt"].to(torch.float32) @ way).to(torch.int32))
+            _, _, _, _, info = env.step(a)
+            follow["gt"] = info["ground_truth"]
+            return
         if gatherer is not None:
             gatherer.step(acts[k % n_act_bufs])
             return
@@ -210,6 +242,7 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
 
     for k in range(settle):  # setup: de-synchronise the episodes
         one_step(k)
+    _fault(leg, rank)
     # ... and keep stepping until the rate is flat (C4's first timed window was 5 % below the other five -- 200 steps
     # do not settle every workload): windows of 50 steps until two in a row are within 1 % of their predecessor, at most 20
     settle_windows = []
@@ -297,10 +330,21 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
             box[name] = {"best_GBps": FRAME * n_local / (ms[0] * 1e-3) / 1e9, "median_GBps": FRAME * n_local / (ms[len(ms) // 2] * 1e-3) / 1e9,
                          "best_ms": ms[0], "median_ms": ms[len(ms) // 2]}
         env.step(acts[0])  # (the probes zeroed the observations: one step redraws every frame)
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    # BASELINE.md section 3's stated timing, whatever --steps was: one window of >= 2,000 steps, same event pair, same stream
+    dt_long = 0.0
+    if long_window and not (gather and dist_on):
+        la, lb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        la.record()
+        for k in range(long_window):
+            one_step(settle + W + 7 * K + 32 + k)
+        lb.record()
+        fence()
+        dt_long = la.elapsed_time(lb) * 1e-3
+    t = torch.tensor([dt, dt_long], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max, dt_long = float(t[0].item()), float(t[1].item())
     extra = {}
     path_gen = None
     if path0 is not None:  # (read right behind the timed region: it covers the K timed steps and the five spread windows)
@@ -337,7 +381,12 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
            "settle_windows_ms": settle_windows,
            "ms_per_step": dt_max / K * 1e3, "raster_avg_ms": raster_ms / raster_n if raster_n else None, "raster_launches": raster_n,
            "logic_avg_ms": logic_ms / logic_n if logic_n else None, "event_region": region,
-           "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if dist_on else None, "note": note}
+           "obs_placement": getattr(env, "obs_placement_info", None), "gather": gather if dist_on else None, "note": note,
+           "value_long": ({"value": n_total * long_window / dt_long, "steps": long_window, "seconds": dt_long, "ms_per_step": dt_long / long_window * 1e3,
+                           "timing": "hipEvent pair on the launch stream around the window, max over ranks; right behind the roofline's bracketed steps"}
+                          if dt_long else None)}
+    if policy:
+        out["policy"] = policy
     if gatherer is not None and rank == 0:  # the frames rank 0 received in the last step equal the ranks' own (rank 0's: checked here)
         got, grew, gdone = gatherer.gathered_step()
         k_last = (gatherer.t - 1) & 1
@@ -370,8 +419,11 @@ def secondary_workloads(primary, dev, settle, traffic=True):
               "dominant_kernel": "step + raster in one launch" if not r["logic_avg_ms"] else "raster",
               "frac_dominant_kernel": (entry["raster_GBps"] / HBM_PEAK_GBPS) if entry["raster_GBps"] else None, "traffic": None}
         if r.get("box") and entry["raster_GBps"]:
-            rl["box_ceiling_GBps"] = {"linear_fill": r["box"]["linear_fill"]["median_GBps"], "frame_shaped": r["box"]["frame_shaped"]["median_GBps"]}
-            rl["frac_of_box_ceiling"] = entry["raster_GBps"] / r["box"]["frame_shaped"]["median_GBps"]
+            # the number that bounds stores on this box is the LINEAR fill; the frame-shaped probe is a control (the same store shape
+            # without compose work), not a ceiling: a raster with compose work can beat it
+            rl["frac_of_linear_fill"] = entry["raster_GBps"] / r["box"]["linear_fill"]["median_GBps"]
+            rl["box_probe_GBps"] = {"linear_fill": r["box"]["linear_fill"]["median_GBps"], "frame_probe": r["box"]["frame_shaped"]["median_GBps"]}
+            rl["frac_of_frame_probe"] = entry["raster_GBps"] / r["box"]["frame_shaped"]["median_GBps"]
         if traffic:
             tb, meta = measure_traffic(env_id, r["n_local"])
             rl["traffic"], rl["traffic_source"] = tb, meta.get("source")
@@ -402,23 +454,36 @@ def secondary_workloads(primary, dev, settle, traffic=True):
 
 
 def other_workloads(primary, dev, settle):
-    """The three env ids that are in no BASELINE config (their launches were the ones furthest below the roofline in round 3):
-    same measurement as the secondary workloads, without the PMC child passes (profiles/ holds those); informational."""
+    """Informational entries measured like the secondary workloads, without the PMC child passes (profiles/ holds those):
+    the three env ids that are in no BASELINE config; Endless-MysteryPath-v0 once more under an agent that FOLLOWS its path (round 6:
+    the regime a trained agent puts the library in -- segments appended every few steps, hardly a reset -- next to the random-action
+    one, so that a store flavour or a generator is judged on both); and the headline workload in the two fused float formats
+    (value / 255 in CHW order written by the raster's stream-out instead of a second pass), priced at the bytes they
+    write per instance."""
     out = []
-    for env_id in ("SearingSpotlights-v0", "Endless-MysteryPath-v0", "MysteryPath-Grid-v0"):
-        if env_id == primary:
-            continue
-        r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev)
-        algo = FRAME + DESC_BYTES[env_id]  # algorithmic bytes of the dominant launch per instance-step (frame + descriptor)
-        out.append({"workload": "%s, %d envs" % (env_id, r["n_local"]), "value": r["value"], "unit": "env steps/s", "ms_per_step": r["ms_per_step"],
-                    "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"], "value_windows": r["value_windows"],
-                    "obs_placement_zones": (r["obs_placement"] or {}).get("zones"),
-                    "roofline": {"bytes_per_launch_per_instance": algo, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                 "frac_dominant_kernel": algo * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if r["raster_avg_ms"] else None,
-                                 "frac_whole_step_frame_bytes_only": algo * r["n_local"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 "box_ceiling_GBps": ({"linear_fill": r["box"]["linear_fill"]["median_GBps"], "frame_shaped": r["box"]["frame_shaped"]["median_GBps"]} if r.get("box") else None),
-                                 "frac_of_box_ceiling": (algo * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 / r["box"]["frame_shaped"]["median_GBps"]) if (r.get("box") and r["raster_avg_ms"]) else None,
-                                 "traffic": None, "traffic_note": "not measured in this run: profiles/ holds the PMC passes"}})
+    plan = [(env_id, "u8_xyc", None) for env_id in ("SearingSpotlights-v0", "Endless-MysteryPath-v0", "MysteryPath-Grid-v0") if env_id != primary]
+    plan.append(("Endless-MysteryPath-v0", "u8_xyc", "follower:0.02"))
+    plan += [("MortarMayhem-Grid-v0", "f32_chw", None), ("MortarMayhem-Grid-v0", "bf16_chw", None)]
+    for env_id, fmt, policy in plan:
+        r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev, obs_format=fmt, policy=policy)
+        algo = FRAME * OBS_ELEM[fmt] + DESC_BYTES[env_id]  # algorithmic bytes of the dominant launch per instance-step (frame + descriptor)
+        dom = algo * r["n_local"] / (r["raster_avg_ms"] * 1e-3) / 1e9 if r["raster_avg_ms"] else None
+        rl = {"bytes_per_launch_per_instance": algo, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "dominant_kernel_GBps": dom,
+              "frac_dominant_kernel": dom / HBM_PEAK_GBPS if dom else None,
+              "frac_whole_step_frame_bytes_only": algo * r["n_local"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+              "traffic": None, "traffic_note": "not measured in this run: profiles/ holds the PMC passes"}
+        if r.get("box") and dom:
+            rl["frac_of_linear_fill"] = dom / r["box"]["linear_fill"]["median_GBps"]
+            rl["box_probe_GBps"] = {"linear_fill": r["box"]["linear_fill"]["median_GBps"], "frame_probe": r["box"]["frame_shaped"]["median_GBps"]}
+            rl["frac_of_frame_probe"] = dom / r["box"]["frame_shaped"]["median_GBps"]
+        e = {"workload": "%s, %d envs%s" % (env_id, r["n_local"], "" if fmt == "u8_xyc" else ", observations as %s" % fmt), "obs_format": fmt,
+             "policy": policy or "uniform random", "value": r["value"], "unit": "env steps/s", "ms_per_step": r["ms_per_step"],
+             "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"], "value_windows": r["value_windows"],
+             "obs_placement_zones": (r["obs_placement"] or {}).get("zones"), "roofline": rl}
+        if policy:
+            e["policy_note"] = ("actions from the previous step's info['ground_truth'] (one-hot right / up / down), a random one with probability %s; "
+                                "the policy's three small torch kernels per step run on the launch stream inside the timed region" % policy.split(":")[1])
+        out.append(e)
     return out
 
 
@@ -511,12 +576,201 @@ def measure_traffic(argv_env, n_local):
     return None, meta
 
 
-# ---------------------------------------------------------------------------------------------------------------- launch
-def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU); rank 0 prints the JSON line."""
+
+# ---------------------------------------------------------------------------------------------------------------- the one line
+class LineGuard:
+    """Rank 0 owes the driver exactly ONE JSON line, and an N-GPU run must not be able to end without it (the
+    config-5 legs run behind the headline, and a rank that fails or hangs in one of them used to leave the others waiting in a
+    collective until the driver's limit).  The line that WOULD be printed right now is kept as a string (`set_line`); it leaves
+    the process exactly once -- at the normal end (`finish`) or from a watchdog thread that runs beside the main thread (which may
+    sit in a collective or a device synchronisation for ever) and fires when
+      * the armed deadline of the current phase passes (`arm`),
+      * some rank announced a failure through the rendezvous store (`abort`; a host-side TCP store, nothing a hung GPU can block),
+      * the process is told to end (SIGTERM / SIGINT: torch.distributed.run and `self_launch` send it to the surviving ranks when
+        one rank dies) -- seen through signal.set_wakeup_fd, which the C-level handler writes whatever the main thread is doing.
+    Ranks other than 0 print nothing; their watchdogs only end them."""
+
+    def __init__(self, rank, world):
+        import signal
+        import threading
+
+        self.rank, self.world = rank, world
+        self.line = None            # JSON text of the line as it stands
+        self.printed = False
+        self.lock = threading.Lock()
+        self.deadline, self.what = None, ""
+        self.store = None
+        self.done = False
+        self.rfd, self.wfd = os.pipe()
+        os.set_blocking(self.wfd, False)
+        try:
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                signal.signal(sig, lambda *_: None)  # (a Python-level handler must exist for the C-level one to write the wake-up byte)
+            signal.set_wakeup_fd(self.wfd, warn_on_full_buffer=False)
+        except ValueError:  # not the main thread (imported by a test)
+            pass
+        self.thread = threading.Thread(target=self._watch, name="bench-line-guard", daemon=True)
+        self.thread.start()
+
+    # -- what the main thread calls
+    def set_line(self, out):
+        text = json.dumps(out)
+        with self.lock:
+            self.line = text
+
+    def arm(self, seconds, what):
+        self.deadline, self.what = time.monotonic() + seconds, what
+
+    def disarm(self):
+        self.deadline = None
+
+    def attach_store(self, store):
+        self.store = store
+
+    def abort(self, reason):
+        """tell every rank (through the store) that this run cannot go on; the watchdogs end the ranks, rank 0 prints first"""
+        try:
+            if self.store is not None:
+                self.store.set("memgym_bench/abort", "rank %d: %s" % (self.rank, reason))
+        except Exception:
+            pass
+
+    def agree(self, key, ok, why="", timeout_s=120.0):
+        """All ranks say ok / not ok under `key` through the store and read each other's word: (True, "") if every rank said ok.
+        Host side only -- no collective, so a rank that could not even build its buffers is heard by ranks that could."""
+        if self.store is None or self.world == 1:
+            return ok, why
+        from datetime import timedelta
+        try:
+            self.store.set("memgym_bench/%s/%d" % (key, self.rank), "1" if ok else ("0" + why[:200]))
+            keys = ["memgym_bench/%s/%d" % (key, r) for r in range(self.world)]
+            self.store.wait(keys, timedelta(seconds=timeout_s))
+            words = [self.store.get(k).decode() for k in keys]
+        except Exception as e:
+            return False, "no agreement on %s within %.0f s: %s" % (key, timeout_s, str(e)[:120])
+        bad = ["rank %d: %s" % (r, w[1:] or "failed") for r, w in enumerate(words) if not w.startswith("1")]
+        return not bad, "; ".join(bad)
+
+    def finish(self, out=None):
+        if out is not None:
+            self.set_line(out)
+        self.done = True
+        self._emit(None)
+
+    # -- the watchdog
+    def _emit(self, reason):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank != 0 or self.line is None:
+                return
+            text = self.line
+            if reason:
+                j = json.loads(text)
+                j["ended_early"] = reason
+                text = json.dumps(j)
+            sys.stdout.write(text + "\n")
+            sys.stdout.flush()
+
+    def _bail(self, reason, rc):
+        had_line = self.line is not None
+        self._emit(reason)
+        if self.rank == 0 or reason:
+            sys.stderr.write("bench.py rank %d: ending early: %s\n" % (self.rank, reason))
+            sys.stderr.flush()
+        os._exit(0 if (had_line or self.rank != 0) and rc == 0 else (rc or 3))
+
+    def _watch(self):
+        import select
+        last_store = 0.0
+        while not self.done:
+            r, _, _ = select.select([self.rfd], [], [], 0.25)
+            if self.done:
+                return
+            if r:
+                sig = os.read(self.rfd, 16)
+                self._bail("signal %s while %s" % (",".join(str(b) for b in sig), self.what or "running"), 0)
+            now = time.monotonic()
+            if self.deadline is not None and now > self.deadline:
+                self.abort("watchdog: %s did not finish in time" % self.what)
+                self._bail("watchdog: %s did not finish within its limit (a rank hung or died)" % self.what, 0)
+            if self.store is not None and now - last_store > 1.0:
+                last_store = now
+                try:
+                    if self.store.check(["memgym_bench/abort"]):
+                        self._bail("aborted: " + self.store.get("memgym_bench/abort").decode(), 0)
+                except Exception as e:  # the store's server (rank 0 / the launcher) is gone
+                    if self.rank != 0:
+                        self._bail("the rendezvous store is gone (%s)" % str(e)[:80], 0)
+
+
+def _fault(leg, rank):
+    """Test hook (tests/test_bench_guard.py): MEMGYM_BENCH_TEST_FAULT=<rank>:<leg>:<exit|raise|hang> makes that rank fail inside that leg."""
+    spec = os.environ.get("MEMGYM_BENCH_TEST_FAULT")
+    if not spec:
+        return
+    r, lg, mode = spec.split(":")
+    if int(r) != rank or lg != leg:
+        return
+    if mode == "exit":
+        os._exit(17)
+    if mode == "raise":
+        raise RuntimeError("injected failure in leg " + leg)
+    if mode == "hang":
+        while True:
+            time.sleep(1.0)
+
+
+def fake_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8_xyc", gather=None, events=True, event_stride=8,
+                  count_done=False, leg="headline", long_window=0, policy=None):
+    """MEMGYM_BENCH_FAKE=1 (tests/test_bench_guard.py, no GPU): the control flow of an N-rank run -- rendezvous, agreement, legs with
+    collectives, the one line -- with a stand-in for the measurement: a few gloo all-reduces and a constant rate."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.ones(1)
+    for k in range(3):
+        if world > 1:
+            dist.all_reduce(t)
+        if k == 1:
+            _fault(leg, rank)
+        time.sleep(0.05)
+    n_total = n_local * world
+    return {"env_id": env_id, "n_local": n_local, "n_total": n_total, "seconds": K * 1e-4, "value": n_total / 1e-4, "wall_ms_per_step": 0.1,
+            "timing": "FAKE (MEMGYM_BENCH_FAKE=1): no measurement", "extra": {}, "value_windows": [], "path_gen": None, "box": None,
+            "setup_steps": settle, "settle_windows_ms": [], "ms_per_step": 0.1, "raster_avg_ms": None, "raster_launches": 0, "logic_avg_ms": None,
+            "event_region": None, "obs_placement": None, "gather": gather if world > 1 else None, "note": None, "value_long": None}
+
+
+def rank_report(dev, backend):
+    """What this rank runs on, for the line's `ranks` (gathered from every rank through the store)."""
     import torch
 
-    have = torch.cuda.device_count()
+    d = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(), "device": str(dev)}
+    try:
+        if dev.type == "cuda":
+            p = torch.cuda.get_device_properties(dev)
+            d.update(name=p.name, arch=getattr(p, "gcnArchName", None), hbm_GiB=round(p.total_memory / 2**30, 1), cus=p.multi_processor_count,
+                     pci_bus_id=getattr(p, "pci_bus_id", None), uuid=str(getattr(p, "uuid", "")) or None)
+            d["peer_access_to_rank0_device"] = bool(dev.index == 0 or torch.cuda.can_device_access_peer(dev.index, 0)) if torch.cuda.device_count() > 1 else None
+    except Exception as e:
+        d["error"] = str(e)[:120]
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------------------- launch
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU); rank 0 prints the JSON line.  All ranks are
+    watched together: when one ends with an error the others get a few seconds to notice (the store's abort word) and are then told
+    to end (SIGTERM -- their LineGuard prints rank 0's line first); nothing here waits for a hung rank longer than that."""
+    import signal
+
+    if os.environ.get("MEMGYM_BENCH_FAKE"):
+        have = args.gpus
+    else:
+        import torch
+        have = torch.cuda.device_count()
     if os.environ.get("MEMGYM_BENCH_ONE_DEVICE"):  # plumbing test: every rank on GPU 0 (tests/test_gpu_bench_ranks.py)
         have = args.gpus
     if have < args.gpus:
@@ -531,15 +785,103 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+    first_bad = None
     try:
-        for p in procs:
-            rc = p.wait() or rc
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad and first_bad is None:
+                first_bad = time.monotonic()
+            if first_bad is not None and time.monotonic() - first_bad > 8.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGTERM)
+                t_end = time.monotonic() + 10.0
+                while any(p.poll() is None for p in procs) and time.monotonic() < t_end:
+                    time.sleep(0.1)
+                break
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    return rc
+    rc0 = procs[0].wait()
+    return rc0  # rank 0's word: 0 when its line went out (a failed leg is IN the line: `ended_early` / `config5`)
+
+
+def build_headline(args, r, env_id, n_local, K, W, world, ranks):
+    """rank 0: the contract's line from the headline measurement `r` (everything the later legs add is optional)."""
+    obs_elem = OBS_ELEM[args.obs_format]
+    gather_txt = ""
+    if r["gather"]:
+        gather_txt = ", peer-mapped obs stores into rank 0's HBM" if r["gather"] == "peer" else ", RCCL obs gather to rank 0"
+    out = {
+        "metric": "env steps/sec (aggregate)", "value": r["value"], "unit": "env steps/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format, "setup_steps": r["setup_steps"],
+        "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 obs (%s), same-step auto-reset, uniform random "
+                               "actions generated on device%s" % (env_id, n_local, world, args.obs_format, gather_txt),
+                   "env_id": env_id, "envs_per_gpu": n_local, "envs_total": r["n_total"],
+                   "parallelism": "env-sharded x%d, no data-path collective" % world if not r["gather"] else
+                   "env-sharded x%d + %s(obs + reward + done)->rank0" % (world, "peer-mapped stores / packed gather" if r["gather"] == "peer" else "gather")},
+        "per_gpu_value": r["value"] / world, "timing": r["timing"], "wall_ms_per_step": r["wall_ms_per_step"],
+        # five consecutive windows of K steps each right behind the timed one (this rank's share x N for N > 1): the spread a
+        # K-step headline carries
+        "value_windows": r["value_windows"],
+        # BASELINE.md section 3's stated timing (>= 2,000 timed steps), whatever --steps was: one such window, timed the same way
+        "value_2000": r.get("value_long"),
+        # who ran: every rank's device as that rank reports it, the backend, the collective library's version
+        "ranks": ranks,
+    }
+    if r["note"]:
+        out["note"] = r["note"]
+    if "gather_check" in r:
+        out["gather_check"] = r["gather_check"]
+        out["gathered"] = r.get("gathered")
+    if r["raster_launches"]:
+        avg_ms = r["raster_avg_ms"]
+        # Algorithmic bytes of the timed launch per instance-step.  Mortar family: the step's workgroups ride in front of the
+        # raster's in ONE launch, so that launch moves the whole step's bytes: SURVEY.md 8(d)'s figure (MortarMayhem-Grid
+        # 21,305 B; rounds 3-4 priced it at the raster's 21,184 only).  Two-launch families: the raster's frame + descriptor.
+        one_launch = not r["logic_avg_ms"]
+        per_inst = (STEP_BYTES.get(env_id, FRAME + DESC_BYTES.get(env_id, 16)) + FRAME * (obs_elem - 1)) if one_launch \
+            else (FRAME * obs_elem + DESC_BYTES.get(env_id, 16))
+        rb = per_inst * n_local
+        achieved = rb / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_source, traffic_meta = None, None, None
+        if world == 1 and obs_elem == 1 and not args.no_traffic:
+            traffic, traffic_meta = measure_traffic(env_id, n_local)
+            traffic_source = traffic_meta.get("source")
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if traffic is None and os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("env_id") == env_id and j.get("envs_per_gpu") == n_local and obs_elem == 1:
+                    traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = ("NOT measured in this run: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload, "
+                                      "%s (profiles/pmc_latest.json, regenerated by tools/profile_round.sh)" % j.get("source", "committed profile"))
+            except Exception:
+                traffic = None
+        # (mortar family: the step's workgroups ride in front of the raster's in ONE launch, so `avg_launch_ms` is the whole
+        # step's launch and there is no separate logic kernel to time; the algorithmic bytes stay the raster's)
+        out["roofline"] = {"bound": "hbm", "kernel": "step + raster in one launch (rank 0)" if one_launch else "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                           "traffic_passes": traffic_meta,
+                           "bytes_per_launch": rb, "bytes_per_instance_step": per_inst, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],
+                           "event_region": r["event_region"], "logic_kernel_avg_ms": r["logic_avg_ms"],
+                           "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * r["n_total"] / (r["seconds"] / K) / 1e9}
+        if r.get("box"):
+            b = r["box"]
+            # frac_of_linear_fill leads: the linear 16-byte fill is what bounds stores on this box and this placement.  The frame
+            # probe (the raster's store shape without compose work) is a CONTROL, not a ceiling -- a raster with compose work can
+            # beat it (round 5: 1.016 for C3), so "0.95 of it" does not mean "5 % left" (VERDICT r5 #8; it was `frac_of_box_ceiling`).
+            out["roofline"]["frac_of_linear_fill"] = achieved / b["linear_fill"]["median_GBps"]
+            out["roofline"]["box_probe_GBps"] = {"linear_fill": b["linear_fill"]["median_GBps"], "frame_probe": b["frame_shaped"]["median_GBps"],
+                                                 "linear_fill_best": b["linear_fill"]["best_GBps"], "frame_probe_best": b["frame_shaped"]["best_GBps"],
+                                                 "how": "mg_store_probe over this run's observation buffer (%d frames), median / best of 9 launches each, right behind the timed region" % n_local}
+            out["roofline"]["frac_of_frame_probe"] = achieved / b["frame_shaped"]["median_GBps"]
+    if r["obs_placement"]:  # mg_obs_alloc: observation buffer assembled from pieces in different HBM zones
+        out["obs_placement"] = r["obs_placement"]
+    return out
 
 
 def main():
@@ -561,8 +903,10 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-instance C1 leg")
+    ap.add_argument("--long-window", type=int, default=2000, help="steps of the extra window behind the timed region (value_2000; 0 = none)")
     ap.add_argument("--config5-envs", type=int, default=32768, help="instances per GPU of the config-5 legs of an N > 1 run (BASELINE: 32,768)")
     ap.add_argument("--config5-steps", type=int, default=100)
+    ap.add_argument("--leg-limit", type=float, default=240.0, help="seconds a config-5 leg (and the rendezvous) may take before the watchdog prints the line and ends the run")
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every N-th step with HIP events (each bracketed step costs ~15 us)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only for plumbing tests with all ranks on one GPU)")
@@ -573,110 +917,96 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    from datetime import timedelta
+
     import torch
     import torch.distributed as dist
 
+    fake = bool(os.environ.get("MEMGYM_BENCH_FAKE"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MEMGYM_BENCH_ONE_DEVICE"):
         local_rank = 0
+    guard = LineGuard(rank, world)
+    guard.arm(args.leg_limit, "the rendezvous")
+    # a collective that never completes must not take rank 0 down before its line is out: the only thing that ends a hung rank of
+    # this program is the LineGuard (which prints first).  c10d's own watchdog would abort the process at its timeout.
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    pg_timeout = timedelta(seconds=120)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if not fake:
+            torch.cuda.set_device(local_rank)
+        if args.backend == "nccl" and not fake:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
     else:
-        torch.cuda.set_device(0)
+        if not fake:
+            torch.cuda.set_device(0)
         if args.gather == "rccl" and "MASTER_PORT" in os.environ:  # a one-rank RCCL group: the gather path on a single GPU
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", 0)} if args.backend == "nccl" else {}))
+            dist.init_process_group(args.backend, rank=0, world_size=1, timeout=pg_timeout, **({"device_id": torch.device("cuda", 0)} if args.backend == "nccl" else {}))
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d (the launcher decides)" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if fake else torch.device("cuda", local_rank)
+    backend = (dist.get_backend() if dist.is_initialized() else None)
+
+    # every rank's report, through the rendezvous store (host side)
+    ranks = {"world": world, "backend": backend, "devices": [rank_report(dev, backend)]}
+    if dist.is_initialized():
+        try:
+            from torch.distributed.distributed_c10d import _get_default_store
+            store = _get_default_store()
+            guard.attach_store(store)
+            store.set("memgym_bench/rank/%d" % rank, json.dumps(ranks["devices"][0]))
+            if rank == 0:
+                keys = ["memgym_bench/rank/%d" % q for q in range(world)]
+                store.wait(keys, timedelta(seconds=60))
+                ranks["devices"] = [json.loads(store.get(k).decode()) for k in keys]
+        except Exception as e:
+            ranks["note"] = "rank reports unavailable: %s" % str(e)[:120]
+        if backend == "nccl":
+            try:
+                ranks["collective_library"] = "RCCL %s (torch.cuda.nccl.version())" % ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        ranks["process_group_timeout_s"] = pg_timeout.total_seconds()
 
     env_id = args.env
     n_local = args.envs_per_gpu or DEFAULT_ENVS[env_id]
     K, W = args.steps, args.warmup
-    r = run_workload(env_id, n_local, K, W, args.settle, world, rank, dev, args.obs_format, args.gather, not args.no_events, args.event_stride)
-    obs_elem = OBS_ELEM[args.obs_format]
+    guard.arm(max(600.0, 2 * args.leg_limit), "the headline workload")
+    r = run_workload(env_id, n_local, K, W, args.settle, world, rank, dev, args.obs_format, args.gather, not args.no_events, args.event_stride,
+                     long_window=args.long_window)
+    guard.disarm()
 
     out = None
     if rank == 0:
-        gather_txt = ""
-        if r["gather"]:
-            gather_txt = ", peer-mapped obs stores into rank 0's HBM" if r["gather"] == "peer" else ", RCCL obs gather to rank 0"
-        out = {
-            "metric": "env steps/sec (aggregate)", "value": r["value"], "unit": "env steps/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "obs_format": args.obs_format, "setup_steps": r["setup_steps"],
-            "config": {"workload": "%s, %d envs/GPU x %d GPU, 84x84x3 obs (%s), same-step auto-reset, uniform random "
-                                   "actions generated on device%s" % (env_id, n_local, world, args.obs_format, gather_txt),
-                       "env_id": env_id, "envs_per_gpu": n_local, "envs_total": r["n_total"],
-                       "parallelism": "env-sharded x%d, no data-path collective" % world if not r["gather"] else
-                       "env-sharded x%d + %s(obs + reward + done)->rank0" % (world, "peer-mapped stores / packed gather" if r["gather"] == "peer" else "gather")},
-            "per_gpu_value": r["value"] / world, "timing": r["timing"], "wall_ms_per_step": r["wall_ms_per_step"],
-            # five consecutive windows of K steps each right behind the timed one (this rank's share x N for N > 1): the spread a
-            # K-step headline carries
-            "value_windows": r["value_windows"],
-        }
-        if r["note"]:
-            out["note"] = r["note"]
-        if "gather_check" in r:
-            out["gather_check"] = r["gather_check"]
-            out["gathered"] = r.get("gathered")
-        if r["raster_launches"]:
-            avg_ms = r["raster_avg_ms"]
-            # Algorithmic bytes of the timed launch per instance-step.  Mortar family: the step's workgroups ride in front of the
-            # raster's in ONE launch, so that launch moves the whole step's bytes: SURVEY.md 8(d)'s figure (MortarMayhem-Grid
-            # 21,305 B; rounds 3-4 priced it at the raster's 21,184 only).  Two-launch families: the raster's frame + descriptor.
-            one_launch = not r["logic_avg_ms"]
-            per_inst = (STEP_BYTES.get(env_id, FRAME + DESC_BYTES.get(env_id, 16)) + FRAME * (obs_elem - 1)) if one_launch \
-                else (FRAME * obs_elem + DESC_BYTES.get(env_id, 16))
-            rb = per_inst * n_local
-            achieved = rb / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_source, traffic_meta = None, None, None
-            if world == 1 and obs_elem == 1 and not args.no_traffic:
-                traffic, traffic_meta = measure_traffic(env_id, n_local)
-                traffic_source = traffic_meta.get("source")
-            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if traffic is None and os.path.exists(pmc):
-                try:
-                    j = json.load(open(pmc))
-                    if j.get("env_id") == env_id and j.get("envs_per_gpu") == n_local and obs_elem == 1:
-                        traffic = j.get("hbm_bytes_per_launch")
-                        traffic_source = ("NOT measured in this run: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload, "
-                                          "%s (profiles/pmc_latest.json, regenerated by tools/profile_round.sh)" % j.get("source", "committed profile"))
-                except Exception:
-                    traffic = None
-            # (mortar family: the step's workgroups ride in front of the raster's in ONE launch, so `avg_launch_ms` is the whole
-            # step's launch and there is no separate logic kernel to time; the algorithmic bytes stay the raster's)
-            out["roofline"] = {"bound": "hbm", "kernel": "step + raster in one launch (rank 0)" if one_launch else "raster (rank 0)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                               "traffic_passes": traffic_meta,
-                               "bytes_per_launch": rb, "bytes_per_instance_step": per_inst, "avg_launch_ms": avg_ms, "launches": r["raster_launches"],
-                               "event_region": r["event_region"], "logic_kernel_avg_ms": r["logic_avg_ms"],
-                               "whole_step_GBps": (STEP_BYTES.get(env_id, FRAME) + FRAME * (obs_elem - 1)) * r["n_total"] / (r["seconds"] / K) / 1e9}
-            if r.get("box"):
-                # the same buffer, the same launch size, pure stores: what separates the box (and the buffer's placement) from the code
-                b = r["box"]
-                out["roofline"]["box_ceiling_GBps"] = {"linear_fill": b["linear_fill"]["median_GBps"], "frame_shaped": b["frame_shaped"]["median_GBps"],
-                                                       "linear_fill_best": b["linear_fill"]["best_GBps"], "frame_shaped_best": b["frame_shaped"]["best_GBps"],
-                                                       "how": "mg_store_probe over this run's observation buffer (%d frames), median / best of 9 launches each, right behind the timed region" % n_local}
-                out["roofline"]["frac_of_box_ceiling"] = achieved / b["frame_shaped"]["median_GBps"]
-                out["roofline"]["frac_of_linear_fill"] = achieved / b["linear_fill"]["median_GBps"]
-        if r["obs_placement"]:  # mg_obs_alloc: observation buffer assembled from pieces in different HBM zones
-            out["obs_placement"] = r["obs_placement"]
+        out = build_headline(args, r, env_id, n_local, K, W, world, ranks)
+        guard.set_line(out)  # from here on the run cannot end without its headline
+        sys.stderr.write("bench.py: headline measured (%d GPU%s): %.4g env steps/s -- held by the line guard, printed once at the end\n" % (world, "s" if world > 1 else "", out["value"]))
+        sys.stderr.flush()
 
     if world > 1 and not args.no_secondary and args.obs_format == "u8_xyc":
-        # BASELINE.json config 5: Endless-MortarMayhem-v0, 32,768 instances per GPU, with and without the gather to rank 0
+        # BASELINE.json config 5: Endless-MortarMayhem-v0, 32,768 instances per GPU, with and without the gather to rank 0.  Each leg
+        # runs under the guard's deadline; the ranks agree on going in and on how it went through the store (no collective), and the
+        # first failure anywhere ends the phase for everybody: a rank that raised cannot leave the others waiting in a collective.
         c5 = {}
+        if rank == 0:
+            out["config5"] = {"workload": "Endless-MortarMayhem-v0, %d envs/GPU x %d GPU (%d envs)" % (args.config5_envs, world, args.config5_envs * world)}
         for label, gm in (("no_gather", None), ("gather_rccl", "rccl"), ("gather_peer", "peer")):
+            guard.arm(args.leg_limit, "config5 leg " + label)
+            go, why = guard.agree("pre/" + label, True, timeout_s=args.leg_limit)
+            if not go:
+                c5[label] = "skipped: " + why
+                break
+            ok, err = True, ""
             try:
-                q = run_workload("Endless-MortarMayhem-v0", args.config5_envs, args.config5_steps, 20, args.settle, world, rank, dev, "u8_xyc", gm, not args.no_events, args.event_stride)
+                q = run_workload("Endless-MortarMayhem-v0", args.config5_envs, args.config5_steps, 20, args.settle, world, rank, dev, "u8_xyc", gm,
+                                 not args.no_events, args.event_stride, leg=label)
                 c5[label] = {"value": q["value"], "unit": "env steps/s", "per_gpu_value": q["value"] / world, "ms_per_step": q["ms_per_step"],
                              "timing": q["timing"], "wall_ms_per_step": q["wall_ms_per_step"],
                              "raster_avg_ms_rank0": q["raster_avg_ms"], "note": q["note"],
@@ -684,25 +1014,37 @@ def main():
                              "gathered": (None if gm is None else q.get("gathered") if q["gather"] == "rccl" else
                                           "obs by peer-mapped stores + reward (f32) + done (u8) by one packed gather: 21168 + 5 B per instance"),
                              "gather_check": q.get("gather_check")}
-            except Exception as e:  # keep the headline line alive
-                c5[label] = "failed: %s" % (str(e)[:200],)
-        if rank == 0:
-            out["config5"] = {"workload": "Endless-MortarMayhem-v0, %d envs/GPU x %d GPU (%d envs)" % (args.config5_envs, world, args.config5_envs * world), **c5}
+            except Exception as e:  # keep the headline line alive -- and tell the others, who may be waiting for this rank in a collective
+                ok, err = False, "%s: %s" % (type(e).__name__, str(e)[:200])
+                c5[label] = "failed: " + err
+            if rank == 0:
+                out["config5"].update(c5)
+                guard.set_line(out)
+            if not ok:
+                guard.abort("config5 leg %s failed: %s" % (label, err))
+                break
+            all_ok, why = guard.agree("post/" + label, ok, err, timeout_s=args.leg_limit)
+            if not all_ok:  # (a rank that failed has raised the abort word already; this rank stops here too)
+                if rank == 0:
+                    out["config5"][label] = {"this_rank": c5[label], "failed_elsewhere": why}
+                    guard.set_line(out)
+                break
+        guard.disarm()
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not fake:
             try:
                 out["cpu_baseline"] = cpu_baseline(env_id)
             except Exception as e:  # the oracle is optional equipment on a box without gcc
-                out["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": os.cpu_count(), "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": os.cpu_count(), "kind": "port", "cpu_model": cpu_model(),
                                        "sample": "unavailable: %s" % e}
             out["pygame_baseline"] = pygame_baseline(env_id)
-        if world == 1 and not args.no_c1:
+        if world == 1 and not args.no_c1 and not fake:
             try:
                 out["c1"] = c1_leg()
             except Exception as e:
                 out["c1"] = "failed: %s" % e
-        if world == 1 and not args.no_secondary and args.obs_format == "u8_xyc":
+        if world == 1 and not args.no_secondary and args.obs_format == "u8_xyc" and not fake:
             try:
                 out["secondary_workloads"] = secondary_workloads(env_id, dev, args.settle, traffic=not args.no_traffic)
             except Exception as e:
@@ -712,9 +1054,23 @@ def main():
                     out["other_workloads"] = other_workloads(env_id, dev, args.settle)
                 except Exception as e:
                     out["other_workloads"] = "failed: %s" % e
-        print(json.dumps(out), flush=True)
+    guard.finish(out)  # the ONE line
     if dist.is_initialized():
-        dist.destroy_process_group()
+        import threading
+        try:
+            aborted = world > 1 and guard.store is not None and guard.store.check(["memgym_bench/abort"])
+        except Exception:
+            aborted = True
+        if aborted:
+            os._exit(0)  # a failed phase: the process group is in no state to be torn down collectively
+        t = threading.Timer(20.0, lambda: os._exit(0))  # the teardown is a collective too: bounded
+        t.daemon = True
+        t.start()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        t.cancel()
 
 
 if __name__ == "__main__":
