@@ -1,5 +1,6 @@
 // mg_api.hip -- the C ABI of include/memgym.h on top of the per-family implementations.
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <map>
 #include <mutex>
@@ -13,28 +14,19 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 }  // namespace mg
 
-constexpr int MG_MAX_GROUPS = 8;
-
-// One handle = one device, num_envs instances in `groups` contiguous blocks (include/memgym.h: mg_set_groups), each block a
-// Family object of its own (state, atlases, queues).  groups == 1: everything runs on the caller's stream as it always did.
+// One handle = one device, num_envs instances, one Family object (state, atlases, queues); everything runs on the caller's stream.
+// (Rounds 3-5 could split a handle into "instance groups" on streams of their own -- mg_set_groups; measured x0.8 on ROCm 7.2,
+// profiles/r03_groups.md -- removed in round 6: dead weight in the ABI, the checkpoint header and this file.)
 struct mg_env {
-    std::vector<mg::Family*> fams;
-    std::vector<int> base;  // first instance of block g; base[groups] = num_envs
-    mg::Family* fam = nullptr;  // fams[0]: static properties
+    mg::Family* fam = nullptr;
     int device = 0;
     int num_envs = 0;
     int variant = 0, family = 0;  // what make_* was called with
-    bool started = false;         // a reset has happened: the grouping is fixed
+    bool started = false;         // a reset has happened
     std::string id;
-    struct Opt {
-        int set;
-        std::string key;
-        std::vector<double> values;
-    };
-    std::vector<Opt> options;  // every mg_set_option / mg_set_option_set so far (replayed by mg_set_groups)
-    const int32_t* set_of_dev = nullptr;
     int obs_format = MG_OBS_U8_XYC;
-    float* vec_dev = nullptr;
+    float* vec_dev = nullptr;     // the caller's vector-observation binding (mg_bind_vector_obs), or the single-instance block's
+    float* vec_dev_caller = nullptr;
     int prof_stride = 0;
     // mg_single_open: pinned, device-mapped host buffers of the single-instance fast path (host address, device address)
     struct Single {
@@ -42,12 +34,9 @@ struct mg_env {
         char *host = nullptr, *dev = nullptr;
         size_t bytes = 0;
         size_t o_action = 0, o_seed = 0, o_obs = 0, o_vec = 0, o_reward32 = 0, o_reward = 0, o_done = 0, o_gt32 = 0, o_gt = 0, o_ep_reward = 0,
-               o_ep_length = 0, o_aux = 0;
+               o_ep_length = 0, o_aux = 0, o_flag = 0;
+        uint32_t ticket = 0;      // completion flag protocol of mg_single_step (see there)
     } single;
-    hipStream_t gs[MG_MAX_GROUPS] = {};
-    hipEvent_t ev_in = nullptr, ev_logic[MG_MAX_GROUPS] = {}, ev_done[MG_MAX_GROUPS] = {};
-    int groups() const { return (int)fams.size(); }
-    int count(int g) const { return base[g + 1] - base[g]; }
 };
 
 namespace {
@@ -120,81 +109,19 @@ mg::Family* make_family(int family, int variant, int n) {
     if (family == 1) return mg::make_spot(variant, n);
     return mg::make_mystery(variant, n);
 }
-void destroy_families(mg_env* e) {
-    if (e->single.host) {  // (the families hold device views of it: mg_destroy synchronises first)
+void destroy_family(mg_env* e) {
+    if (e->single.host) {  // (the family holds device views of it: mg_destroy synchronises first)
+        if (e->vec_dev && e->vec_dev == (float*)(e->single.dev + e->single.o_vec)) e->vec_dev = e->vec_dev_caller;  // never leave a pointer into freed memory
         (void)hipHostFree(e->single.host);
         e->single = mg_env::Single();
     }
-    for (auto* f : e->fams) delete f;
-    e->fams.clear();
+    delete e->fam;
     e->fam = nullptr;
-    for (int g = 0; g < MG_MAX_GROUPS; ++g) {
-        if (e->gs[g]) (void)hipStreamDestroy(e->gs[g]);
-        if (e->ev_logic[g]) (void)hipEventDestroy(e->ev_logic[g]);
-        if (e->ev_done[g]) (void)hipEventDestroy(e->ev_done[g]);
-        e->gs[g] = nullptr;
-        e->ev_logic[g] = e->ev_done[g] = nullptr;
-    }
-    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
-    e->ev_in = nullptr;
-}
-// (re)build the blocks of a handle; options, observation format, vector-observation binding and profiling are carried over
-void build_groups(mg_env* e, int groups) {
-    destroy_families(e);
-    e->base.assign(groups + 1, 0);
-    for (int g = 0; g <= groups; ++g) e->base[g] = (int)((int64_t)e->num_envs * g / groups);
-    for (int g = 0; g < groups; ++g) {
-        mg::Family* f = make_family(e->family, e->variant, e->count(g));
-        e->fams.push_back(f);
-        f->obs_format = e->obs_format;
-        f->prof.stride = e->prof_stride;
-        for (auto& o : e->options) f->set_option_set(o.set, o.key, o.values.data(), (int)o.values.size());
-        if (e->set_of_dev) f->bind_option_sets(e->set_of_dev + e->base[g]);
-        if (e->vec_dev && f->vec_dim()) f->bind_vector_obs(e->vec_dev + (size_t)e->base[g] * f->vec_dim());
-    }
-    e->fam = e->fams[0];
-    if (groups > 1) {
-        MG_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
-        for (int g = 0; g < groups; ++g) {
-            MG_HIP(hipStreamCreateWithFlags(&e->gs[g], hipStreamNonBlocking));
-            MG_HIP(hipEventCreateWithFlags(&e->ev_logic[g], hipEventDisableTiming));
-            MG_HIP(hipEventCreateWithFlags(&e->ev_done[g], hipEventDisableTiming));
-            e->fams[g]->logic_event = e->ev_logic[g];
-        }
-    }
 }
 size_t obs_bytes_of(int f) {
     const size_t elem = f == MG_OBS_F32_CYX ? 4 : ((f == MG_OBS_F16_CYX || f == MG_OBS_BF16_CYX) ? 2 : 1);
     return elem * 84 * 84 * 3;
 }
-// Run `body(g, stream)` for every block: on the caller's stream for one block; otherwise on the blocks' own streams, which
-// first wait for what the caller's stream has enqueued so far, and the caller's stream waits for all of them afterwards.
-// stagger: block g's stream additionally waits for block g - 1's logic kernel (Family::logic_event).
-template <typename F>
-void for_groups(mg_env* e, hipStream_t s, bool stagger, F&& body) {
-    const int G = e->groups();
-    if (G == 1) {
-        body(0, s);
-        return;
-    }
-    // measurement switches (tools/groups_probe.py): MEMGYM_GROUPS_LAB bit 0 = no fork from / join into the caller's stream
-    // (results are then NOT ordered with it), bit 1 = no stagger
-    static const int lab = [] {
-        const char* v = lab_env("MEMGYM_GROUPS_LAB");
-        return v ? atoi(v) : 0;
-    }();
-    if (!(lab & 1)) MG_HIP(hipEventRecord(e->ev_in, s));
-    for (int g = 0; g < G; ++g) {
-        if (!(lab & 1)) MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_in, 0));
-        if (stagger && g > 0 && !(lab & 2)) MG_HIP(hipStreamWaitEvent(e->gs[g], e->ev_logic[g - 1], 0));
-        body(g, e->gs[g]);
-        if (!(lab & 1)) MG_HIP(hipEventRecord(e->ev_done[g], e->gs[g]));
-    }
-    if (!(lab & 1))
-        for (int g = 0; g < G; ++g) MG_HIP(hipStreamWaitEvent(s, e->ev_done[g], 0));
-}
-template <typename T>
-T* off(T* p, size_t n) { return p ? p + n : nullptr; }
 }  // namespace
 
 extern "C" {
@@ -231,9 +158,8 @@ int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out) {
         e->family = family;
         e->variant = variant;
         try {
-            build_groups(e, 1);
+            e->fam = make_family(family, variant, num_envs);
         } catch (...) {
-            destroy_families(e);
             delete e;
             throw;
         }
@@ -250,34 +176,11 @@ void mg_destroy(mg_env* env) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(env->device);
-    (void)hipDeviceSynchronize();  // the blocks' streams may still run
-    destroy_families(env);
+    (void)hipDeviceSynchronize();
+    destroy_family(env);
     delete env;
     if (prev >= 0) (void)hipSetDevice(prev);
 }
-
-int mg_set_groups(mg_env* env, int groups) {
-    return guarded(env, [&] {
-        if (groups != 1 && groups != 2 && groups != 4 && groups != 8) throw std::runtime_error("mg_set_groups: 1, 2, 4 or 8 groups");
-        if (env->num_envs % groups != 0 || env->num_envs / groups < 1) throw std::runtime_error("mg_set_groups: num_envs must be divisible by the number of groups");
-        if (env->started) throw std::runtime_error("mg_set_groups: the grouping is fixed by the first mg_reset");
-        if (env->single.open) throw std::runtime_error("mg_set_groups: the handle is open for the single-instance fast path");
-        if (groups != env->groups()) {
-            const int before = env->groups();
-            try {
-                build_groups(env, groups);
-            } catch (...) {  // e.g. out of memory for the second set of state arrays: the handle keeps working as it was
-                try {
-                    build_groups(env, before);
-                } catch (...) {
-                    destroy_families(env);
-                }
-                throw;
-            }
-        }
-    });
-}
-int32_t mg_groups(const mg_env* env) { return env ? env->groups() : 0; }
 
 int32_t mg_num_envs(const mg_env* env) { return env ? env->num_envs : 0; }
 int32_t mg_action_dim(const mg_env* env) { return env ? env->fam->action_dim() : 0; }
@@ -286,8 +189,8 @@ int32_t mg_vec_dim(const mg_env* env) { return env ? env->fam->vec_dim() : 0; }
 int mg_bind_vector_obs(mg_env* env, float* vec_dev) {
     return guarded(env, [&] {
         if (env->fam->vec_dim() == 0 && vec_dev) throw std::runtime_error("mg_bind_vector_obs: this env id has no vector observation");
-        env->vec_dev = vec_dev;
-        for (int g = 0; g < env->groups(); ++g) env->fams[g]->bind_vector_obs(off(vec_dev, (size_t)env->base[g] * env->fam->vec_dim()));
+        env->vec_dev = env->vec_dev_caller = vec_dev;
+        env->fam->bind_vector_obs(vec_dev);
     });
 }
 const char* mg_info_name(const mg_env* env, int k) { return env ? env->fam->info_name(k) : nullptr; }
@@ -295,8 +198,7 @@ const char* mg_info_name(const mg_env* env, int k) { return env ? env->fam->info
 int mg_set_option(mg_env* env, const char* key, const double* values, int n) {
     return guarded(env, [&] {
         if (!key || !values || n < 1) throw mg::OptionError{-3, "mg_set_option: bad arguments"};
-        for (auto* f : env->fams) f->set_option(key, values, n);
-        env->options.push_back({0, std::string(key), std::vector<double>(values, values + n)});
+        env->fam->set_option(key, values, n);
     });
 }
 
@@ -304,15 +206,13 @@ int mg_set_option_set(mg_env* env, int set_id, const char* key, const double* va
     return guarded(env, [&] {
         if (!key || !values || n < 1) throw mg::OptionError{-3, "mg_set_option_set: bad arguments"};
         if (set_id < 0 || set_id >= MG_MAX_OPTION_SETS) throw mg::OptionError{-3, "mg_set_option_set: set index out of range"};
-        for (auto* f : env->fams) f->set_option_set(set_id, key, values, n);
-        env->options.push_back({set_id, std::string(key), std::vector<double>(values, values + n)});
+        env->fam->set_option_set(set_id, key, values, n);
     });
 }
 
 int mg_bind_option_sets(mg_env* env, const int32_t* set_of_dev) {
     return guarded(env, [&] {
-        for (int g = 0; g < env->groups(); ++g) env->fams[g]->bind_option_sets(off(set_of_dev, (size_t)env->base[g]));
-        env->set_of_dev = set_of_dev;
+        env->fam->bind_option_sets(set_of_dev);
     });
 }
 
@@ -320,8 +220,7 @@ int mg_set_obs_format(mg_env* env, int format) {
     return guarded(env, [&] {
         if (format != MG_OBS_U8_XYC && format != MG_OBS_F32_CYX && format != MG_OBS_F16_CYX && format != MG_OBS_BF16_CYX)
             throw mg::OptionError{-3, "mg_set_obs_format: unknown format"};
-        env->obs_format = format;
-        for (auto* f : env->fams) f->obs_format = format;
+        env->obs_format = env->fam->obs_format = format;
     });
 }
 
@@ -333,12 +232,7 @@ size_t mg_obs_bytes(const mg_env* env) {
 int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, void* obs_dev, float* gt_dev, void* stream) {
     return guarded(env, [&] {
         if (!obs_dev) throw std::runtime_error("mg_reset: obs_dev is NULL");
-        const size_t ob = obs_bytes_of(env->obs_format);
-        const int gd = env->fam->gt_dim();
-        for_groups(env, (hipStream_t)stream, false, [&](int g, hipStream_t st) {
-            const size_t b = (size_t)env->base[g];
-            env->fams[g]->reset(off(seeds_dev, b), off(mask_dev, b), (char*)obs_dev + b * ob, off(gt_dev, b * gd), st);
-        });
+        env->fam->reset(seeds_dev, mask_dev, obs_dev, gt_dev, (hipStream_t)stream);
         env->started = true;
     });
 }
@@ -346,10 +240,7 @@ int mg_reset(mg_env* env, const int64_t* seeds_dev, const uint8_t* mask_dev, voi
 int mg_render(mg_env* env, void* obs_dev, void* stream) {
     return guarded(env, [&] {
         if (!obs_dev) throw std::runtime_error("mg_render: obs_dev is NULL");
-        const size_t ob = obs_bytes_of(env->obs_format);
-        for_groups(env, (hipStream_t)stream, false, [&](int g, hipStream_t st) {
-            env->fams[g]->raster_only((char*)obs_dev + (size_t)env->base[g] * ob, nullptr, st);
-        });
+        env->fam->raster_only(obs_dev, nullptr, (hipStream_t)stream);
     });
 }
 
@@ -377,10 +268,8 @@ int mg_render_debug(mg_env* env, uint8_t* rgb_dev, void* stream) {
         uint8_t* frames = nullptr;
         MG_HIP(hipMalloc((void**)&frames, (size_t)env->num_envs * MG_OBS_BYTES));
         try {
-            for (int g = 0; g < env->groups(); ++g) {
-                env->fams[g]->sync_state();
-                env->fams[g]->raster_debug(frames + (size_t)env->base[g] * MG_OBS_BYTES, st);
-            }
+            env->fam->sync_state();
+            env->fam->raster_debug(frames, st);
             const size_t total = (size_t)env->num_envs * 336 * 336;
             const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
             hipLaunchKernelGGL(debug_stretch_kernel, dim3(grid), dim3(256), 0, st, frames, rgb_dev, env->num_envs);
@@ -400,51 +289,63 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
         if (!actions_dev || !obs_dev || !reward_dev || !done_dev) throw std::runtime_error("mg_step: NULL buffer");
         hipStream_t st = (hipStream_t)stream;
         const mg_info_buffers ib = read_info(info);
-        const size_t ob = obs_bytes_of(env->obs_format);
-        const int ad = env->fam->action_dim(), gd = env->fam->gt_dim();
-        for_groups(env, st, true, [&](int g, hipStream_t gst) {
-            const size_t b = (size_t)env->base[g];
-            mg_info_buffers gi = ib;  // this block's rows of every array
-            gi.ep_reward_dev = off(ib.ep_reward_dev, b);
-            gi.ep_length_dev = off(ib.ep_length_dev, b);
-            for (int k = 0; k < MG_INFO_SLOTS; ++k) gi.aux_dev[k] = off(ib.aux_dev[k], b);
-            gi.final_obs_dev = ib.final_obs_dev ? (char*)ib.final_obs_dev + b * ob : nullptr;
-            gi.reward64_dev = off(ib.reward64_dev, b);
-            gi.gt64_dev = off(ib.gt64_dev, b * gd);
-            mg::Family* f = env->fams[g];
-            void* obs_g = (char*)obs_dev + b * ob;
-            if (autoreset && gi.final_obs_dev) {
-                // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
-                // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
-                // consumption and frames as the fused path (tests/test_gpu_vector_api.py)
-                f->step(actions_dev + b * ad, obs_g, reward_dev + b, done_dev + b, off(gt_dev, b * gd), &gi, 0, gst);
-                f->raster_only(gi.final_obs_dev, done_dev + b, gst);
-                f->reset(nullptr, done_dev + b, obs_g, off(gt_dev, b * gd), gst);
-            } else {
-                f->step(actions_dev + b * ad, obs_g, reward_dev + b, done_dev + b, off(gt_dev, b * gd), &gi, autoreset, gst);
-            }
-            if (gi.gt64_dev) f->ground_truth64(gi.gt64_dev, gst);
-        });
+        mg::Family* f = env->fam;
+        if (autoreset && ib.final_obs_dev) {
+            // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
+            // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
+            // consumption and frames as the fused path (tests/test_gpu_vector_api.py)
+            f->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, &ib, 0, st);
+            f->raster_only(ib.final_obs_dev, done_dev, st);
+            f->reset(nullptr, done_dev, obs_dev, gt_dev, st);
+        } else {
+            f->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, &ib, autoreset, st);
+        }
+        if (ib.gt64_dev) f->ground_truth64(ib.gt64_dev, st);
     });
 }
 
 int mg_ground_truth64(mg_env* env, double* gt64_dev, void* stream) {
     return guarded(env, [&] {
-        const int gd = env->fam->gt_dim();
-        if (!gd) return;
+        if (!env->fam->gt_dim()) return;
         if (!gt64_dev) throw std::runtime_error("mg_ground_truth64: gt64_dev is NULL");
-        for_groups(env, (hipStream_t)stream, false, [&](int g, hipStream_t st) {
-            env->fams[g]->sync_state();
-            env->fams[g]->ground_truth64(gt64_dev + (size_t)env->base[g] * gd, st);
-        });
+        env->fam->sync_state();
+        env->fam->ground_truth64(gt64_dev, (hipStream_t)stream);
     });
 }
 
 // ---- the single-instance fast path (include/memgym.h: mg_single_io) ----
+} // extern "C"
+namespace {
+// Wait for everything enqueued on `st` WITHOUT hipStreamSynchronize (round 6): a stream memory operation writes the
+// call's ticket into the pinned block behind the step's launches (the command processor executes it when they have completed -- and
+// with them their stores into the same pinned block), and the host polls that word.  hipStreamSynchronize on this runtime costs
+// more than the step's kernels once the work is this small.  A wait that takes longer than 50 ms (a fault, a debugger) falls back to the
+// synchronising call, which also reports the stream's error; a runtime without stream memory operations synchronises as before.
+void single_wait(mg_env::Single& S, hipStream_t st) {
+    static bool use_flag = true;
+    if (use_flag) {
+        const uint32_t want = ++S.ticket;
+        if (hipStreamWriteValue32(st, S.dev + S.o_flag, want, 0) == hipSuccess) {
+            volatile uint32_t* flag = (volatile uint32_t*)(S.host + S.o_flag);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0;; ++spins) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return;
+                __builtin_ia32_pause();
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+            }
+        } else {
+            (void)hipGetLastError();
+            use_flag = false;
+        }
+    }
+    MG_HIP(hipStreamSynchronize(st));
+}
+}  // namespace
+extern "C" {
 int mg_single_open(mg_env* env, mg_single_io* io) {
     return guarded(env, [&] {
         if (!io || io->struct_size != sizeof(mg_single_io)) throw std::runtime_error("mg_single_open: set io->struct_size = sizeof(mg_single_io)");
-        if (env->num_envs != 1 || env->groups() != 1) throw std::runtime_error("mg_single_open: the handle must hold exactly one instance in one group");
+        if (env->num_envs != 1) throw std::runtime_error("mg_single_open: the handle must hold exactly one instance");
         mg_env::Single& S = env->single;
         if (!S.open) {
             size_t o = 0;
@@ -455,14 +356,15 @@ int mg_single_open(mg_env* env, mg_single_io* io) {
             S.o_reward32 = take(4); S.o_reward = take(8); S.o_done = take(1);
             S.o_gt32 = take(sizeof(float) * 8); S.o_gt = take(sizeof(double) * 8);
             S.o_ep_reward = take(8); S.o_ep_length = take(4); S.o_aux = take(sizeof(float) * MG_INFO_SLOTS * 64);  // (one 256-byte line per slot)
+            S.o_flag = take(4);
             S.bytes = o;
             MG_HIP(hipHostMalloc((void**)&S.host, S.bytes, hipHostMallocMapped | hipHostMallocCoherent));
             memset(S.host, 0, S.bytes);
             MG_HIP(hipHostGetDevicePointer((void**)&S.dev, S.host, 0));
             S.open = true;
         }
-        if (env->fam->vec_dim()) {  // the vector observation is written at every reset, into the mapped buffer from now on
-            env->vec_dev = (float*)(S.dev + S.o_vec);
+        if (env->fam->vec_dim()) {  // the vector observation is written at every reset, into the mapped buffer from now on (io->vec;
+            env->vec_dev = (float*)(S.dev + S.o_vec);  // a buffer bound earlier with mg_bind_vector_obs is no longer written)
             env->fam->bind_vector_obs(env->vec_dev);
         }
         io->obs = S.host + S.o_obs;
@@ -486,7 +388,7 @@ int mg_single_reset(mg_env* env, int64_t seed, int has_seed, void* stream) {
         f->reset(has_seed ? (const int64_t*)(S.dev + S.o_seed) : nullptr, nullptr, S.dev + S.o_obs, f->gt_dim() ? (float*)(S.dev + S.o_gt32) : nullptr, st);
         f->ground_truth64((double*)(S.dev + S.o_gt), st);
         env->started = true;
-        MG_HIP(hipStreamSynchronize(st));
+        single_wait(S, st);
     });
 }
 
@@ -509,15 +411,14 @@ int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream) {
         f->step((const int32_t*)(S.dev + S.o_action), S.dev + S.o_obs, (float*)(S.dev + S.o_reward32), (uint8_t*)(S.dev + S.o_done),
                 f->gt_dim() ? (float*)(S.dev + S.o_gt32) : nullptr, &ib, 0, st);
         f->ground_truth64((double*)(S.dev + S.o_gt), st);
-        MG_HIP(hipStreamSynchronize(st));
+        single_wait(S, st);
     });
 }
 
 size_t mg_state_size(const mg_env* env) {
     if (!env) return 0;
     size_t t = sizeof(StateHeader);
-    for (auto* f : env->fams)
-        for (auto& b : f->state_blobs()) t += b.second;
+    for (auto& b : env->fam->state_blobs()) t += b.second;
     return t;
 }
 
@@ -525,7 +426,7 @@ int mg_get_state(mg_env* env, void* host_buf, size_t size) {
     return guarded(env, [&] {
         if (!host_buf || size < mg_state_size(env)) throw std::runtime_error("mg_get_state: buffer too small");
         MG_HIP(hipDeviceSynchronize());
-        for (auto* f : env->fams) f->sync_state();
+        env->fam->sync_state();
         StateHeader h;
         memset(&h, 0, sizeof(h));
         memcpy(h.magic, "MGSTATE1", 8);
@@ -533,14 +434,12 @@ int mg_get_state(mg_env* env, void* host_buf, size_t size) {
         h.num_envs = (uint32_t)env->num_envs;
         h.payload = mg_state_size(env) - sizeof(StateHeader);
         h.id_hash = fnv1a(env->id);
-        h.pad[0] = (uint8_t)env->groups();
         memcpy(host_buf, &h, sizeof(h));
         char* p = (char*)host_buf + sizeof(StateHeader);
-        for (auto* f : env->fams)
-            for (auto& b : f->state_blobs()) {
-                MG_HIP(hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost));
-                p += b.second;
-            }
+        for (auto& b : env->fam->state_blobs()) {
+            MG_HIP(hipMemcpy(p, b.first, b.second, hipMemcpyDeviceToHost));
+            p += b.second;
+        }
     });
 }
 
@@ -557,20 +456,15 @@ int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
         if (h.num_envs != (uint32_t)env->num_envs)
             throw std::runtime_error("mg_set_state: the blob holds " + std::to_string(h.num_envs) + " instances, the handle " +
                                      std::to_string(env->num_envs));
-        if ((int)h.pad[0] != env->groups())
-            throw std::runtime_error("mg_set_state: the blob was taken with " + std::to_string((int)h.pad[0]) + " instance group(s), the handle has " +
-                                     std::to_string(env->groups()) + " (mg_set_groups before the first reset)");
         if (h.payload != mg_state_size(env) - sizeof(StateHeader) || size < mg_state_size(env))
             throw std::runtime_error("mg_set_state: payload size differs from this handle's state");
         MG_HIP(hipDeviceSynchronize());
         const char* p = (const char*)host_buf + sizeof(StateHeader);
-        for (auto* f : env->fams) {
-            for (auto& b : f->state_blobs()) {
-                MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
-                p += b.second;
-            }
-            f->on_state_loaded();  // reset(seed=None) / auto-reset are legal on a restored handle
+        for (auto& b : env->fam->state_blobs()) {
+            MG_HIP(hipMemcpy(b.first, p, b.second, hipMemcpyHostToDevice));
+            p += b.second;
         }
+        env->fam->on_state_loaded();  // reset(seed=None) / auto-reset are legal on a restored handle
         env->started = true;
     });
 }
@@ -578,25 +472,15 @@ int mg_set_state(mg_env* env, const void* host_buf, size_t size) {
 int mg_set_profiling(mg_env* env, int on) {
     return guarded(env, [&] {
         env->prof_stride = on < 0 ? 0 : on;
-        for (auto* f : env->fams) {
-            f->prof.stride = env->prof_stride;
-            f->prof.count[0] = f->prof.count[1] = 0;
-        }
+        env->fam->prof.stride = env->prof_stride;
+        env->fam->prof.count[0] = env->fam->prof.count[1] = 0;
     });
 }
 
 int mg_get_profile(mg_env* env, int kind, double* total_ms, int64_t* launches) {
     return guarded(env, [&] {
         if (kind < 0 || kind > 1 || !total_ms || !launches) throw std::runtime_error("mg_get_profile: bad arguments");
-        *total_ms = 0;
-        *launches = 0;
-        for (auto* f : env->fams) {  // with several blocks: the sum over the blocks' (concurrent) launches
-            double ms = 0;
-            int64_t n = 0;
-            f->prof.collect(kind, &ms, &n);
-            *total_ms += ms;
-            *launches += n;
-        }
+        env->fam->prof.collect(kind, total_ms, launches);
     });
 }
 
@@ -604,16 +488,14 @@ int mg_poll_errors(mg_env* env, int* flags) {
     return guarded(env, [&] {
         if (!flags) throw std::runtime_error("mg_poll_errors: NULL");
         MG_HIP(hipDeviceSynchronize());
-        *flags = 0;
-        for (auto* f : env->fams) *flags |= f->poll_errors();
+        *flags = env->fam->poll_errors();
     });
 }
 
 int mg_peek_errors(mg_env* env, int* flags) {
     return guarded(env, [&] {
         if (!flags) throw std::runtime_error("mg_peek_errors: NULL");
-        *flags = 0;
-        for (auto* f : env->fams) *flags |= f->peek_errors();
+        *flags = env->fam->peek_errors();
     });
 }
 
@@ -651,13 +533,7 @@ int mg_debug_counter(mg_env* env, const char* name, int64_t* value) {
     return guarded(env, [&] {
         if (!name || !value) throw std::runtime_error("mg_debug_counter: NULL");
         MG_HIP(hipDeviceSynchronize());
-        int64_t total = 0;
-        for (auto* f : env->fams) {
-            int64_t v = 0;
-            if (!f->debug_counter(name, &v)) throw std::runtime_error(std::string("mg_debug_counter: no counter named ") + name + " for " + env->id);
-            total += v;
-        }
-        *value = total;
+        if (!env->fam->debug_counter(name, value)) throw std::runtime_error(std::string("mg_debug_counter: no counter named ") + name + " for " + env->id);
     });
 }
 
@@ -665,10 +541,8 @@ int mg_debug_rng(mg_env* env, int32_t i, uint64_t* out) {
     return guarded(env, [&] {
         if (i < 0 || i >= env->num_envs) throw std::runtime_error("mg_debug_rng: index out of range");
         MG_HIP(hipDeviceSynchronize());
-        int g = 0;
-        while (g + 1 < env->groups() && i >= env->base[g + 1]) ++g;
-        env->fams[g]->sync_state();
-        env->fams[g]->debug_rng(i - env->base[g], out);
+        env->fam->sync_state();
+        env->fam->debug_rng(i, out);
     });
 }
 

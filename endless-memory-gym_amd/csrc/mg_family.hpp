@@ -116,7 +116,21 @@ struct RngStore {
 struct OptListStore {
     DevArray<int32_t> ext;
     std::vector<int> host;  // the entries as set (capacity checks at reset time)
-    int max() const { int m = 0; for (int x : host) m = x > m ? x : m; return m; }
+    // largest entry of the list `l` this store backs.  A store that was never set() (an option set > 0 whose parameter block was copied
+    // from the defaults) has no host mirror: the defaults are short byte lists held in l's inline words -- read those (the
+    // capacity check at reset time saw 0 for such a set).
+    int max(const OptList& l) const {
+        int m = 0;
+        if (!host.empty() || l.ext) {
+            for (int x : host) m = x > m ? x : m;
+            return m;
+        }
+        for (int k = 0; k < l.n && k < OPT_INLINE; ++k) {
+            const int x = (int)((l.w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+            m = x > m ? x : m;
+        }
+        return m;
+    }
     void set(OptList& l, const std::vector<int>& v) {
         host = v;
         l.n = (int)v.size();
@@ -179,13 +193,7 @@ struct KernelProfile {
 class Family {
    public:
     KernelProfile prof;
-    // Set by the C ABI for handles with several instance groups (mg_set_groups): recorded on the launch stream right behind
-    // the step's logic kernel, so that the NEXT group's logic kernel can start under this group's raster launch.
-    hipEvent_t logic_event = nullptr;
-    void end_logic(hipStream_t s) {
-        prof.end(0, s);
-        if (logic_event) MG_HIP(hipEventRecord(logic_event, s));
-    }
+    void end_logic(hipStream_t s) { prof.end(0, s); }
     int obs_format = MG_OBS_U8_XYC;  // stream-out format of the raster kernel (include/memgym.h)
     virtual ~Family() {}
     virtual int action_dim() const = 0;

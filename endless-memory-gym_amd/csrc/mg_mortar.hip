@@ -8,7 +8,7 @@
 //   memory_gym/pygame_assets.py          Command :241-304  MortarTile/MortarArena :306-418
 //
 // The step is ONE launch for uint8 observations (mortar_step_raster_kernel: the step's workgroups lead the raster's grid and a
-// frame waits for its own descriptor), two launches otherwise (float formats, HIP-graph capture, instance groups):
+// frame waits for its own descriptor), two launches otherwise (float formats, HIP-graph capture):
 //   mortar_step_kernel : one LANE per environment instance.  Episode state machine, RNG, reward/done/info; emits a
 //                   16-byte frame descriptor per instance.  State is small fixed-size records in HBM, read and
 //                   written fully coalesced (lane i <-> record i).
@@ -332,7 +332,7 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
     }
     uint8_t* cmds = io.cmds + (size_t)i * P.cmd_cap;
     double reward = 0.0;
-    bool done = false;
+    bool done = false, cap = false;
     int success = 0;
     uint8_t glyph = 0xFF;
     bool rng_used = false;
@@ -444,6 +444,7 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
                         // list is unbounded, endless_mortar_mayhem.py:316-318): end the episode AND say so
                         raise_error(io.err, ERR_CMD_OVERFLOW);
                         done = true;
+                        cap = true;
                         s.vis_base = (uint16_t)(s.num_cmds - 1);
                     }
                     s.cur_cmd = 0;
@@ -506,6 +507,7 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
     reward_out[i] = (float)reward;
     if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
+    if (info.capacity_dev) info.capacity_dev[i] = cap ? 1 : 0;  // (include/memgym.h: the episode ended on a capacity of this build)
 
     MortarDesc d;
     memset(&d, 0, sizeof(d));
@@ -837,8 +839,8 @@ class MortarFamily : public Family {
         if (dirty_) rebuild();
         if (!seeds && !seeded_) throw std::runtime_error("reset(seed=None) before any seeded reset");
         for (auto& O : opt_) {  // the display schedule (commands x (duration + delay) entries) is indexed with 16 bits
-            const long long n_max = P_.variant == V_ENDLESS ? O->P.initial_count : O->st_command_count.max();
-            if (!P_.taskb && n_max * ((long long)O->st_show_dur.max() + O->st_show_delay.max()) > 65535)
+            const long long n_max = P_.variant == V_ENDLESS ? O->P.initial_count : O->st_command_count.max(O->P.command_count);
+            if (!P_.taskb && n_max * ((long long)O->st_show_dur.max(O->P.show_dur) + O->st_show_delay.max(O->P.show_delay)) > 65535)
                 throw OptionError{-3, "command_count x (command_show_duration + command_show_delay) exceeds the 65,535 entries of this build's display schedule"};
         }
         if (seeds) seeded_ = true;  // with a mask the caller is responsible for having seeded the other instances
@@ -859,7 +861,7 @@ class MortarFamily : public Family {
         upload_sets(s);
         const MortarStepArgs sa{P_, n_, io(), actions, reward, done, gt_dim() ? gt : nullptr, ib, autoreset};
         // one launch: mortar_step_raster_kernel (handles with ONE option set: the per-set step code reads its parameters from memory)
-        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !per_set() && !logic_event && !capturing(s)) {
+        if (obs_format == MG_OBS_U8_XYC && fuse_step() && !per_set() && !capturing(s)) {
             epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never the 0 a reset's (or the two-launch step's) descriptors carry
             ++ticket_;                    // claim words hold the ticket of the last one-launch step: never this one
             const int logic_wgs = (n_ + 255) / 256;

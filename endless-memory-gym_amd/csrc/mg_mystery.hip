@@ -51,6 +51,7 @@ struct MysteryParams {
     int bg_coop;        // Endless, fused launch: owed segments as queue entries of the service waves (small launches), not one per lane of frame workgroups
     int lazy_append;    // Endless, lazy: a segment appended during an episode is owed too, not a queue entry of the step (emp_step_a)
     int pre;            // Endless, lazy: the NEXT episode's first segment is generated ahead of time as a background job (see EMP_PRE)
+    int seg_cap, fall_cap;  // Endless: segments / fall-off cells an episode may reach (MAX_SEG / MAX_FALL; the lab build lowers them for tests)
     OptList cardinal;
     double r_goal, r_fall, r_progress, r_dense, r_step;
 };
@@ -678,6 +679,7 @@ __device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, int act0,
     reward_out[i] = (float)reward;
     if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
+    if (info.capacity_dev) info.capacity_dev[i] = 0;  // (the finite variants have no capacity an episode can reach)
     if (done && autoreset) return true;
     memset(&d, 0, sizeof(d));
     d.valid = 1;
@@ -944,7 +946,9 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
 
 // EndlessMysteryPathEnv.step (endless_mystery_path.py:282-444), first part: move; returns 1 if a new segment is due
 // (`current_segment > num_segments - 2`, :333-335), which the wave then generates before the second part runs.
-__device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, int a, int& nx, int& ny) {
+// Bit 0 of the result: a segment is due; bit 1: the instance has reached the capacity of its segment store (EMP_CAP).
+constexpr int EMP_DUE = 1, EMP_CAP = 2;
+__device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, int a, int& nx, int& ny, int* io_err) {
     int a0 = a == 1 ? 2 : 0, a1 = a == 2 ? 1 : (a == 3 ? 2 : 0);
     if (!s.off) {
         int before = s.ax;
@@ -969,6 +973,12 @@ __device__ int emp_step_a(const MysteryParams& P, int i, MysteryCore& s, int a, 
     // read of a segment that is still owed (the next node's direction at the end of the last generated segment) makes the
     // owed ones due now -- conservative: within two columns of the end of what exists
     int owed = EMP_OWED(s);
+    if (s.cur_seg > s.num_seg + owed - 2 && s.num_seg + owed >= P.seg_cap) {
+        // the segment store is full (the reference's list is unbounded, pygame_assets.py:559): nothing is appended, this step ends the
+        // episode and says why (include/memgym.h: mg_info_buffers.capacity_dev, error bit 4); what is owed is generated if the step can see it
+        raise_error(io_err, 4);
+        return 2 | ((owed > 0 && nx >= (G + 1) * s.num_seg - 2) ? 1 : 0);
+    }
     if (s.cur_seg > s.num_seg + owed - 2) {
         // Round 5: the segment the reference appends now (:333-335) is OWED like a reset's second and third -- the agent has only
         // entered the last but one, the new one starts eight columns ahead -- and generated by the next background job instead of by
@@ -1000,10 +1010,10 @@ static __device__ unsigned long long g_lab_step_clock[12 * 4096];
 // records, then the queue's counter), not a matter of bytes (profiles/r03_emp.md section 7, r05_emp.md).
 template <bool OWN_RESET>
 __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
-                           uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d) {
+                           uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d, bool cap = false) {
     typedef uint32_t q4 __attribute__((ext_vector_type(4)));
     double reward = 0.0;
-    bool done = false;
+    bool done = cap;  // cap: the segment store is full and the reference would append now (emp_step_a) -- the episode ends here
     const int seg = s.cur_seg;
     SegRec R, Rprev;
     R.seg = -1;
@@ -1107,8 +1117,11 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
             }
             if (found) done = true;
             if (!found) {
-                if (s.n_falloff < MAX_FALL) fl[s.n_falloff++] = key;
-                else raise_error(io.err, 8);
+                if (s.n_falloff < P.fall_cap) fl[s.n_falloff++] = key;
+                else {  // the list of fall-off cells is full (the reference's is unbounded, endless_mystery_path.py:385-393): the episode ends
+                    raise_error(io.err, 8);
+                    done = cap = true;
+                }
             }
         }
         // reset all stamina flags -- only segments visited since the last reset can hold any; whole records at a time
@@ -1161,6 +1174,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     reward_out[i] = (float)reward;
     if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
     done_out[i] = done ? 1 : 0;
+    if (info.capacity_dev) info.capacity_dev[i] = cap ? 1 : 0;
     LAB_STEP_CLOCK(9);
     bool fresh = false;
     if (done && autoreset) {
@@ -1387,14 +1401,15 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
     MysteryCore s = load_core(&io.core[i]);
     asm volatile("" : "+v"(act));  // ... (a use the compiler cannot move: without it the request is issued after the record has arrived)
     int nx = 0, ny = 0;
-    const int due = emp_step_a(P, i, s, act, nx, ny);
+    const int ra = emp_step_a(P, i, s, act, nx, ny, io.err);
+    const int due = ra & EMP_DUE;
     LAB_STEP_CLOCK(1);
     MysteryDesc d;
     bool q = false, bg = false;
     if (due) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
     } else {
-        q = emp_step_b<!PS>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d);
+        q = emp_step_b<!PS>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d, (ra & EMP_CAP) != 0);
         LAB_STEP_CLOCK(2);
         if (q) {
             queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
@@ -1455,12 +1470,15 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
         // the new segment is due: whatever is still owed comes first (stream order), or -- emp_step_a's conservative test --
         // only what is owed is due and `current_segment > num_segments - 2` does not hold yet
         int want = 0;
+        bool cap = false;
         if (me) {
             if (entry & EMP_Q_OWED) {  // a background job: one owed segment, nothing else
                 want = EMP_OWED(s) > 0 ? 1 : 0;
                 EMP_OWED(s) = (uint8_t)(EMP_OWED(s) - want);
             } else {
-                want = EMP_OWED(s) + ((s.cur_seg > s.num_seg + EMP_OWED(s) - 2) ? 1 : 0);
+                const bool append = s.cur_seg > s.num_seg + EMP_OWED(s) - 2;
+                cap = append && s.num_seg + EMP_OWED(s) >= P.seg_cap;  // (emp_step_a has raised the error bit; the step below ends the episode)
+                want = EMP_OWED(s) + ((append && !cap) ? 1 : 0);
                 EMP_OWED(s) = 0;
             }
         }
@@ -1474,7 +1492,7 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
         }
         if (me)
             reset_me = emp_step_b<false>(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
-                                         gti, info, autoreset, d) ? 1 : 0;
+                                         gti, info, autoreset, d, cap) ? 1 : 0;
         reset_me = bcast(reset_me, 0);
     }
     if (reset_me) {
@@ -2115,6 +2133,8 @@ class MysteryFamily : public Family {
         P_.svc_prio = [endless] { const char* e = lab_env("MEMGYM_SVC_PRIO"); return e ? atoi(e) : (endless ? 1 : 0); }();
         P_.path_help = [] { const char* e = lab_env("MEMGYM_PATH_HELP"); return e ? atoi(e) : 1; }();
         P_.bg_coop = lab_int("MEMGYM_EMP_BG_COOP", n <= 20480 ? 1 : 0);
+        P_.seg_cap = std::min(MAX_SEG, std::max(4, lab_int("MEMGYM_EMP_SEG_CAP", MAX_SEG)));    // (lab build: tests reach the capacities in a few
+        P_.fall_cap = std::min(MAX_FALL, std::max(1, lab_int("MEMGYM_EMP_FALL_CAP", MAX_FALL)));  // hundred steps, tests/test_gpu_capacity.py)
         lazy_wanted_ = endless && [] { const char* e = lab_env("MEMGYM_EMP_LAZY"); return e ? atoi(e) != 0 : true; }();
         // the next episode's first segment ahead of time (EMP_PRE): with the lane-per-path background jobs of the larger launches
         // (as entries of the service queue -- bg_coop -- a record ahead of time costs the path it saves)
@@ -2482,6 +2502,7 @@ class MysteryFamily : public Family {
         d.endless = s.endless; d.grid = s.grid; d.n = s.n; d.depth = s.depth; d.agent_radius = s.agent_radius; d.sprite_dim = s.sprite_dim;
         d.v_axis_i = s.v_axis_i; d.v_diag_i = s.v_diag_i; d.tile = s.tile; d.cross_dim = s.cross_dim; d.camera_offset = s.camera_offset;
         d.svc_prio = s.svc_prio; d.lazy = s.lazy; d.path_help = s.path_help; d.bg_coop = s.bg_coop; d.pre = s.pre; d.lazy_append = s.lazy_append;
+        d.seg_cap = s.seg_cap; d.fall_cap = s.fall_cap;
     }
     bool per_set() const { return set_of_ != nullptr && !extra_.empty(); }
     // the sets as the kernels read them, stream-ordered behind what the stream holds (pageable source: staged before the call returns)

@@ -356,7 +356,8 @@ int mg_obs_set_search_ms(double ms) {
 }
 
 // bench.py's per-box control (see store_probe_*_kernel): one launch of `pattern` over n_frames x 21,168 bytes at `buf`, on `stream`.
-int mg_store_probe(void* buf, size_t n_frames, int pattern, hipStream_t stream) {
+int mg_store_probe(void* buf, size_t n_frames, int pattern, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (!buf || n_frames == 0 || n_frames > (1u << 30) || pattern < 0 || pattern > 3) {
         mg::set_error("mg_store_probe: bad arguments");
         return -1;

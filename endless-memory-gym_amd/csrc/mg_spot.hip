@@ -636,7 +636,9 @@ struct Trig {
 // Spotlight.__init__: 5 draws (radius, speed, start angle, target delta, offset delta).  `ls` = this lane's slot id: every lane of
 // the instance draws the same numbers; the lane owning the slot the free mask hands out stores the record AND gets it back in
 // `rec` (reading it back from memory is two round trips in every wave in which any instance spawned, i.e. in every launch).
-__device__ __forceinline__ void new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SlotRec* rec = nullptr) {
+// Returns false when all SLOTS slots are taken (the reference's list is unbounded, endless_searing_spotlights.py:191): the draws are
+// consumed, no spotlight is added, error bit 1 is raised -- and the step that called ends the episode (mg_info_buffers.capacity_dev).
+__device__ __forceinline__ bool new_spot(const SpotParams& P, const SpotIO& io, int i, int ls, SpotCore& s, Pcg& g, SlotRec* rec = nullptr) {
     int radius = g.integers(P.r_lo, P.r_hi);
     double speed = g.uniform(P.speed_lo, P.speed_hi);
     int start = g.integers(0, 360);
@@ -644,13 +646,13 @@ __device__ __forceinline__ void new_spot(const SpotParams& P, const SpotIO& io, 
     int offset = target + g.integers(-135, 135);
     if (s.n_spots >= SLOTS || s.free_mask == 0) {
         raise_error(io.err, 1);
-        return;
+        return false;
     }
     int slot = __ffs(s.free_mask) - 1;
     s.free_mask &= ~(1u << slot);
     s.order |= (uint64_t)slot << (4 * s.n_spots);
     s.n_spots++;
-    if (slot != ls) return;
+    if (slot != ls) return true;
     size_t k = (size_t)i * SLOTS + slot;
     SlotRec n;
     n.r = radius | (P.black_background ? 0x80 : 0);  // bit 7: Spotlight.has_border
@@ -662,6 +664,7 @@ __device__ __forceinline__ void new_spot(const SpotParams& P, const SpotIO& io, 
     io.sp_speed[k] = n.speed;
     io.sp_ang[k] = n.ang;
     if (rec) *rec = n;
+    return true;
 }
 
 // The spotlights a reset starts with (free_mask == 0xFFFF: the q-th takes slot q, which lane q owns): 5 draws each, one after another
@@ -1047,7 +1050,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
 
     // ---- spotlight task ----
     double reward = 0.0, r = 0.0;
-    bool spot_done = false;
+    bool spot_done = false, cap = false;  // cap: a spotlight was due and all slots are taken -- this step ends the episode (new_spot)
     s.spawn_timer++;
     if constexpr (EN) {
         if (__builtin_expect(s.spawn_timer >= P.spawn_interval, 0)) {
@@ -1055,13 +1058,13 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
             f_spawn = true;
 #endif
             rng_used = true;
-            new_spot(P, io, i, ls, s, g, &mine);
+            cap = !new_spot(P, io, i, ls, s, g, &mine);
             s.spawn_timer = 0;
         }
     } else if (s.n_intervals > 0) {
         if (__builtin_expect(s.spawn_timer >= P.interval0, 0)) {
             rng_used = true;
-            new_spot(P, io, i, ls, s, g, &mine);
+            cap = !new_spot(P, io, i, ls, s, g, &mine);
             s.n_intervals--;
             s.spawn_timer = 0;
         }
@@ -1224,6 +1227,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
         s.t++;
         if (s.t == P.max_steps) done = true;
     }
+    done = done || cap;
 #ifdef MG_LAB_SPOT_CLOCK
     asm volatile("" ::"v"(done));
 #endif
@@ -1248,6 +1252,7 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
         reward_out[i] = (float)reward;
         if (info.reward64_dev) info.reward64_dev[i] = reward;  // the reference's Python float, unrounded
         done_out[i] = done ? 1 : 0;
+        if (info.capacity_dev) info.capacity_dev[i] = cap ? 1 : 0;
     }
 
     // debug view only: the (rotated_agent_surface, rotated_agent_rect) pair of this step -- a reset leaves it alone, and the

@@ -19,7 +19,7 @@ MG_MAX_OPTION_SETS = 8
 
 class InfoBuffers(C.Structure):
     _fields_ = [("struct_size", C.c_size_t), ("ep_reward_dev", C.c_void_p), ("ep_length_dev", C.c_void_p), ("aux_dev", C.c_void_p * MG_INFO_SLOTS),
-                ("final_obs_dev", C.c_void_p), ("reward64_dev", C.c_void_p), ("gt64_dev", C.c_void_p)]
+                ("final_obs_dev", C.c_void_p), ("reward64_dev", C.c_void_p), ("gt64_dev", C.c_void_p), ("capacity_dev", C.c_void_p)]
 
 
 class SingleIO(C.Structure):  # include/memgym.h: mg_single_io (host addresses of pinned, device-mapped buffers)
@@ -48,9 +48,6 @@ def _load():
     for f in ("mg_num_envs", "mg_action_dim", "mg_gt_dim"):
         getattr(L, f).argtypes = [C.c_void_p]
         getattr(L, f).restype = C.c_int32
-    L.mg_set_groups.argtypes = [C.c_void_p, C.c_int]
-    L.mg_groups.argtypes = [C.c_void_p]
-    L.mg_groups.restype = C.c_int32
     L.mg_info_name.argtypes = [C.c_void_p, C.c_int]
     L.mg_info_name.restype = C.c_char_p
     L.mg_set_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]

@@ -100,6 +100,17 @@ class ObsGatherer:
                                 if self.rank == dst else [None, None])
         self.work_packed = [None, None]
         self.t = 0
+        # what the environment stored into before this gatherer re-routed it (restored by close())
+        self._own = (env.obs, getattr(env, "reward", None), getattr(env, "done_u8", None))
+
+    def close(self):
+        """Join the outstanding gathers and hand the environment its OWN observation / reward / done tensors back: from the next
+        step on the env stores into them again and nothing returned by it aliases this gatherer's double buffers."""
+        self.drain()
+        obs, rew, done = self._own
+        self.env.use_obs_buffer(obs)
+        if self.scalars and rew is not None:
+            self.env.use_step_buffers(rew, done)
 
     def _join(self, k):
         for w in (self.work, self.work_packed):
@@ -108,6 +119,9 @@ class ObsGatherer:
                 w[k] = None
 
     def step(self, actions):
+        """env.step(actions) into this step's half of the double buffers, then the asynchronous gathers of that half.
+        LIFETIME of what it returns: obs, reward and done are views of the double buffers -- valid until the step AFTER NEXT
+        overwrites them (like gathered()); a trainer that keeps them longer copies them.  close() ends the arrangement."""
         k = self.t & 1
         self._join(k)  # the gathers that still read these buffers (step t - 2): the launch stream waits for them
         self.env.use_obs_buffer(self.bufs[k])
@@ -224,8 +238,15 @@ class PeerObsBuffer:
         streams at the same time (it takes the place of fence()'s 4-byte all-reduce)."""
         self.n_local = int(env.num_envs)
         self._packed = packed_scalars(self.n_local, self.device)
-        env.use_step_buffers(self._packed[1], self._packed[2])
+        self._scalars_env, self._scalars_own = env, (env.reward, env.done_u8)
+        env.use_step_buffers(self._packed[1], self._packed[2])  # (from now on env.step()'s reward / done are views of the packed buffer: valid until the next step)
         self._recv_packed = [torch.empty_like(self._packed[0]) for _ in range(self.world)] if self.rank == self.dst else None
+
+    def unbind_scalars(self):
+        """the environment stores its rewards / dones into its own tensors again"""
+        if getattr(self, "_scalars_env", None) is not None:
+            self._scalars_env.use_step_buffers(*self._scalars_own)
+            self._scalars_env = None
 
     def fence_with_scalars(self):
         """After it returns on dst (stream-ordered on nccl), every rank's frames of the step are in `full` and dst holds every

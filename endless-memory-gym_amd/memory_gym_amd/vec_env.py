@@ -118,7 +118,7 @@ class VecMemoryGym:
                    "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
     def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False,
-                 obs_buffer=None, obs_placement=None, groups=1, ground_truth64=False):
+                 obs_buffer=None, obs_placement=None, ground_truth64=False, on_capacity="raise"):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -133,12 +133,6 @@ class VecMemoryGym:
         h = C.c_void_p()
         _native.check(_native.LIB.mg_create(env_id.encode(), self.num_envs, self.device.index, C.byref(h)), "mg_create")
         self._h = h
-        # groups > 1 (1, 2, 4, 8; num_envs divisible): the instances are stepped in that many blocks on streams of their own,
-        # one block's logic kernel under the previous block's raster launch (include/memgym.h: mg_set_groups).  Same results.
-        self.groups = int(groups)
-        if self.groups != 1:
-            with torch.cuda.device(self.device):
-                _native.check(_native.LIB.mg_set_groups(h, self.groups), "mg_set_groups")
         self.action_dim = _native.LIB.mg_action_dim(h)
         self.gt_dim = _native.LIB.mg_gt_dim(h)
         self.vec_dim = _native.LIB.mg_vec_dim(h)
@@ -208,6 +202,17 @@ class VecMemoryGym:
         self._info.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
         self._info.reward64_dev = self.reward64.data_ptr()
         self._info.gt64_dev = self.gt64.data_ptr() if self.gt64 is not None else None
+        # What happens when ONE instance reaches a capacity of this build (128 path segments, 128 fall-off cells, 512 commands, 16 live
+        # spotlights; the reference's lists are unbounded).  The kernels end that instance's episode and raise a sticky error bit either
+        # way.  "raise" (default): step() turns the bit into a RuntimeError -- nothing that differs from the reference goes unnoticed.
+        # "truncate": step() reports the instance as truncated (`truncated[i]`, info["capacity_exceeded"][i]) and the batch goes on: one
+        # instance of 262,144 that outlives a list does not abort a rollout (missing #1).
+        if on_capacity not in ("raise", "truncate"):
+            raise ValueError("on_capacity must be 'raise' or 'truncate'")
+        self.on_capacity = on_capacity
+        self.capacity_u8 = torch.zeros(N, dtype=torch.uint8, device=dev) if on_capacity == "truncate" else None
+        self._info.capacity_dev = self.capacity_u8.data_ptr() if self.capacity_u8 is not None else None
+        self._tolerated = self.CAPACITY_BITS if on_capacity == "truncate" else 0
         self.reset_params = process_reset_params(env_id, None)
         self._applied = dict(DEFAULTS[env_id])
         self._set_params = [self._applied]  # what each option set of the handle holds (set 0 = the handle-wide one)
@@ -216,7 +221,8 @@ class VecMemoryGym:
         self.autoreset = True
         self._seeded = False  # no instance has an RNG stream before the first reset (or load_state_dict)
         self._swapped = False  # use_obs_buffer() since the last call that wrote every row
-        self._truncated = torch.zeros(N, dtype=torch.bool, device=dev)  # `truncation` is always False in the reference
+        # `truncation` is always False in the reference; on_capacity="truncate": True where the episode ended on a capacity of this build
+        self._truncated = self.capacity_u8.view(torch.bool) if self.capacity_u8 is not None else torch.zeros(N, dtype=torch.bool, device=dev)
         self._n_actions = self.num_envs * self.action_dim
         self._p_err = C.byref(self._err)
         self._bind_step()
@@ -247,6 +253,8 @@ class VecMemoryGym:
             info[nm] = t
         if self.gt_dim:
             info["ground_truth"] = self.gt if self.gt64 is None else self.gt64
+        if self.capacity_u8 is not None:
+            info["capacity_exceeded"] = self._truncated
         self._info_dict = info
 
     def _write_set(self, set_id, params):
@@ -388,7 +396,7 @@ class VecMemoryGym:
             self._launch_step(a)
         self._swapped = False  # a step writes every row
         _native.LIB.mg_peek_errors(self._h, self._p_err)  # host-mapped word: no synchronisation
-        if self._err.value:
+        if self._err.value & ~self._tolerated:
             self.check_errors()
         info = dict(self._info_dict)
         if self.final_obs is not None and self.autoreset:  # rows valid where done_mask is set
@@ -510,6 +518,8 @@ class VecMemoryGym:
         _native.check(_native.LIB.mg_get_profile(self._h, kind, C.byref(ms), C.byref(n)), "mg_get_profile")
         return ms.value, n.value
 
+    CAPACITY_BITS = 1 | 4 | 8 | 32  # the bits that say "an instance reached a capacity of this build and its episode was ended"
+
     ERROR_BITS = {1: "more than 16 live spotlights in one instance (raise spawn_interval / spot speeds or lower initial_spawns)",
                   2: "path generation found no valid path (pygame_assets.py:723-724 raises here too)",
                   4: "endless path longer than 128 segments", 8: "more than 128 distinct fall-off cells",
@@ -523,10 +533,13 @@ class VecMemoryGym:
         step() looks at the same bits after every call without synchronising and ends up here when one is set."""
         f = C.c_int()
         _native.check(_native.LIB.mg_poll_errors(self._h, C.byref(f)), "mg_poll_errors")
+        self.capacity_events = getattr(self, "capacity_events", 0) | (f.value & self._tolerated)  # (kinds seen so far, on_capacity="truncate")
+        f.value &= ~self._tolerated
         if f.value:
             what = "; ".join(m for b, m in self.ERROR_BITS.items() if f.value & b)
+            hint = " (make(..., on_capacity='truncate') reports such instances as truncated instead of raising)" if f.value & self.CAPACITY_BITS else ""
             raise RuntimeError("memory_gym_amd: device error flags 0x%x: %s -- the frames of the affected instances are "
-                               "no longer the reference's (include/memgym.h: mg_poll_errors)" % (f.value, what))
+                               "no longer the reference's (include/memgym.h: mg_poll_errors)%s" % (f.value, what, hint))
 
     def rng_words(self, i):
         w = np.zeros(6, np.uint64)
@@ -603,8 +616,14 @@ class MemoryGymEnv(_EnvBase):
         self._ep_length_host = view(io.ep_length, C.c_int32, (1,))
         self._aux_host = [view(io.aux[k], C.c_float, (1,)) for k in range(len(self.vec.info_names))]
         self._two_actions = self.vec.action_dim == 2
-        self._stream = C.c_void_p(torch.cuda.current_stream(self.vec.device).cuda_stream)
+        # (the launch stream is torch's CURRENT stream at every call, like the batched path: a handle cached at construction or at the last
+        # reset may be another stream than the caller's by now, or a released one -- ADVICE r5)
+        self._raw_stream = self.vec._raw_stream
         self._step_fn, self._h, self._errword = _native.LIB.mg_single_step, self.vec._h, self.vec._err
+        if self.vec.vector_obs is not None:
+            # mg_single_open re-bound the handle's vector observation to the mapped block: `vec.vector_obs` (the batched tensor) is no
+            # longer written; this adapter's observations carry the vector from the mapped block
+            self.vec.vector_obs_stale = True
         self._peek = _native.LIB.mg_peek_errors
 
     # ---- gymnasium.Env protocol surface that exists with or without gymnasium
@@ -642,8 +661,7 @@ class MemoryGymEnv(_EnvBase):
             v._apply_options(options)
             if seed is None and not v._seeded:  # first reset without a seed: OS entropy, like gymnasium's np_random(None)
                 seed = int(np.random.SeedSequence().generate_state(1, np.uint64)[0] >> np.uint64(1))
-            self._stream = C.c_void_p(torch.cuda.current_stream(v.device).cuda_stream)
-            _native.check(_native.LIB.mg_single_reset(self._h, 0 if seed is None else int(seed), 0 if seed is None else 1, self._stream), "mg_single_reset")
+            _native.check(_native.LIB.mg_single_reset(self._h, 0 if seed is None else int(seed), 0 if seed is None else 1, C.c_void_p(self._raw_stream())), "mg_single_reset")
             v._seeded = True
         out = {}
         if v.gt_dim:
@@ -655,7 +673,7 @@ class MemoryGymEnv(_EnvBase):
             a0, a1 = int(action[0]), int(action[1])
         else:
             a0 = a1 = int(action)
-        rc = self._step_fn(self._h, a0, a1, self._stream)
+        rc = self._step_fn(self._h, a0, a1, self._raw_stream())
         if rc != 0:
             _native.check(rc, "mg_single_step")
         self._peek(self._h, C.byref(self._errword))  # host-mapped word: no synchronisation

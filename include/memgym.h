@@ -52,6 +52,14 @@ typedef struct mg_info_buffers {
      * endless_searing_spotlights.py:407,496, endless_mystery_path.py:92-97) -- [num_envs][mg_gt_dim]; gt_dev is its float32
      * rounding (0.6 -> 0.60000002).  Costs one small launch behind the step's; see also mg_ground_truth64. */
     double* gt64_dev;
+    /* Optional (round 6): uint8 [num_envs], written by every mg_step: 1 where the instance's episode was ENDED IN THIS STEP BECAUSE IT
+     * REACHED A CAPACITY OF THIS BUILD (done_dev is 1 for it as well), else 0.  The reference's lists grow without limit -- path
+     * segments (pygame_assets.py:559, called from endless_mystery_path.py:333-335), fall-off cells (:385-393), the command list
+     * (endless_mortar_mayhem.py:311-333), live spotlights (endless_searing_spotlights.py:191) -- here they hold 128 segments, 128
+     * cells, 512 commands and 16 spotlights per instance.  An instance that would need one more ends its episode like a truncation
+     * (a reset follows under autoreset); the sticky error bit (mg_poll_errors: 4, 8, 32, 1) is raised as before, so a caller that
+     * ignores this array still hears about it.  With it a trainer treats the instance as truncated and goes on with the batch. */
+    uint8_t* capacity_dev;
 } mg_info_buffers;
 
 /* gymnasium.make(id) + Env.__init__  (memory_gym/__init__.py:13-61; e.g. mortar_mayhem_grid.py:55-90).
@@ -60,18 +68,6 @@ typedef struct mg_info_buffers {
 int mg_create(const char* env_id, int32_t num_envs, int device, mg_env** out);
 void mg_destroy(mg_env* env);
 const char* mg_last_error(void);
-
-/* Instance groups (optional; the reference has no counterpart: it steps one instance at a time).  A handle's instances can
- * be split into `groups` contiguous, equally treated blocks (1, 2, 4 or 8; num_envs must be divisible).  mg_reset / mg_step
- * then launch each block's kernels on a stream of its own, staggered: block g's logic kernel waits for block g - 1's, so it
- * runs UNDER block g - 1's raster launch (the logic kernels are latency-bound, the raster kernels HBM-bound).  MEASURED SLOWER
- * than one block on ROCm 7.2 -- x0.8 for two blocks, every cross-stream event dependency costs ~10-25 us of stream time
- * (profiles/r03_groups.md) -- so it stays an opt-in; the caller's stream waits for all blocks at the end of the call
- * (stream-ordered: no host synchronisation).  Results are bit-identical to groups = 1: instance i is the same instance with
- * the same RNG stream whatever the grouping (tests/test_gpu_groups.py).  All buffers keep their [num_envs] layout.  Must be
- * called before the first mg_reset; option calls made earlier are replayed.  Checkpoints record the grouping. */
-int mg_set_groups(mg_env* env, int groups);
-int32_t mg_groups(const mg_env* env);
 
 /* Static properties (action_space / observation_space / ground_truth_space of the reference classes):
  * mg_action_dim: 1 = Discrete(4) (mortar_mayhem_grid.py:82, endless_mystery_path.py:83),
@@ -199,10 +195,10 @@ int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream);
 
 /* Checkpoint hooks (the reference cannot serialise an env; SoA state makes it free).  Synchronous.
  * mg_state_size: bytes needed.  The blob starts with a 64-byte header {magic "MGSTATE1", MG_STATE_VERSION, num_envs,
- * payload bytes, FNV-1a of the env id, groups}; the layout behind it is private to one MG_STATE_VERSION.  mg_set_state refuses
+ * payload bytes, FNV-1a of the env id}; the layout behind it is private to one MG_STATE_VERSION.  mg_set_state refuses
  * (-1, message in mg_last_error) a blob whose magic, version, env id, num_envs or payload size differ from the handle's
  * instead of mis-assigning it. */
-#define MG_STATE_VERSION 6u
+#define MG_STATE_VERSION 7u
 size_t mg_state_size(const mg_env* env);
 int mg_get_state(mg_env* env, void* host_buf, size_t size);
 int mg_set_state(mg_env* env, const void* host_buf, size_t size);
@@ -277,14 +273,14 @@ typedef struct mg_obs_alloc_info {
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out_dev, mg_obs_alloc_info* info);
 int mg_obs_free(void* obs_dev);
 int mg_obs_set_search_ms(double ms);  /* process-wide; >= 0 */
-/* Measurement hook (bench.py's per-box control: roofline.box_ceiling_GBps): ONE launch of a pure store stream over
- * n_frames x 21,168 bytes at obs_dev on `stream`; the caller times it with events.  pattern 0 = linear fill, one 16-byte
- * store per thread (the memory system's ceiling for stores at this size and placement); pattern 1 = the raster's store
- * shape without compose work (persistent 256-lane workgroups writing whole frames; the raster's grid and residency) = the
- * ceiling of a frame-shaped stream; patterns 2 / 3 = other frame-shaped streams measured in round 5 (pairs of adjacent vectors per
- * lane; pairs + each wave a contiguous quarter of the frame: tools/store_shapes.py, profiles/r05_store_shapes.md).  Overwrites the
- * buffer with zeros. */
-int mg_store_probe(void* obs_dev, size_t n_frames, int pattern, hipStream_t stream);
+/* Measurement hook (bench.py's per-box control: roofline.box_probe_GBps).  DESTROYS THE BUFFER'S CONTENTS: the n_frames x 21,168
+ * bytes at obs_dev are overwritten with zeros -- a caller that probes a live observation buffer steps or renders (mg_render) afterwards.
+ * ONE launch of a pure store stream on `stream`; the caller times it with events.  pattern 0 = linear fill, one 16-byte store per
+ * thread (the memory system's ceiling for stores at this size and placement); pattern 1 = the raster's store shape without compose
+ * work (persistent 256-lane workgroups writing whole frames; the raster's grid and residency): a CONTROL for the raster, not a ceiling
+ * (a raster with compose work can beat it); patterns 2 / 3 = other frame-shaped streams measured in round 5 (pairs of adjacent
+ * vectors per lane; pairs + each wave a contiguous quarter of the frame: tools/store_shapes.py, profiles/r05_store_shapes.md). */
+int mg_store_probe(void* obs_dev, size_t n_frames, int pattern, void* stream);
 /* Test hook: live buffers, pooled spare pieces, bytes of virtual address space reserved so far. */
 int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* reserved_va_bytes);
 

@@ -51,8 +51,6 @@ int main(int argc, char** argv) {
     mg_env* env = nullptr;
     MG_OK(mg_create(env_id, n, 0, &env));
     const int adim = mg_action_dim(env), n_act = adim == 1 ? 4 : 3;
-    // optional 5th argument: the number of instance groups (include/memgym.h mg_set_groups; results must not depend on it)
-    if (argc > 4) MG_OK(mg_set_groups(env, atoi(argv[4])));
 
     uint8_t *obs_d, *done_d;
     float* rew_d;
@@ -149,7 +147,7 @@ int main(int argc, char** argv) {
             return 1;
         }
     }
-    printf("OK %s: %d instances x %d steps in %d group(s), %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, (int)mg_groups(env), episodes);
+    printf("OK %s: %d instances x %d steps, %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, episodes);
     (void)hipFree(rew64_d);
     mg_destroy(env);
     mgo_batch_destroy(ref);

@@ -56,3 +56,19 @@ def test_reset_params_mirror_the_reference():
         rp.process_reset_params("MortarMayhem-Grid-v0", {"arena_size": 7})
     # calc_max_episode_steps with the reference's swapped arguments: 119 for MM-Grid, 275 for MM
     assert rp.calc_max_episode_steps(10, 3, 1, 6, 2) == 119 and rp.calc_max_episode_steps(10, 3, 1, 18, 6) == 275
+
+
+def test_public_header_compiles_as_plain_c_and_cxx_without_hip(tmp_path):
+    """include/memgym.h promises `void*` streams so that a trainer needs no HIP include (mg_store_probe had been declared
+    with a hipStream_t): a C and a C++ translation unit that include nothing but the header must compile with the host compilers."""
+    import shutil
+    import subprocess
+
+    inc = os.path.join(ROOT, "include")
+    for cc, ext, flags in (("gcc", "c", ["-std=c99"]), ("g++", "cpp", ["-std=c++11"])):
+        if not shutil.which(cc):
+            pytest.skip(cc + " not installed")
+        src = tmp_path / ("use_header." + ext)
+        src.write_text('#include "memgym.h"\nint probe(void* b, void* s) { mg_single_io io; io.struct_size = sizeof io; (void)io; return mg_store_probe(b, 1, 0, s); }\n')
+        p = subprocess.run([cc] + flags + ["-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / ("o." + ext))], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr

@@ -116,6 +116,7 @@ def _gatherer_worker(rank, world, port, n_total, out_dir):
     m = _load_dist_module()
     lo, hi = m.shard_range(n_total, rank, world)
     env = _FakeEnv(lo, hi)
+    own = (env.obs, env.reward, env.done_u8)
     g = m.ObsGatherer(env)
     assert g.bufs[0] is not g.bufs[1]
     for t in range(7):
@@ -140,7 +141,11 @@ def _gatherer_worker(rank, world, port, n_total, out_dir):
                 assert g.gathered() is frames
             else:
                 assert got is None
-    g.drain()
+    g.close()  # joins the gathers and gives the environment its own tensors back
+    assert env.obs is own[0] and env.reward is own[1] and env.done_u8 is own[2]
+    kept = g.packed[0][1].clone()
+    env.step(1)
+    assert torch.equal(g.packed[0][1], kept), "a step after close() must not touch the gatherer's buffers"
     if rank == 0:
         open(os.path.join(out_dir, "ok"), "w").write("ok")
     dist.barrier()

@@ -138,12 +138,12 @@ def test_every_instance_competent(label, env_id, n, steps, every, options, count
 
 @pytest.mark.slow
 def test_endless_mortar_lists_of_a_dozen():
-    """Endless-MortarMayhem-v0 at the C5 shard size under competent play until command lists hold a dozen entries and more on over
+    """Endless-MortarMayhem-v0 under competent play until command lists hold a dozen entries and more on over
     1 % of the instances (endless_mortar_mayhem.py:311-333: every completed list grows by one command and is executed again from the
     start -- 1,628 steps for the eleven lists before the twelfth with the default timings)."""
     if os.environ.get("MEMGYM_FAST"):
         pytest.skip("MEMGYM_FAST")
-    n = 32768
+    n = 16384  # (the mortar family's one launch is the same arrangement at every size; the C5 shard size itself: the competent run above)
     stats = {"counters": ("cmd_list_max", "cmd_list_ge12")}
     _lock_step("C5 long", "Endless-MortarMayhem-v0", n, 1760, 220, None, eps=0.1, stats=stats)
     assert stats["cmd_list_ge12"] > n // 100 and stats["max_max_command_sequence"] >= 11, stats
