@@ -196,8 +196,15 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
         if not peer.ok:  # no peer access between this GPU and rank 0's: fall back to the collective
             note = "peer mapping unavailable (%s): fell back to the RCCL gather" % peer.why
             peer, gather = None, "rccl"
+    own_buffer = None
+    pad = int(os.environ.get("MEMGYM_BENCH_OBS_PAD_FRAMES", "0"))
+    if pad and peer is None and obs_format == "u8_xyc":
+        # measurement hook (library variants built with -DMG_LAB_OBS_STRIDE: frames at a padded stride need room behind the N-th frame)
+        from memory_gym_amd.vec_env import alloc_obs_buffer
+        big, _ = alloc_obs_buffer((n_local + pad, 84, 84, 3), torch.uint8, dev)
+        own_buffer = big[:n_local]
     env = memory_gym_amd.make(env_id, num_envs=n_local, device=dev.index, obs_format=obs_format,
-                              obs_buffer=peer.local if peer else None)
+                              obs_buffer=peer.local if peer else own_buffer)
     # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
     env.reset(seed=shard_seeds(n_total, rank, world, base_seed=0, device=dev))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

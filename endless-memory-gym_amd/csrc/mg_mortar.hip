@@ -612,7 +612,8 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
     R.T = A.tables;
     R.tid = tid;
     const int stride = (int)gridDim.x - logic_wgs;
-    for (int env = (int)blockIdx.x < logic_base ? (int)blockIdx.x : (int)blockIdx.x - logic_wgs; env < n; env += stride) {
+    for (int v = (int)blockIdx.x < logic_base ? (int)blockIdx.x : (int)blockIdx.x - logic_wgs; v < n; v += stride) {
+        const int env = xcd_grouped_frame(v, n);
         // every lane reads the same words (one transaction per wave); no barrier: the waves of a workgroup wait separately
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.io.desc + env);
         uint32_t w[4];

@@ -109,6 +109,72 @@ __global__ __launch_bounds__(256) void store_probe_frames_kernel(u32x4* out, int
     }
 }
 
+// Pattern 4 (round 6): the frame walk with LINE-ALIGNED ownership -- a frame is 21,168 B = 165.375 cache lines of 128 B, so
+// every frame boundary but each eighth splits a line between two workgroups; here workgroup f writes [up128(21,168 f), up128(21,168 (f + 1)))
+// instead: the same bytes per launch, every 128-byte line written by exactly one workgroup (what a raster would do that takes the stray
+// 48 .. 80 bytes of its neighbour's frame through an exchange).
+__global__ __launch_bounds__(256) void store_probe_lines_kernel(u32x4* out, int n) {
+    extern __shared__ unsigned char occupancy_pad[];
+    const int tid = threadIdx.x;
+    const size_t end = (size_t)n * 1323;
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        size_t v0 = ((size_t)f * 1323 + 7) & ~(size_t)7, v1 = ((size_t)(f + 1) * 1323 + 7) & ~(size_t)7;  // in 16-byte vectors: 8 per line
+        if (f == 0) v0 = 0;
+        if (v1 > end) v1 = end;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const size_t v = v0 + tid + 256 * j;
+            if (v < v1) out[v] = (u32x4)(0u);
+        }
+    }
+}
+// Pattern 6: the raster's frame walk with an XCD-AWARE order of frames: workgroups are dealt to the eight XCDs round-robin (workgroup b ->
+// XCD b % 8, each with an L2 of its own), so neighbouring frames -- whose shared 64-byte block at the boundary is written half by one
+// workgroup and half by the next -- lie in DIFFERENT L2s and leave as two partial writes.  Here ordinal v = 64 q + 8 r + x draws frame
+// 64 q + 8 x + r: the eight workgroups of one XCD within a block of 64 own eight CONSECUTIVE frames (= 1,323 whole lines), so every split
+// block is written by two workgroups of the same XCD and its L2 can merge the halves before the line leaves.  Same bytes, same stores.
+__device__ __forceinline__ int xcd_grouped_frame(int v) { return (v & ~63) | ((v & 7) << 3) | ((v >> 3) & 7); }
+__global__ __launch_bounds__(256) void store_probe_frames_xcd_kernel(u32x4* out, int n) {
+    extern __shared__ unsigned char occupancy_pad[];
+    const int tid = threadIdx.x;
+    for (int v = blockIdx.x; v < n; v += gridDim.x) {
+        const int f = (v | 63) < n ? xcd_grouped_frame(v) : v;  // (a last, partial block of 64 keeps the plain order)
+        u32x4* dst = out + (size_t)f * 1323;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dst[tid + 256 * j] = (u32x4)(0u);
+        if (tid < 43) dst[tid + 1280] = (u32x4)(0u);
+    }
+}
+// Pattern 7: a workgroup writes EIGHT CONSECUTIVE frames one after another, each as the 64-byte-aligned span [up64(start), up64(next start))
+// (what a raster would do that holds a frame's last partial block back and writes it together with the head of its next frame): no block is
+// ever shared between two workgroups; the concurrently written window is eight times as wide.
+__global__ __launch_bounds__(256) void store_probe_octets_kernel(u32x4* out, int n) {
+    extern __shared__ unsigned char occupancy_pad[];
+    const int tid = threadIdx.x;
+    const size_t end = (size_t)n * 1323;
+    for (int g = blockIdx.x; g * 8 < n; g += gridDim.x) {
+#pragma unroll 1
+        for (int k = 0; k < 8 && g * 8 + k < n; ++k) {
+            const size_t f = (size_t)g * 8 + k;
+            size_t v0 = (f * 1323 + 3) & ~(size_t)3, v1 = ((f + 1) * 1323 + 3) & ~(size_t)3;  // in 16-byte vectors: 4 per 64-byte block
+            if (v1 > end) v1 = end;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const size_t v = v0 + tid + 256 * j;
+                if (v < v1) out[v] = (u32x4)(0u);
+            }
+        }
+    }
+}
+// Pattern 5: one frame per workgroup, no LDS request, no persistent loop (grid = frames): the frame's shape alone, dispatched like a fill.
+__global__ __launch_bounds__(256) void store_probe_frame_per_wg_kernel(u32x4* out) {
+    const int tid = threadIdx.x;
+    u32x4* dst = out + (size_t)blockIdx.x * 1323;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dst[tid + 256 * j] = (u32x4)(0u);
+    if (tid < 43) dst[tid + 1280] = (u32x4)(0u);
+}
+
 // Pattern 2 (lab: tools/store_shapes.py): the frame walk with each lane writing PAIRS of adjacent vectors (32 contiguous bytes per lane:
 // a linear sweep of that kind is as fast as one vector per thread, profiles/r01g_store_patterns.md) -- three store rounds per frame
 // instead of six.  Pattern 3: pairs, and the workgroup's four waves write contiguous quarters of the frame.
@@ -358,7 +424,7 @@ int mg_obs_set_search_ms(double ms) {
 // bench.py's per-box control (see store_probe_*_kernel): one launch of `pattern` over n_frames x 21,168 bytes at `buf`, on `stream`.
 int mg_store_probe(void* buf, size_t n_frames, int pattern, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!buf || n_frames == 0 || n_frames > (1u << 30) || pattern < 0 || pattern > 3) {
+    if (!buf || n_frames == 0 || n_frames > (1u << 30) || pattern < 0 || pattern > 7) {
         mg::set_error("mg_store_probe: bad arguments");
         return -1;
     }
@@ -368,6 +434,17 @@ int mg_store_probe(void* buf, size_t n_frames, int pattern, void* stream_) {
     } else if (pattern == 1) {
         const int grid = (int)std::min<size_t>(n_frames, PROBE_GRID);
         hipLaunchKernelGGL(store_probe_frames_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames);
+    } else if (pattern == 4) {
+        const int grid = (int)std::min<size_t>(n_frames, PROBE_GRID);
+        hipLaunchKernelGGL(store_probe_lines_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames);
+    } else if (pattern == 6) {
+        const int grid = (int)std::min<size_t>(n_frames, PROBE_GRID);
+        hipLaunchKernelGGL(store_probe_frames_xcd_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames);
+    } else if (pattern == 7) {
+        const int grid = (int)std::min<size_t>((n_frames + 7) / 8, PROBE_GRID);
+        hipLaunchKernelGGL(store_probe_octets_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames);
+    } else if (pattern == 5) {
+        hipLaunchKernelGGL(store_probe_frame_per_wg_kernel, dim3((unsigned)n_frames), dim3(256), 0, stream, (u32x4*)buf);
     } else {
         const int grid = (int)std::min<size_t>(n_frames, PROBE_GRID);
         hipLaunchKernelGGL(store_probe_frames_pairs_kernel, dim3(grid), dim3(256), 22528, stream, (u32x4*)buf, (int)n_frames, pattern == 3 ? 1 : 0);

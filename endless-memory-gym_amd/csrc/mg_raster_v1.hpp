@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     R.T = A.tables;
     R.tid = threadIdx.x;
     const int tid = threadIdx.x;
-    for (int env = blockIdx.x; env < n; env += gridDim.x) {
+    for (int v = blockIdx.x; v < n; v += gridDim.x) {
+        const int env = xcd_grouped_frame(v, n);
         const typename Composer::Desc* d = descs + env;  // workgroup-uniform
         if (Composer::skip(d) || (only && !only[env])) continue;  // `only`: per-frame filter (final observations)
         Composer::compose(d, R);

@@ -23,6 +23,25 @@ namespace mg {
 
 constexpr int TAIL = FRAME_VEC16 - 5 * 256;  // 43 lanes of a 256-lane workgroup carry a sixth 16-byte chunk
 
+// Measurement builds (tools/build_all_variant.sh, profiles/r06_store_counters.md): MG_LAB_OBS_STRIDE = bytes between the uint8 frames of
+// neighbouring instances (21,248 = 166 whole cache lines: no 64-byte block is shared by two frames); MG_LAB_XCD_GROUP: the frame a
+// workgroup's ordinal draws is permuted so that neighbouring frames are composed on the same XCD (see xcd_grouped_frame).
+#ifdef MG_LAB_OBS_STRIDE
+constexpr size_t OBS_STRIDE_U8 = MG_LAB_OBS_STRIDE;
+#else
+constexpr size_t OBS_STRIDE_U8 = FRAME_BYTES;
+#endif
+// Workgroups are dealt to the eight XCDs round-robin (workgroup b -> XCD b % 8, each with an L2 of its own).  Ordinal v = 64 q + 8 r + x
+// draws frame 64 q + 8 x + r: the eight workgroups of one XCD within a block of 64 own eight CONSECUTIVE frames (= 1,323 whole lines).
+__device__ __forceinline__ int xcd_grouped_frame(int v, int n) {
+#ifdef MG_LAB_XCD_GROUP
+    return (v | 63) < n ? ((v & ~63) | ((v & 7) << 3) | ((v >> 3) & 7)) : v;  // (a last, partial block of 64 keeps the plain order)
+#else
+    (void)n;
+    return v;
+#endif
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct (HIP's uint4 class members end up in scratch)
 
 // 16-bit element of the half formats: IEEE half, or bfloat16 = the float32 quotient rounded to nearest even
@@ -51,7 +70,7 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
     if constexpr (FMT == MG_OBS_U8_XYC && BUF) {
         const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
         // raw buffer over this frame only: stride 0, FRAME_BYTES records, dword 3 = 32-bit untyped data (gfx9 encoding)
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES, 0, FRAME_BYTES, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t*>(obs) + (size_t)env * OBS_STRIDE_U8, 0, FRAME_BYTES, 0x00020000);
         u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
         u32x4 v5 = (u32x4)(0u);
         if (tid < TAIL) v5 = lds16[tid + 1280];
@@ -64,7 +83,7 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
         __builtin_amdgcn_raw_buffer_store_b128(v5, rs, (tid + 1280) * 16, 0, AUX);  // lanes >= TAIL: out of range, dropped
     } else if constexpr (FMT == MG_OBS_U8_XYC) {
         const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
-        u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * FRAME_BYTES);
+        u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * OBS_STRIDE_U8);
         u32x4 v0 = lds16[tid], v1 = lds16[tid + 256], v2 = lds16[tid + 512], v3 = lds16[tid + 768], v4 = lds16[tid + 1024];
         u32x4 v5 = (u32x4)(0u);
         if (tid < TAIL) v5 = lds16[tid + 1280];

@@ -279,7 +279,10 @@ int mg_obs_set_search_ms(double ms);  /* process-wide; >= 0 */
  * thread (the memory system's ceiling for stores at this size and placement); pattern 1 = the raster's store shape without compose
  * work (persistent 256-lane workgroups writing whole frames; the raster's grid and residency): a CONTROL for the raster, not a ceiling
  * (a raster with compose work can beat it); patterns 2 / 3 = other frame-shaped streams measured in round 5 (pairs of adjacent
- * vectors per lane; pairs + each wave a contiguous quarter of the frame: tools/store_shapes.py, profiles/r05_store_shapes.md). */
+ * vectors per lane; pairs + each wave a contiguous quarter of the frame: tools/store_shapes.py, profiles/r05_store_shapes.md); patterns
+ * 4 / 5 (round 6, profiles/r06_store_counters.md): the frame walk with line-aligned ownership (every 128-byte line written by one
+ * workgroup); one frame per workgroup without the persistent loop; 6 / 7: the frame walk with neighbouring frames on the same XCD;
+ * eight consecutive frames per workgroup as 64-byte-aligned spans. */
 int mg_store_probe(void* obs_dev, size_t n_frames, int pattern, void* stream);
 /* Test hook: live buffers, pooled spare pieces, bytes of virtual address space reserved so far. */
 int mg_obs_debug_stats(size_t* live_buffers, size_t* pooled_pieces, size_t* reserved_va_bytes);

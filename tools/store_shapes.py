@@ -17,9 +17,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 buf, info = alloc_obs_buffer((n, 84, 84, 3), torch.uint8, "cuda:0")
 print("buffer: %d frames, placement %s" % (n, info))
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-names = {0: "linear fill", 1: "frame walk, 6 strided vectors per lane (the raster's)", 2: "frame walk, 3 rounds of adjacent pairs", 3: "pairs + wave-contiguous quarters"}
+names = {0: "linear fill", 1: "frame walk, 6 strided vectors per lane (the raster's)", 2: "frame walk, 3 rounds of adjacent pairs", 3: "pairs + wave-contiguous quarters",
+         4: "frame walk, line-aligned ownership", 5: "one frame per workgroup, no persistent loop",
+         6: "frame walk, XCD-grouped order of frames", 7: "eight consecutive frames per workgroup, 64-byte-aligned spans"}
 for rep in range(2):
-    for pattern in (0, 1, 2, 3, 1, 2):
+    for pattern in (0, 1, 6, 7, 4, 3, 1, 6):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
         for q in range(12):
             ev[q].record()
