@@ -836,6 +836,7 @@ def build_headline(args, r, env_id, n_local, K, W, world, ranks):
         "value_windows": r["value_windows"],
         # BASELINE.md section 3's stated timing (>= 2,000 timed steps), whatever --steps was: one such window, timed the same way
         "value_2000": r.get("value_long"),
+        "policy": r.get("policy") or "uniform random",
         # who ran: every rank's device as that rank reports it, the backend, the collective library's version
         "ranks": ranks,
     }
@@ -910,6 +911,8 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-instance C1 leg")
+    ap.add_argument("--policy", default=os.environ.get("MEMGYM_BENCH_POLICY") or None,
+                    help="actions of the HEADLINE workload: default uniform random (BASELINE's); 'follower:EPS' = read off info['ground_truth'] (Endless-MysteryPath-v0)")
     ap.add_argument("--long-window", type=int, default=2000, help="steps of the extra window behind the timed region (value_2000; 0 = none)")
     ap.add_argument("--config5-envs", type=int, default=32768, help="instances per GPU of the config-5 legs of an N > 1 run (BASELINE: 32,768)")
     ap.add_argument("--config5-steps", type=int, default=100)
@@ -987,7 +990,7 @@ def main():
     K, W = args.steps, args.warmup
     guard.arm(max(600.0, 2 * args.leg_limit), "the headline workload")
     r = run_workload(env_id, n_local, K, W, args.settle, world, rank, dev, args.obs_format, args.gather, not args.no_events, args.event_stride,
-                     long_window=args.long_window)
+                     long_window=args.long_window, policy=args.policy)
     guard.disarm()
 
     out = None

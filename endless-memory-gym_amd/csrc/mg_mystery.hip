@@ -820,6 +820,67 @@ __device__ void emp_direction(const MysteryIO& io, int i, MysteryCore& s, float*
     }
 }
 
+// ---- the past-path walk on whole segment records (emp_fill_desc) ----
+// Highest position p in [1, hi] of a record whose node lies in column x_rel == rel, 0 if none (rel > 7: none).  Four node bytes per word;
+// ~((x + 0x7F..) | x | 0x7F..) flags exactly the zero bytes of x (bytes <= 7 here: no carry between bytes).
+__device__ __forceinline__ int seg_last_in_column(const uint32_t (&w)[SEG_STRIDE / 4], int hi, int rel) {
+    int pos = 0;
+    const uint32_t t4 = (uint32_t)(rel & 7) * 0x01010101u;
+    const bool possible = rel <= 7;
+#pragma unroll
+    for (int j = 0; j < SEG_STRIDE / 4; ++j) {  // (upwards: the highest word with a match is taken last)
+        const uint32_t x = (w[j] & 0x07070707u) ^ t4;
+        uint32_t z = ~((x + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 in every byte of x that is zero
+        const int last = hi - 4 * j;                            // bytes 0 .. last of this word are positions <= hi
+        if (j >= 2 && !__ballot(last >= 0)) break;              // (no lane of the wave has a node this far into its record: paths are ~10-20 nodes)
+        const uint32_t upto = last >= 3 ? 0xFFFFFFFFu : (last < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - last))));
+        z &= upto;
+        if (j == 0) z &= ~0xFFu;  // byte 0 of the record is the node count
+        if (z) pos = 4 * j + ((31 - __clz((int)z)) >> 3);
+    }
+    return possible ? pos : 0;
+}
+// Occupancy of the nodes at positions lo .. hi of a record: bit 8 x_rel + y (bits 8 x_rel + 7 stay clear).  Bytes outside the range are
+// replaced by a node (7, 7) that no path has (y <= 6) before the four bytes of a word are turned into bits.
+__device__ __forceinline__ uint64_t seg_occupancy(const uint32_t (&w)[SEG_STRIDE / 4], int lo, int hi) {
+    uint64_t m = 0;
+#pragma unroll
+    for (int j = 0; j < SEG_STRIDE / 4; ++j) {
+        const int first = lo - 4 * j, last = hi - 4 * j;  // bytes first .. last of this word are in range
+        if (j >= 2 && !__ballot(last >= 0)) break;        // (wave-uniform: nothing of any lane's range lies in this word or behind it)
+        const uint32_t from = first <= 0 ? 0xFFFFFFFFu : (first > 3 ? 0u : (0xFFFFFFFFu << (8 * first)));
+        const uint32_t upto = last >= 3 ? 0xFFFFFFFFu : (last < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - last))));
+        const uint32_t keep = from & upto;
+        const uint32_t sw = ((w[j] & 0x07070707u) << 3) | ((w[j] >> 3) & 0x07070707u);  // x_rel and y swapped: 8 x_rel + y per byte
+        const uint32_t v = (sw & keep) | (0x3F3F3F3Fu & ~keep);
+        m |= 1ull << (v & 63u);
+        m |= 1ull << ((v >> 8) & 63u);
+        m |= 1ull << ((v >> 16) & 63u);
+        m |= 1ull << (v >> 24);
+    }
+    return m & 0x7F7F7F7F7F7F7F7Full;
+}
+// The occupancy of one segment (8 columns x 7 rows, a byte per column) into the descriptor's mask: bit 7 col + y, col = cbase + x_rel
+// (cbase = the segment's first column minus past_x, -8 .. 15; columns outside 0 .. 15 hold no node of the walk)
+__device__ __forceinline__ void emp_deposit(uint64_t occ, int cbase, uint64_t& mask0, uint64_t& mask1) {
+    uint64_t dense = 0;  // 7 bits per column, column x_rel at bit 7 x_rel
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dense |= ((occ >> (8 * c)) & 0x7Full) << (7 * c);
+    const int sh = 7 * cbase;  // -56 .. 105
+    if (sh >= 64) {
+        mask1 |= dense << (sh - 64);
+    } else if (sh > 0) {
+        mask0 |= dense << sh;
+        mask1 |= dense >> (64 - sh);
+    } else {
+        mask0 |= dense >> (-sh);
+    }
+}
+
+// WHOLE: the past-path walk on whole records (the step kernel, one lane per instance: its longest phase under a path-following agent);
+// false: the reference's loop -- the fused raster / service launch calls this for the few instances it resets or finishes, inside a
+// register budget that sets how many frame workgroups a CU holds (the whole-record form there: 310 us per launch instead of 135).
+template <bool WHOLE>
 __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i, const MysteryCore& s, MysteryDesc& d, int nx, SegRec& R,
                               const SegRec Rprev) {  // (by value: as a reference the caller's record stayed in scratch)
     memset(&d, 0, sizeof(d));
@@ -838,34 +899,73 @@ __device__ void emp_fill_desc(const MysteryParams& P, const MysteryIO& io, int i
         d.stamina_red = (uint8_t)(int)(SCREEN * (1 - ((double)st / P.stamina_level)));
     }
     uint64_t mask0 = 0, mask1 = 0;
-    if (P.show_past_path) {  // _draw_past_path
-        int x = nx - 1;
-        if (x >= 0) {
-            int past_x = x - P.depth > 0 ? x - P.depth : 0;
+    if (P.show_past_path) {  // _draw_past_path (endless_mystery_path.py:111-132)
+        const int x0 = nx - 1;
+        if (x0 >= 0) {
+            const int past_x = x0 - P.depth > 0 ? x0 - P.depth : 0;
             d.tile_x0 = past_x * P.tile - s.camera_x;
-            int seg = s.cur_node_seg, idx = s.cur_node_idx - 1;
-            while (x >= past_x && x >= 0) {
-                if (idx < 0) {
-                    seg--;
-                    if (seg < 0) break;
+            // The reference walks the path backwards from the node before the agent's, tile by tile, until it has drawn one in column
+            // past_x.  As a loop per lane that was the longest phase of the step under an agent that FOLLOWS its path (up to ~35 tiles,
+            // each a run-time indexed byte of a record held in registers: 9.8 us of a wave's 20, profiles/r06_emp.md).  The walk only
+            // ever touches the record of the current node's segment and the one before it (the window is at most depth + 2 <= 9 columns,
+            // a segment has 8, and the stored path is 4-connected), so it is done on whole records instead: the STOP position = the
+            // last node before the agent's in column past_x (four node bytes per word, exact zero-byte flags), the tiles = the nodes
+            // between it and the agent's as a 64-bit occupancy (bit 8 x_rel + y), repacked to the descriptor's 7 bits per column.
+            const int C = s.cur_node_seg;
+            const bool cur_in_R = C == R.seg, cur_in_prev = C == Rprev.seg;
+            // (depth < 2: the first node of the walk may already lie left of past_x when the agent has just stepped off the path -- the
+            // reference's loop ends there; the whole-record form assumes the walk starts inside the window.  Uniform per handle.)
+            const bool generic = !WHOLE || P.depth < 2 || !(cur_in_R || cur_in_prev) || (cur_in_R && C > 0 && Rprev.seg != C - 1);
+            bool done_fast = false;
+            if constexpr (WHOLE) if (__builtin_expect(!generic, 1)) {
+                uint32_t wc[SEG_STRIDE / 4];
+#pragma unroll
+                for (int j = 0; j < SEG_STRIDE / 4; ++j) wc[j] = cur_in_R ? R.w[j] : Rprev.w[j];
+                const int hi_c = s.cur_node_idx;  // positions 1 .. cur_node_idx hold the nodes before the agent's
+                const int rel_c = past_x - C * (G + 1);
+                const int stop_c = (rel_c >= 0 && hi_c >= 1) ? seg_last_in_column(wc, hi_c, rel_c) : 0;
+                const uint64_t occ_c = seg_occupancy(wc, stop_c ? stop_c : 1, hi_c);
+                emp_deposit(occ_c, C * (G + 1) - past_x, mask0, mask1);
+                done_fast = true;
+                if (!stop_c && C > 0) {  // the walk goes on in the segment before
+                    if (cur_in_R) {
+                        const int n_p = (int)(Rprev.w[0] & 0xFFu);
+                        const int rel_p = past_x - (C - 1) * (G + 1);
+                        const int stop_p = rel_p >= 0 ? seg_last_in_column(Rprev.w, n_p, rel_p) : 0;
+                        const uint64_t occ_p = seg_occupancy(Rprev.w, stop_p ? stop_p : 1, n_p);
+                        emp_deposit(occ_p, (C - 1) * (G + 1) - past_x, mask0, mask1);
+                        if (!stop_p && C - 1 > 0) done_fast = false;  // (cannot happen: past_x >= 8 C - 8; the loop below is the definition)
+                    } else {
+                        done_fast = false;  // (the segment before the previous one: cannot happen either, see above)
+                    }
+                }
+            }
+            if (__builtin_expect(!done_fast, 0)) {  // the reference's loop, literally
+                mask0 = mask1 = 0;
+                int x = x0, seg = s.cur_node_seg, idx = s.cur_node_idx - 1;
+                while (x >= past_x && x >= 0) {
+                    if (idx < 0) {
+                        seg--;
+                        if (seg < 0) break;
+                        R.load_or_take(io, i, seg, Rprev);
+                        idx = R.byte(0) - 1;
+                    }
                     R.load_or_take(io, i, seg, Rprev);
-                    idx = R.byte(0) - 1;
+                    uint8_t b = R.byte(1 + idx);
+                    x = node_x(seg, b);
+                    int y = node_y(b);
+                    int col = x - past_x;
+                    if (col >= 0 && col < 16) {
+                        const int cell = col * G + y;  // (a run-time index into d.tile_mask would put the descriptor into scratch)
+                        const uint64_t bit = 1ull << (cell & 63);
+                        if (cell < 64) mask0 |= bit;
+                        else mask1 |= bit;
+                    } else if (col >= 16) {
+                        raise_error(io.err, 16);
+                    }
+                    if (x == past_x) break;
+                    idx--;
                 }
-                R.load_or_take(io, i, seg, Rprev);
-                uint8_t b = R.byte(1 + idx);
-                x = node_x(seg, b);
-                int y = node_y(b);
-                int col = x - past_x;
-                if (col >= 0 && col < 16) {
-                    const int cell = col * G + y;  // (a run-time index into d.tile_mask would put the descriptor into scratch)
-                    const uint64_t bit = 1ull << (cell & 63);
-                    if (cell < 64) mask0 |= bit;
-                    else mask1 |= bit;
-                } else if (col >= 16) {
-                    raise_error(io.err, 16);
-                }
-                if (x == past_x) break;
-                idx--;
             }
         }
     }
@@ -939,7 +1039,7 @@ __device__ void emp_post_reset(const MysteryParams& P, const MysteryIO& io, int 
     emp_post_reset_state(P, io, i, s, gt, R);
     SegRec none;
     none.seg = -1;
-    emp_fill_desc(P, io, i, s, d, s.ax / P.tile, R, none);
+    emp_fill_desc<false>(P, io, i, s, d, s.ax / P.tile, R, none);
     d.cross_on = 0;
     if (P.show_stamina) d.stamina_red = 0;
 }
@@ -1008,7 +1108,7 @@ static __device__ unsigned long long g_lab_step_clock[12 * 4096];
 // fall-off list) -- is requested in ONE batch: the kernel is a chain of dependent memory round trips on 512 waves (~2 us each on a
 // memory system the observation stream has just swept; rounds 3-4: records, then the fall-off list, then the stamina flags'
 // records, then the queue's counter), not a matter of bytes (profiles/r03_emp.md section 7, r05_emp.md).
-template <bool OWN_RESET>
+template <bool OWN_RESET, bool WHOLE_DESC = false>
 __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
                            uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d, bool cap = false) {
     typedef uint32_t q4 __attribute__((ext_vector_type(4)));
@@ -1204,7 +1304,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
         nx = s.ax / P.tile;
         fresh = true;
     }
-    emp_fill_desc(P, io, i, s, d, nx, R, Rprev);
+    emp_fill_desc<WHOLE_DESC>(P, io, i, s, d, nx, R, Rprev);
     if (fresh) {
         d.cross_on = 0;
         if (P.show_stamina) d.stamina_red = 0;
@@ -1409,7 +1509,7 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
     if (due) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
     } else {
-        q = emp_step_b<!PS>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d, (ra & EMP_CAP) != 0);
+        q = emp_step_b<!PS, true>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d, (ra & EMP_CAP) != 0);
         LAB_STEP_CLOCK(2);
         if (q) {
             queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);

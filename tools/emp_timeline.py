@@ -19,9 +19,15 @@ n = 32768
 env = memory_gym_amd.make("Endless-MysteryPath-v0", num_envs=n, device=0)
 env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda"))
 g = torch.Generator(device="cuda").manual_seed(1)
-for t in range(260):
-    env.step(torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32))
+POLICY = os.environ.get("EMP_TIMELINE_POLICY", "random")  # "follower": the action read off the ground truth (eps 0.02), like tools/emp_policy_bench.py
+obs, info = env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda"))
+for t in range(int(os.environ.get("EMP_TIMELINE_STEPS", "260"))):
+    a = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int32)
+    if POLICY == "follower":
+        a = torch.where(torch.rand(n, device="cuda", generator=g) < 0.02, a, info["ground_truth"].argmax(1).to(torch.int32) + 1)
+    obs, rew, done, _, info = env.step(a)
 torch.cuda.synchronize()
+print("policy:", POLICY)
 W = 14336 + 256
 W = min(W, 16384)
 buf = np.zeros(3 * 16384, np.uint64)
