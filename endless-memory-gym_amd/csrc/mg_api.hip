@@ -216,6 +216,22 @@ int mg_bind_option_sets(mg_env* env, const int32_t* set_of_dev) {
     });
 }
 
+int mg_set_capacity(mg_env* env, const char* what, int64_t value) {
+    return guarded(env, [&] {
+        if (!what) throw mg::OptionError{-3, "mg_set_capacity: NULL"};
+        if (env->started) throw std::runtime_error("mg_set_capacity: before the first mg_reset / mg_set_state");
+        env->fam->set_capacity(what, value);
+    });
+}
+int64_t mg_capacity(mg_env* env, const char* what) {
+    int64_t v = -1;
+    const int rc = guarded(env, [&] {
+        if (!what) throw mg::OptionError{-3, "mg_capacity: NULL"};
+        v = env->fam->capacity(what);
+    });
+    return rc == 0 ? v : -1;
+}
+
 int mg_set_obs_format(mg_env* env, int format) {
     return guarded(env, [&] {
         if (format != MG_OBS_U8_XYC && format != MG_OBS_F32_CYX && format != MG_OBS_F16_CYX && format != MG_OBS_BF16_CYX)

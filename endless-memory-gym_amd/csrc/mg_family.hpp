@@ -198,6 +198,9 @@ class Family {
     virtual ~Family() {}
     virtual int action_dim() const = 0;
     virtual int gt_dim() const = 0;
+    // capacities of the per-instance lists the reference grows without limit (include/memgym.h: mg_set_capacity / mg_capacity)
+    virtual void set_capacity(const std::string& what, int64_t) { throw OptionError{-2, "this env id has no capacity named " + what}; }
+    virtual int64_t capacity(const std::string& what) const { throw OptionError{-2, "this env id has no capacity named " + what}; }
     virtual int vec_dim() const { return 0; }          // size of obs["vector_observation"] (MortarMayhemB*), else 0
     virtual void bind_vector_obs(float* /*dev*/) {}    // caller buffer [num_envs][vec_dim], written at every reset
     virtual const char* info_name(int k) const = 0;

@@ -758,6 +758,24 @@ class MortarFamily : public Family {
         defaults_ = P_;  // (short lists only: no device arrays behind them)
     }
 
+    // include/memgym.h: mg_set_capacity.  "commands" (Endless-MortarMayhem-v0): entries of the command list per instance -- the reference's
+    // list grows by one with every completed round (endless_mortar_mayhem.py:311-333); an episode that would need one more ends (capacity_dev)
+    void set_capacity(const std::string& what, int64_t v) override {
+        if (!(P_.variant == V_ENDLESS && what == "commands")) return Family::set_capacity(what, v);
+        if (v < 4 || v > 32768) throw OptionError{-3, "commands: 4 .. 32,768"};
+        if (seeded_) throw std::runtime_error("mg_set_capacity: before the first reset");
+        if (2 * P_.initial_count > v) throw OptionError{-3, "commands: below twice the initial_command_count in force"};
+        MG_HIP(hipDeviceSynchronize());
+        P_.cmd_cap = (int)v;
+        cmds_.alloc((size_t)n_ * P_.cmd_cap);
+        for (size_t k = 1; k < opt_.size(); ++k) copy_geometry(opt_[k]->P, P_);
+        copy_geometry(defaults_, P_);
+        sets_dirty_ = true;
+    }
+    int64_t capacity(const std::string& what) const override {
+        if (P_.variant == V_ENDLESS && what == "commands") return P_.cmd_cap;
+        return Family::capacity(what);
+    }
     int action_dim() const override { return P_.variant == V_GRID ? 1 : 2; }
     int gt_dim() const override { return P_.variant == V_ENDLESS ? 2 : 0; }
     int vec_dim() const override { return P_.taskb ? VEC_DIM : 0; }

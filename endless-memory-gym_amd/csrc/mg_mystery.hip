@@ -68,10 +68,14 @@ struct __attribute__((aligned(16))) MysteryCore {
     double ep_sum;
     uint8_t td[3], have_start;
     int8_t end_y;
-    uint8_t gx, gy;       // grid controller position (MysteryPath-Grid-v0); endless: range of segments holding stamina flags
+    uint8_t gx, gy;       // grid controller position (MysteryPath-Grid-v0)
     uint8_t bg;           // endless: -bg_scroll, the scrolling background's phase in pixels (< tile)
 };
 static_assert(sizeof(MysteryCore) == 96, "MysteryCore must be 96 bytes");
+// endless: [EMP_FLO, EMP_FHI] = range of segments that may hold stamina flags (empty: lo > hi).  Two 32-bit halves of the finite variants'
+// visited_mask (rounds 1-5: the grid controller's two position bytes, which capped the segment store at 255 records).
+#define EMP_FLO(s) (reinterpret_cast<int32_t*>(&(s).visited_mask)[0])
+#define EMP_FHI(s) (reinterpret_cast<int32_t*>(&(s).visited_mask)[1])
 #define EMP_OWED(s) ((s).path_len)  // endless: segments the instance is owed ("lazy initial segments" below)
 #define EMP_PRE(s) ((s).ex)         // endless: io.aux[i] holds the next episode's first segment (ex / ey: the finite variants' goal)
 // The whole record as six 16-byte loads issued together.  Field by field the compiler split it into eleven odd-sized loads
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(256) void mystery_gt64_kernel(int n, const MysteryC
 
 struct MysteryIO {
     MysteryCore* core;
-    uint8_t* segs;      // endless: [N][MAX_SEG][SEG_STRIDE]; node byte = x_rel | y<<3 | rvis<<6 | svis<<7
+    uint8_t* segs;      // endless: [N][seg_rows][SEG_STRIDE]; node byte = x_rel | y<<3 | rvis<<6 | svis<<7
+    int seg_rows;       // segment records per instance (MAX_SEG by default; mg_set_capacity "path_segments")
     RngSoA rng;
     MysteryDesc* desc;
     int* err;
@@ -696,7 +701,7 @@ __device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, int act0,
 
 // ============================================ endless ============================================
 __device__ __forceinline__ uint8_t* seg_ptr(const MysteryIO& io, int i, int seg) {
-    return io.segs + ((size_t)i * MAX_SEG + seg) * SEG_STRIDE;
+    return io.segs + ((size_t)i * io.seg_rows + seg) * SEG_STRIDE;
 }
 __device__ __forceinline__ int node_x(int seg, uint8_t b) { return seg * (G + 1) + (b & 7); }
 __device__ __forceinline__ int node_y(uint8_t b) { return (b >> 3) & 7; }
@@ -774,7 +779,7 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
             stage[lane] = (uint8_t)b;
         }
         const int nseg = bcast((int)s.num_seg, L);
-        if (nseg < MAX_SEG && lane < SEG_STRIDE / 4)
+        if (nseg < io.seg_rows && lane < SEG_STRIDE / 4)
             reinterpret_cast<uint32_t*>(seg_ptr(io, bcast(i, L), nseg))[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the requester's lane reads the record back (emp_post_reset, SegRec)
         if (lane == L) {
@@ -782,7 +787,7 @@ __device__ void serve_emp(const MysteryIO& io, const PathWS& W, int i, int want,
             s.have_start = 1;
             s.end_y = (int8_t)ey;
             EMP_PRE(s) = 0;  // the stream has moved: a record generated ahead of time no longer continues it
-            if (s.num_seg >= MAX_SEG) raise_error(io.err, 4);
+            if (s.num_seg >= io.seg_rows) raise_error(io.err, 4);
             else s.num_seg++;
             todo_n--;
         }
@@ -1024,8 +1029,8 @@ __device__ __forceinline__ void emp_post_reset_state(const MysteryParams& P, con
     s.cur_seg = 0;
     s.fails = 0;
     s.n_falloff = 0;
-    s.gx = 255;  // endless: [gx, gy] = range of segments that may hold stamina flags (empty)
-    s.gy = 0;
+    EMP_FLO(s) = 0x7FFFFFFF;  // no segment holds a stamina flag
+    EMP_FHI(s) = -1;
     s.stamina = P.stamina_level;
     s.max_x = 0;
     s.tiles_visited = 0;
@@ -1185,8 +1190,8 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
                 reward += P.r_dense;
                 s.stamina = P.stamina_level;
                 b |= 0x80;
-                s.gx = seg < s.gx ? (uint8_t)seg : s.gx;  // segments that may hold stamina flags
-                s.gy = seg > s.gy ? (uint8_t)seg : s.gy;
+                EMP_FLO(s) = seg < EMP_FLO(s) ? seg : EMP_FLO(s);  // segments that may hold stamina flags
+                EMP_FHI(s) = seg > EMP_FHI(s) ? seg : EMP_FHI(s);
             }
             sp[hit] = b;
         }
@@ -1227,7 +1232,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
         // reset all stamina flags -- only segments visited since the last reset can hold any; whole records at a time
         // (bytes past the node count are unused).  The agent's segment and the one before it are in registers already, as they
         // are in memory (no node was flagged in this step: the agent is not on the path).
-        for (int q = s.gx; q <= (int)s.gy && q < s.num_seg; ++q) {
+        for (int q = EMP_FLO(s); q <= EMP_FHI(s) && q < s.num_seg; ++q) {
             uint32_t* wp = reinterpret_cast<uint32_t*>(seg_ptr(io, i, q));
             uint32_t w[SEG_STRIDE / 4];
             if (q == R.seg) {
@@ -1244,8 +1249,8 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
 #pragma unroll
             for (int j = 1; j < SEG_STRIDE / 4; ++j) wp[j] = w[j] & 0x7F7F7F7Fu;
         }
-        s.gx = 255;
-        s.gy = 0;
+        EMP_FLO(s) = 0x7FFFFFFF;
+        EMP_FHI(s) = -1;
         s.stamina = P.stamina_level;
     } else {
         s.cross_on = 0;
@@ -1785,7 +1790,7 @@ __device__ int lane_segment_record(const MysteryIO& io, const LaneWS& W, bool ha
     return ey;
 }
 __device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, MysteryCore& s, Pcg& g) {
-    const bool room = s.num_seg < MAX_SEG;
+    const bool room = s.num_seg < io.seg_rows;
     const int ey = lane_segment_record(io, W, s.have_start != 0, (int)s.end_y, g, room ? reinterpret_cast<uint32_t*>(seg_ptr(io, i, s.num_seg)) : nullptr);
     if (room) s.num_seg++;
     else raise_error(io.err, 4);
@@ -1930,7 +1935,7 @@ __device__ __forceinline__ void lane_owed_segment(const MysteryIO& io, const Lan
     g.load(io.rng, i);
     uint32_t* const rec = io.aux + (size_t)i * AUX_WORDS;
     for (int k = 0; k < how_many && (owed > 0 || pre_job); ++k) {
-        const bool room = s.num_seg < MAX_SEG;
+        const bool room = s.num_seg < io.seg_rows;
         uint32_t* dst = pre_job ? rec : (room ? reinterpret_cast<uint32_t*>(seg_ptr(io, i, s.num_seg)) : nullptr);
         // (a reset's first segment draws its start row)
         const int ey = lane_segment_record(io, W, !pre_job && s.have_start != 0, (int)s.end_y, g, dst);
@@ -2270,7 +2275,8 @@ class MysteryFamily : public Family {
             stats_.alloc(4);
         }
         if (endless) {
-            segs_.alloc((size_t)n * MAX_SEG * SEG_STRIDE);
+            seg_rows_ = MAX_SEG;
+            segs_.alloc((size_t)n * seg_rows_ * SEG_STRIDE);
             aux_.alloc((size_t)n * AUX_WORDS);
         } else {
             segs_.alloc(16);
@@ -2283,6 +2289,25 @@ class MysteryFamily : public Family {
         defaults_ = P_;  // (the cardinal list is short: no device array behind it)
     }
 
+    // include/memgym.h: mg_set_capacity.  "path_segments" (Endless-MysteryPath-v0): records of the segment store per instance -- the
+    // reference's path grows without limit (pygame_assets.py:559); an episode that needs one more segment than this ends (capacity_dev)
+    void set_capacity(const std::string& what, int64_t v) override {
+        if (!(P_.endless && what == "path_segments")) return Family::set_capacity(what, v);
+        if (v < 4 || v > 32767) throw OptionError{-3, "path_segments: 4 .. 32,767"};
+        if (seeded_) throw std::runtime_error("mg_set_capacity: before the first reset");
+        MG_HIP(hipDeviceSynchronize());
+        seg_rows_ = (int)v;
+        segs_.alloc((size_t)n_ * seg_rows_ * SEG_STRIDE);
+        P_.seg_cap = seg_rows_;
+        for (auto& e : extra_) e->P.seg_cap = seg_rows_;
+        defaults_.seg_cap = seg_rows_;
+        sets_dirty_ = true;
+    }
+    int64_t capacity(const std::string& what) const override {
+        if (P_.endless && what == "path_segments") return P_.seg_cap;
+        if (P_.endless && what == "fall_off_cells") return P_.fall_cap;
+        return Family::capacity(what);
+    }
     int action_dim() const override { return (P_.endless || P_.grid) ? 1 : 2; }
     int gt_dim() const override { return P_.endless ? 3 : 0; }
     const char* info_name(int k) const override {
@@ -2577,6 +2602,7 @@ class MysteryFamily : public Family {
         o.core = core_.p;
         o.segs = segs_.p;
         o.rng = rng_.view();
+        o.seg_rows = seg_rows_;
         o.desc = desc_.p;
         o.err = err_.dev;
         o.queue = queue_.p;
@@ -2705,6 +2731,7 @@ class MysteryFamily : public Family {
     std::unique_ptr<Atlas> atlas_;
     DevArray<MysteryCore> core_;
     DevArray<uint8_t> segs_;
+    int seg_rows_ = MAX_SEG;
     DevArray<MysteryDesc> desc_;
     DevArray<int> queue_;  // n entries + the counters
     DevArray<int> bgq_;    // endless: background jobs (owed segments), small launches

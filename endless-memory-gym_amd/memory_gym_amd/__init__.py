@@ -17,14 +17,14 @@ from . import envs  # noqa: F401,E402
 
 
 def make(env_id, num_envs=None, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False, obs_buffer=None,
-         obs_placement=None, ground_truth64=False, on_capacity="raise"):
+         obs_placement=None, ground_truth64=False, on_capacity="raise", capacity=None):
     if num_envs is None:
         if env_id not in envs.CLASSES:
             raise ValueError("unknown env id %r" % (env_id,))
         return envs.CLASSES[env_id](render_mode=render_mode, device=device)
     return VecMemoryGym(env_id, num_envs=num_envs, device=device, render_mode=render_mode, obs_format=obs_format,
                         final_observation=final_observation, obs_buffer=obs_buffer, obs_placement=obs_placement,
-                        ground_truth64=ground_truth64, on_capacity=on_capacity)
+                        ground_truth64=ground_truth64, on_capacity=on_capacity, capacity=capacity)
 
 
 def _register_with_gymnasium():

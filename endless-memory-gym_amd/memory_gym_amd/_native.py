@@ -86,6 +86,9 @@ def _load():
     if hasattr(L, "mg_set_option_set"):
         L.mg_set_option_set.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_int]
         L.mg_bind_option_sets.argtypes = [C.c_void_p, C.c_void_p]
+    L.mg_set_capacity.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.mg_capacity.argtypes = [C.c_void_p, C.c_char_p]
+    L.mg_capacity.restype = C.c_int64
     if hasattr(L, "mg_debug_counter"):  # (absent from builds of earlier rounds that tools/ A/B against through MEMGYM_HIP_LIB)
         L.mg_debug_counter.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     return L

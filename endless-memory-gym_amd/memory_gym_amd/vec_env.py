@@ -118,7 +118,7 @@ class VecMemoryGym:
                    "f16_chw": (2, torch.float16, (3, 84, 84)), "bf16_chw": (3, torch.bfloat16, (3, 84, 84))}
 
     def __init__(self, env_id, num_envs=1, device=None, render_mode=None, obs_format="u8_xyc", final_observation=False,
-                 obs_buffer=None, obs_placement=None, ground_truth64=False, on_capacity="raise"):
+                 obs_buffer=None, obs_placement=None, ground_truth64=False, on_capacity="raise", capacity=None):
         if env_id not in DEFAULTS:
             raise ValueError("unknown env id %r" % (env_id,))
         if obs_format not in self.OBS_FORMATS:
@@ -133,6 +133,15 @@ class VecMemoryGym:
         h = C.c_void_p()
         _native.check(_native.LIB.mg_create(env_id.encode(), self.num_envs, self.device.index, C.byref(h)), "mg_create")
         self._h = h
+        # capacity={"path_segments": 1024} / {"commands": 2048}: room for the lists the reference grows without limit (include/memgym.h:
+        # mg_set_capacity; the defaults -- 128 segments = 1,024 tiles, 512 commands -- are what every measured number of this repo uses)
+        self.capacity = {}
+        for what, value in (capacity or {}).items():
+            with torch.cuda.device(self.device):
+                rc = _native.LIB.mg_set_capacity(h, what.encode(), int(value))
+            if rc != 0:
+                raise ValueError("capacity[%r] = %r: %s" % (what, value, _native.last_error()))
+            self.capacity[what] = int(value)
         self.action_dim = _native.LIB.mg_action_dim(h)
         self.gt_dim = _native.LIB.mg_gt_dim(h)
         self.vec_dim = _native.LIB.mg_vec_dim(h)
@@ -471,7 +480,8 @@ class VecMemoryGym:
         with torch.cuda.device(self.device):
             _native.check(_native.LIB.mg_get_state(self._h, buf.ctypes.data, n), "mg_get_state")
         # the reset options in force belong to the state: geometry, schedules and limits are derived from them
-        sd = {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf, "options": dict(self._applied), "seeded": self._seeded}
+        sd = {"env_id": self.env_id, "num_envs": self.num_envs, "blob": buf, "options": dict(self._applied), "seeded": self._seeded,
+              "capacity": dict(self.capacity)}
         if self._set_of is not None:  # per-instance option sets in use
             sd["option_sets"] = [dict(p) for p in self._set_params]
             sd["set_of"] = self._set_of.cpu().numpy()
@@ -481,6 +491,8 @@ class VecMemoryGym:
         """Restore a checkpoint, also into a handle that was never reset: the options in force when it was taken are
         applied first (a rebuild of the geometry happens at the restore, not at some later reset), then the state."""
         assert sd["env_id"] == self.env_id and sd["num_envs"] == self.num_envs
+        if sd.get("capacity", {}) != self.capacity:
+            raise ValueError("the checkpoint was taken with capacity=%r, this handle was made with %r" % (sd.get("capacity", {}), self.capacity))
         with torch.cuda.device(self.device):
             opts = sd.get("options")
             if opts is not None and any(self._applied.get(k) != v for k, v in opts.items()):

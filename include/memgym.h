@@ -56,7 +56,7 @@ typedef struct mg_info_buffers {
      * REACHED A CAPACITY OF THIS BUILD (done_dev is 1 for it as well), else 0.  The reference's lists grow without limit -- path
      * segments (pygame_assets.py:559, called from endless_mystery_path.py:333-335), fall-off cells (:385-393), the command list
      * (endless_mortar_mayhem.py:311-333), live spotlights (endless_searing_spotlights.py:191) -- here they hold 128 segments, 128
-     * cells, 512 commands and 16 spotlights per instance.  An instance that would need one more ends its episode like a truncation
+     * cells, 512 commands (mg_set_capacity raises the first and the third) and 16 spotlights per instance.  An instance that would need one more ends its episode like a truncation
      * (a reset follows under autoreset); the sticky error bit (mg_poll_errors: 4, 8, 32, 1) is raised as before, so a caller that
      * ignores this array still hears about it.  With it a trainer treats the instance as truncated and goes on with the batch. */
     uint8_t* capacity_dev;
@@ -112,6 +112,21 @@ int mg_set_option(mg_env* env, const char* key, const double* values, int n);
 #define MG_MAX_OPTION_SETS 8
 int mg_set_option_set(mg_env* env, int set_id, const char* key, const double* values, int n);
 int mg_bind_option_sets(mg_env* env, const int32_t* set_of_dev);
+
+/* Capacities of the per-instance lists that the reference grows without limit.  mg_set_capacity(env, what, value), before the handle's
+ * first mg_reset (it re-allocates the list's array; mg_state_size changes with it and a checkpoint only loads into a handle of the same
+ * capacity); mg_capacity returns the value in force, -1 for a name the env id does not have.
+ *   "path_segments"  Endless-MysteryPath-v0: segments of an episode's path (EndlessMysteryPath.add_path_segment, pygame_assets.py:559,
+ *                    called from endless_mystery_path.py:333-335 whenever the agent enters the last but one); default 128 = 1,024 tiles,
+ *                    4 .. 32,767, 52 bytes per segment and instance.  (Not a ring: an agent that falls off is put back to the START of
+ *                    its path, endless_mystery_path.py:316-322, and walks every segment again.)
+ *   "commands"       Endless-MortarMayhem-v0: entries of the command list (endless_mortar_mayhem.py:311-333); default 512, 4 .. 32,768,
+ *                    one byte per entry and instance.
+ *   "fall_off_cells" Endless-MysteryPath-v0 (read only): 128 distinct cells an episode may fall off at (:385-393).
+ * An instance that would need one more entry than the capacity ends its episode in that step: done_dev, mg_info_buffers.capacity_dev and
+ * the sticky error bit (mg_poll_errors) say so.  16 live spotlights per instance (the spotlight family) is fixed. */
+int mg_set_capacity(mg_env* env, const char* what, int64_t value);
+int64_t mg_capacity(mg_env* env, const char* what);
 
 /* Observation format written to obs_dev by mg_reset / mg_step (default MG_OBS_U8_XYC).
  *   MG_OBS_U8_XYC   uint8   [num_envs][84 x][84 y][3]  -- the reference's observation: pygame.surfarray.array3d order

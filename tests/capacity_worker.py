@@ -35,7 +35,13 @@ SCENARIOS = {
 def main():
     name, mode = sys.argv[1], sys.argv[2]
     env_id, options, n, steps, eps, field, cap = SCENARIOS[name]
-    env = memory_gym_amd.make(env_id, num_envs=n, device=0, on_capacity=mode)
+    capacity = None
+    if os.environ.get("MEMGYM_TEST_CAPACITY"):  # "name=value": mg_set_capacity through make(capacity=...); the scenario's list is then that long
+        what, value = os.environ["MEMGYM_TEST_CAPACITY"].split("=")
+        capacity, cap = {what: int(value)}, int(value)
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0, on_capacity=mode, capacity=capacity)
+    if capacity:
+        assert env.capacity == capacity and memory_gym_amd._native.LIB.mg_capacity(env._h, list(capacity)[0].encode()) == cap
     ref = oracle_lib.OracleBatch(env_id, n, options=options)
     seeds = np.arange(n, dtype=np.int64) + 7
     obs, _ = env.reset(seed=seeds, options=options)
