@@ -409,7 +409,8 @@ int mg_single_reset(mg_env* env, int64_t seed, int has_seed, void* stream) {
 }
 
 int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream) {
-    return guarded(env, [&] {
+    int flags = 0;
+    const int rc = guarded(env, [&] {
         mg_env::Single& S = env->single;
         if (!S.open) throw std::runtime_error("mg_single_step: mg_single_open first");
         hipStream_t st = (hipStream_t)stream;
@@ -428,7 +429,9 @@ int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream) {
                 f->gt_dim() ? (float*)(S.dev + S.o_gt32) : nullptr, &ib, 0, st);
         f->ground_truth64((double*)(S.dev + S.o_gt), st);
         single_wait(S, st);
+        flags = f->peek_errors();  // (the word lives in pinned host memory: a plain read; saves the caller a second native call per step)
     });
+    return rc != 0 ? rc : flags;
 }
 
 size_t mg_state_size(const mg_env* env) {

@@ -686,11 +686,11 @@ class MemoryGymEnv(_EnvBase):
         else:
             a0 = a1 = int(action)
         rc = self._step_fn(self._h, a0, a1, self._raw_stream())
-        if rc != 0:
-            _native.check(rc, "mg_single_step")
-        self._peek(self._h, C.byref(self._errword))  # host-mapped word: no synchronisation
-        if self._errword.value:
-            self.vec.check_errors()
+        if rc != 0:  # negative: the call failed; positive: device error bits as they stand (include/memgym.h)
+            if rc < 0:
+                _native.check(rc, "mg_single_step")
+            if rc & ~self.vec._tolerated:
+                self.vec.check_errors()
         r, d = float(self._reward_host[0]), bool(self._done_host[0])  # r: the reference's Python float, bit for bit
         out = {}
         if d:  # end of episode (rare): the reference's terminal info dict

@@ -190,7 +190,11 @@ int mg_ground_truth64(mg_env* env, double* gt64_dev, void* stream);
  * enqueue the step's launches, wait for the stream -- no copy operation, no allocation, no indexing kernel.
  *   mg_single_reset(env, seed, has_seed, stream)   Env.reset(seed) + wait; options through mg_set_option as ever
  *   mg_single_step(env, a0, a1, stream)            Env.step(action) WITHOUT auto-reset (the caller resets, like the reference's
- *                                                  loop) + wait; results are in the buffers of mg_single_io when it returns
+ *                                                  loop) + wait; results are in the buffers of mg_single_io when it returns.
+ *                                                  Returns 0, a negative error code, or -- POSITIVE -- the device error bits as they
+ *                                                  stand (mg_peek_errors; sticky until mg_poll_errors).  The wait polls a word in the
+ *                                                  pinned block that a stream memory operation writes behind the step's launches
+ *                                                  (no hipStreamSynchronize; round 6)
  * `obs` has the handle's observation format; `gt` holds mg_gt_dim doubles; `vec` the MortarMayhemB vector observation or NULL.
  * The buffers live as long as the handle.  Same results as the batched path with one instance (tests/test_gpu_single_instance.py). */
 typedef struct mg_single_io {
