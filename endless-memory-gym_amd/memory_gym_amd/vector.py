@@ -27,10 +27,12 @@ except Exception:  # gymnasium is not a dependency of the hot path
 
 
 class GymnasiumVectorEnv(_Base):
-    def __init__(self, env_id, num_envs, device=None, obs_format="u8_xyc", as_numpy=False):
+    def __init__(self, env_id, num_envs, device=None, obs_format="u8_xyc", as_numpy=False, on_capacity="raise", capacity=None):
         # as_numpy: gymnasium's host-side layout with the reference's dtypes -- rewards and info["ground_truth"] as float64
+        # on_capacity="truncate": a sub-environment whose episode this build ended on one of its capacities (VecMemoryGym) comes back with
+        # terminations[i] = False and truncations[i] = True, like a time limit; its final_observation / final_info are set as for any end
         self.env = VecMemoryGym(env_id, num_envs=num_envs, device=device, obs_format=obs_format, final_observation=True,
-                                ground_truth64=bool(as_numpy))
+                                ground_truth64=bool(as_numpy), on_capacity=on_capacity, capacity=capacity)
         self.as_numpy = bool(as_numpy)
         done = False
         if _Base is not object:  # gymnasium 0.29: VectorEnv.__init__(num_envs, observation_space, action_space) batches the spaces
@@ -75,9 +77,12 @@ class GymnasiumVectorEnv(_Base):
         infos = {}
         if "ground_truth" in info:
             infos["ground_truth"] = info["ground_truth"]
+        term = done if self.env.capacity_u8 is None else (done & ~trunc)  # gymnasium: an episode ends EITHER terminated or truncated
+        if "capacity_exceeded" in info:
+            infos["capacity_exceeded"] = info["capacity_exceeded"]
         if not self.as_numpy:
             infos.update(final_observation=info["final_observation"], _final_observation=done, final_info=ep, _final_info=done)
-            return obs, reward, done, trunc, infos
+            return obs, reward, term, trunc, infos
         d = done.cpu().numpy()
         out = self._host(infos)
         if d.any():
@@ -90,7 +95,7 @@ class GymnasiumVectorEnv(_Base):
                 fobs[i] = rows[j]
                 finfo[i] = {k: (int(v[i]) if k == "length" else float(v[i])) for k, v in host_ep.items()}
             out.update(final_observation=fobs, _final_observation=d.copy(), final_info=finfo, _final_info=d.copy())
-        return self._host(obs), self.env.reward64.cpu().numpy(), d, trunc.cpu().numpy(), out  # (the reference's Python floats: doubles)
+        return self._host(obs), self.env.reward64.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy(), out  # (the reference's Python floats: doubles)
 
     # gymnasium.vector.VectorEnv API surface used by trainers
     def step_async(self, actions):
