@@ -337,11 +337,12 @@ namespace {
 // with them their stores into the same pinned block), and the host polls that word.  hipStreamSynchronize on this runtime costs
 // more than the step's kernels once the work is this small.  A wait that takes longer than 50 ms (a fault, a debugger) falls back to the
 // synchronising call, which also reports the stream's error; a runtime without stream memory operations synchronises as before.
-void single_wait(mg_env::Single& S, hipStream_t st) {
+void single_wait(mg_env::Single& S, hipStream_t st, bool armed = false) {
     static bool use_flag = true;
     if (use_flag) {
-        const uint32_t want = ++S.ticket;
-        if (hipStreamWriteValue32(st, S.dev + S.o_flag, want, 0) == hipSuccess) {
+        // armed: the step's own last kernel stores the ticket (Family::arm_done_flag; S.ticket was advanced when it was armed)
+        const uint32_t want = armed ? S.ticket : ++S.ticket;
+        if (armed || hipStreamWriteValue32(st, S.dev + S.o_flag, want, 0) == hipSuccess) {
             volatile uint32_t* flag = (volatile uint32_t*)(S.host + S.o_flag);
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spins = 0;; ++spins) {
@@ -425,10 +426,12 @@ int mg_single_step(mg_env* env, int32_t a0, int32_t a1, void* stream) {
         for (int k = 0; k < MG_INFO_SLOTS; ++k) ib.aux_dev[k] = (float*)(S.dev + S.o_aux + 256 * k);
         ib.reward64_dev = (double*)(S.dev + S.o_reward);
         mg::Family* f = env->fam;
+        const bool armed = f->arm_done_flag((uint32_t*)(S.dev + S.o_flag), S.ticket + 1);
+        if (armed) ++S.ticket;
         f->step((const int32_t*)(S.dev + S.o_action), S.dev + S.o_obs, (float*)(S.dev + S.o_reward32), (uint8_t*)(S.dev + S.o_done),
                 f->gt_dim() ? (float*)(S.dev + S.o_gt32) : nullptr, &ib, 0, st);
         f->ground_truth64((double*)(S.dev + S.o_gt), st);
-        single_wait(S, st);
+        single_wait(S, st, armed);
         flags = f->peek_errors();  // (the word lives in pinned host memory: a plain read; saves the caller a second native call per step)
     });
     return rc != 0 ? rc : flags;

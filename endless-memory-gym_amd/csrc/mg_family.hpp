@@ -198,6 +198,9 @@ class Family {
     virtual ~Family() {}
     virtual int action_dim() const = 0;
     virtual int gt_dim() const = 0;
+    // mg_single_step (mg_api.hip): can the family's next step() store `ticket` to *flag_dev itself when its results are out?  false: the
+    // caller waits through a stream memory operation behind the step's launches
+    virtual bool arm_done_flag(uint32_t* /*flag_dev*/, uint32_t /*ticket*/) { return false; }
     // capacities of the per-instance lists the reference grows without limit (include/memgym.h: mg_set_capacity / mg_capacity)
     virtual void set_capacity(const std::string& what, int64_t) { throw OptionError{-2, "this env id has no capacity named " + what}; }
     virtual int64_t capacity(const std::string& what) const { throw OptionError{-2, "this env id has no capacity named " + what}; }

@@ -582,9 +582,14 @@ __global__ __launch_bounds__(256) void mortar_step_kernel(MortarStepArgs a) {
 // exchange at the few cache lines of claim words, and those ~7,000 serialised atomics cost the 16,384-instance launch 6 of
 // its 66 us (profiles/r04_one_launch.md).
 constexpr unsigned long long RESCUE_AFTER_TICKS = 20000;  // 200 us
+// DONE_FLAG (the single-instance fast path, mg_single_step: ONE frame workgroup): when the frame is out, the workgroup stores `done_ticket`
+// to `done_flag` -- a word in the caller's pinned block that the host polls -- at system scope: 2.7 us less per step than a stream memory
+// operation behind the launch, 4.5 us less than hipStreamSynchronize (tools/microbench/launch_wait.hip).  Everything else the host reads
+// (reward, done, the episode record) was stored by the step's wave BEFORE it published the descriptor this workgroup waited for.
+template <bool DONE_FLAG>
 __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepArgs a, int logic_wgs, int logic_base, uint32_t epoch,
                                                                     uint32_t ticket, uint32_t* claims, uint32_t* rescues,
-                                                                    RasterAtlas A, void* __restrict__ obs) {
+                                                                    RasterAtlas A, void* __restrict__ obs, uint32_t* done_flag, uint32_t done_ticket) {
     const int n = a.n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int rel = (int)blockIdx.x - logic_base;
@@ -661,6 +666,11 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
         __syncthreads();
         store_frame<MG_OBS_U8_XYC, false>(smem, obs, env, t);  // (plain stores: non-temporal ones 281 -> 226-241 M at 65,536, round 4)
         __syncthreads();
+    }
+    if constexpr (DONE_FLAG) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // this wave's stores (the frame; after a rescue also the step's results) are performed system-wide
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -776,6 +786,16 @@ class MortarFamily : public Family {
         if (P_.variant == V_ENDLESS && what == "commands") return P_.cmd_cap;
         return Family::capacity(what);
     }
+    // mg_single_step: the NEXT step's last kernel stores `ticket` to *flag (a word the host polls) once its results are out.  Only the
+    // one-launch step of a one-instance handle without ground truth can promise that; everything else answers false and the caller puts a
+    // stream memory operation behind the step instead.
+    bool arm_done_flag(uint32_t* flag_dev, uint32_t ticket) override {
+        if (!(n_ == 1 && obs_format == MG_OBS_U8_XYC && fuse_step() && !per_set() && gt_dim() == 0 && !dirty_)) return false;
+        flag_dev_ = flag_dev;
+        flag_ticket_ = ticket;
+        flag_armed_ = true;
+        return true;
+    }
     int action_dim() const override { return P_.variant == V_GRID ? 1 : 2; }
     int gt_dim() const override { return P_.variant == V_ENDLESS ? 2 : 0; }
     int vec_dim() const override { return P_.taskb ? VEC_DIM : 0; }
@@ -888,8 +908,14 @@ class MortarFamily : public Family {
             // lab build, MEMGYM_LAB_LOGIC_LAST=1: the step workgroups at the END of the grid -- the dispatch order the design must survive
             static const bool logic_last = lab_int("MEMGYM_LAB_LOGIC_LAST", 0) != 0;
             prof.begin(1, s);
-            hipLaunchKernelGGL(mortar_step_raster_kernel, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, sa, logic_wgs,
-                               logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs);
+            if (flag_armed_ && n_ == 1) {
+                hipLaunchKernelGGL(mortar_step_raster_kernel<true>, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, sa, logic_wgs,
+                                   logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs, flag_dev_, flag_ticket_);
+                flag_armed_ = false;
+            } else {
+                hipLaunchKernelGGL(mortar_step_raster_kernel<false>, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, sa, logic_wgs,
+                                   logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs, (uint32_t*)nullptr, 0u);
+            }
             MG_HIP(hipGetLastError());
             prof.end(1, s);
             return;
@@ -942,6 +968,9 @@ class MortarFamily : public Family {
     }
 
    private:
+    uint32_t* flag_dev_ = nullptr;  // arm_done_flag
+    uint32_t flag_ticket_ = 0;
+    bool flag_armed_ = false;
     uint32_t ticket_ = 0;  // one-launch step: number of the step, the value a slot's claim word takes when a wave claims it
     uint32_t epoch_ = 0;  // the one-launch step's descriptor epoch, 1 .. 255 (every step rewrites every descriptor, so the only stale
                           // values a frame workgroup can meet are the previous step's and the 0 of a reset / two-launch step)
