@@ -87,13 +87,20 @@ struct MortarComposer {
     static __device__ __forceinline__ bool skip(const Desc* dp) { return dp->tmpl == 0xFFFF; }
     static __device__ __forceinline__ void compose(const Desc* dp, const RasterCtx& R) {
         const Desc& d = *dp;
+#if defined(MG_LAB_NO_TEMPLATE) && MG_LAB_NO_TEMPLATE == 2  // measurement builds (profiles/r06_raster_limits.md): no template at all (stale LDS)
+#elif defined(MG_LAB_NO_TEMPLATE)                           // ... a cleared frame instead of the template: no global loads, the LDS writes stay
+        fill_clear(R);
+#else
         fill_template(R, d.tmpl);
+#endif
         __syncthreads();
+#ifndef MG_LAB_NO_STAMPS
         if (d.sprite != 0xFF) stamp(R, STAMP_SPRITE0 + d.sprite, d.sx, d.sy);
         if (d.glyph < 9) {
             __syncthreads();
             stamp(R, STAMP_GLYPH0 + d.glyph, d.glyph_x0, d.glyph_x0);
         }
+#endif
     }
 };
 
