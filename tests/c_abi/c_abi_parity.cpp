@@ -52,6 +52,22 @@ int main(int argc, char** argv) {
     MG_OK(mg_create(env_id, n, 0, &env));
     const int adim = mg_action_dim(env), n_act = adim == 1 ? 4 : 3;
 
+    // capacities of the lists the reference grows without limit (mg_set_capacity, before the first reset): a larger store changes where an
+    // instance's records lie, nothing else -- the run below must equal the oracle all the same
+    const bool emp = !strcmp(env_id, "Endless-MysteryPath-v0"), emm = !strcmp(env_id, "Endless-MortarMayhem-v0");
+    if (emp) {
+        if (mg_capacity(env, "path_segments") != 128 || mg_capacity(env, "fall_off_cells") != 128) { printf("default capacities differ from the header's\n"); return 1; }
+        MG_OK(mg_set_capacity(env, "path_segments", 200));
+        if (mg_capacity(env, "path_segments") != 200) { printf("mg_capacity does not return what mg_set_capacity set\n"); return 1; }
+        if (mg_set_capacity(env, "path_segments", 2) == 0 || mg_set_capacity(env, "commands", 600) == 0) { printf("a bad capacity was accepted\n"); return 1; }
+    } else if (emm) {
+        if (mg_capacity(env, "commands") != 512) { printf("default command capacity differs from the header's\n"); return 1; }
+        MG_OK(mg_set_capacity(env, "commands", 700));
+    } else if (mg_capacity(env, "path_segments") != -1 || mg_set_capacity(env, "path_segments", 200) == 0) {
+        printf("an env id without that list accepted its capacity\n");
+        return 1;
+    }
+
     uint8_t *obs_d, *done_d;
     float* rew_d;
     int32_t* act_d;
@@ -91,6 +107,11 @@ int main(int argc, char** argv) {
     mg_info_buffers info;
     memset(&info, 0, sizeof(info));
     info.reward64_dev = rew64_d;
+    uint8_t* cap_d;  // (round 6) 1 where an episode was ended on a capacity of the build: never in this run
+    HIP_OK(hipMalloc((void**)&cap_d, n));
+    HIP_OK(hipMemset(cap_d, 0xFF, n));
+    info.capacity_dev = cap_d;
+    std::vector<uint8_t> cap(n);
     if (mg_step(env, act_d, obs_d, rew_d, done_d, nullptr, &info, 1, stream) == 0) {  // struct_size still 0: must be refused
         printf("a mg_info_buffers without struct_size was accepted\n");
         return 1;
@@ -114,9 +135,14 @@ int main(int argc, char** argv) {
         HIP_OK(hipMemcpyAsync(obs.data(), obs_d, frame * n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipMemcpyAsync(rew.data(), rew_d, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipMemcpyAsync(done.data(), done_d, n, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(cap.data(), cap_d, n, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         mgo_batch_step(ref, act.data(), 1, want.data(), want_rew.data(), want_done.data());
         for (int i = 0; i < n; ++i) {
+            if (cap[i] != 0) {
+                printf("capacity_dev[%d] = %d at step %d (written by every step, 0 unless the episode ended on a capacity)\n", i, cap[i], t);
+                return 1;
+            }
             if (done[i] != want_done[i] || rew[i] != (float)want_rew[i] || rew64[i] != want_rew[i] || memcmp(&obs[frame * i], &want[frame * i], frame) != 0) {
                 printf("MISMATCH at step %d, instance %d: done %d/%d reward %g/%g\n", t, i, done[i], want_done[i], rew[i], want_rew[i]);
                 return 1;
@@ -136,6 +162,10 @@ int main(int argc, char** argv) {
         MG_OK(mg_set_state(env, blob.data(), blob.size()));
         mg_env* other = nullptr;
         MG_OK(mg_create(env_id, n + 1, 0, &other));
+        if (mg_set_capacity(env, "path_segments", 300) == 0) {
+            printf("mg_set_capacity after the first reset was accepted\n");
+            return 1;
+        }
         if (mg_set_state(other, blob.data(), blob.size()) == 0) {
             printf("a state blob of %d instances was accepted by a handle of %d\n", n, n + 1);
             return 1;
@@ -149,6 +179,7 @@ int main(int argc, char** argv) {
     }
     printf("OK %s: %d instances x %d steps, %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, episodes);
     (void)hipFree(rew64_d);
+    (void)hipFree(cap_d);
     mg_destroy(env);
     mgo_batch_destroy(ref);
     (void)hipFree(obs_d); (void)hipFree(done_d); (void)hipFree(rew_d); (void)hipFree(act_d); (void)hipFree(seeds_d);

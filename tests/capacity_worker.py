@@ -32,7 +32,35 @@ SCENARIOS = {
 }
 
 
+def vector_front_end():
+    """gymnasium's vector convention: an episode this build ended on a capacity is TRUNCATED, not terminated (like a time limit); its
+    final_observation / final_info are there as for any other end."""
+    from memory_gym_amd.vector import GymnasiumVectorEnv
+    n, env_id = 96, "Endless-MysteryPath-v0"
+    envs = GymnasiumVectorEnv(env_id, n, on_capacity="truncate")
+    ref = oracle_lib.OracleBatch(env_id, n)   # (only the policy's eyes: the oracle's copies play on where this build truncates)
+    seeds = 7
+    obs, info = envs.reset(seed=seeds)
+    ref.reset(np.arange(n, dtype=np.int64) + seeds)
+    ended = 0
+    follow = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    gt = info["ground_truth"]
+    for t in range(420):
+        a = (gt.float() @ follow).to(torch.int32)  # a perfect follower, from the environment's own ground truth
+        obs, rew, term, trunc, infos = envs.step(a)
+        gt = infos["ground_truth"]
+        capx = infos["capacity_exceeded"]
+        assert torch.equal(capx, trunc) and not (term & trunc).any(), "terminated and truncated exclude each other"
+        if trunc.any():
+            assert infos["_final_info"][trunc].all() and infos["_final_observation"][trunc].all()
+            assert (infos["final_info"]["length"][trunc] > 100).all(), "a capacity end comes after a long walk"
+            ended += int(trunc.sum())
+    print(json.dumps({"scenario": "vector", "ended": ended}))
+
+
 def main():
+    if sys.argv[1] == "vector":
+        return vector_front_end()
     name, mode = sys.argv[1], sys.argv[2]
     env_id, options, n, steps, eps, field, cap = SCENARIOS[name]
     capacity = None

@@ -83,3 +83,11 @@ def test_a_larger_segment_store_is_the_same_environment():
         memory_gym_amd.make(env_id, num_envs=8, device=0, capacity={"path_segments": 2})
     with pytest.raises(ValueError, match="capacity"):
         memory_gym_amd.make("MortarMayhem-Grid-v0", num_envs=8, device=0, capacity={"path_segments": 200})
+
+
+def test_vector_front_end_reports_a_capacity_end_as_truncation():
+    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB, MEMGYM_EMP_SEG_CAP="6")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "capacity_worker.py"), "vector"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["ended"] > 0, j
