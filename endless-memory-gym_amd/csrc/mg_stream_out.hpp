@@ -75,12 +75,21 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
         u32x4 v5 = (u32x4)(0u);
         if (tid < TAIL) v5 = lds16[tid + 1280];
         constexpr int AUX = NT ? 2 : 0;  // cache policy operand: bit 1 = nt
+#if defined(MG_LAB_BUF_ORDER) && MG_LAB_BUF_ORDER == 1  // measurement builds: downwards like the plain path (round 6)
+        __builtin_amdgcn_raw_buffer_store_b128(v5, rs, (tid + 1280) * 16, 0, AUX);  // lanes >= TAIL: out of range, dropped
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (tid + 1024) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v3, rs, (tid + 768) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v2, rs, (tid + 512) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (tid + 256) * 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v0, rs, tid * 16, 0, AUX);
+#else
         __builtin_amdgcn_raw_buffer_store_b128(v0, rs, tid * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (tid + 256) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v2, rs, (tid + 512) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v3, rs, (tid + 768) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (tid + 1024) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v5, rs, (tid + 1280) * 16, 0, AUX);  // lanes >= TAIL: out of range, dropped
+#endif
     } else if constexpr (FMT == MG_OBS_U8_XYC) {
         const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
         u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * OBS_STRIDE_U8);
@@ -93,8 +102,16 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
             __builtin_nontemporal_store(v4, &dst[tid + 1024]);
             if (tid < TAIL) __builtin_nontemporal_store(v5, &dst[tid + 1280]);
         } else {
+            // DOWNWARDS, the partial tail first (round 6): the same six stores in the opposite order measure 2.2-2.6 % faster on the mortar
+            // family's one-launch step at 65,536 instances (289.6-289.9 -> 297.2-297.4 M env-steps/s, A/B/A/B on one box), 1-2 % at 32,768,
+            // nothing at 16,384 and on the Mystery Path launches (profiles/r06_store_counters.md, "pacing"); upwards was rounds 1-5.
+#if defined(MG_LAB_STORE_ORDER) && MG_LAB_STORE_ORDER == 0   // measurement builds: upwards
             dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3; dst[tid + 1024] = v4;
             if (tid < TAIL) dst[tid + 1280] = v5;
+#else
+            if (tid < TAIL) dst[tid + 1280] = v5;
+            dst[tid + 1024] = v4; dst[tid + 768] = v3; dst[tid + 512] = v2; dst[tid + 256] = v1; dst[tid] = v0;
+#endif
         }
     } else if constexpr (FMT == MG_OBS_F32_CYX) {
         float4* dst = reinterpret_cast<float4*>(static_cast<float*>(obs) + (size_t)env * FRAME_BYTES);
