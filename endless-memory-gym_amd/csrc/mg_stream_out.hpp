@@ -34,7 +34,9 @@ constexpr size_t OBS_STRIDE_U8 = FRAME_BYTES;
 // Workgroups are dealt to the eight XCDs round-robin (workgroup b -> XCD b % 8, each with an L2 of its own).  Ordinal v = 64 q + 8 r + x
 // draws frame 64 q + 8 x + r: the eight workgroups of one XCD within a block of 64 own eight CONSECUTIVE frames (= 1,323 whole lines).
 __device__ __forceinline__ int xcd_grouped_frame(int v, int n) {
-#ifdef MG_LAB_XCD_GROUP
+#ifdef MG_LAB_FRAMES_DOWN  // measurement builds: the launch walks the buffer from its end to its start
+    return n - 1 - v;
+#elif defined(MG_LAB_XCD_GROUP)
     return (v | 63) < n ? ((v & ~63) | ((v & 7) << 3) | ((v >> 3) & 7)) : v;  // (a last, partial block of 64 keeps the plain order)
 #else
     (void)n;
