@@ -77,21 +77,14 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
         u32x4 v5 = (u32x4)(0u);
         if (tid < TAIL) v5 = lds16[tid + 1280];
         constexpr int AUX = NT ? 2 : 0;  // cache policy operand: bit 1 = nt
-#if defined(MG_LAB_BUF_ORDER) && MG_LAB_BUF_ORDER == 1  // measurement builds: downwards like the plain path (round 6)
-        __builtin_amdgcn_raw_buffer_store_b128(v5, rs, (tid + 1280) * 16, 0, AUX);  // lanes >= TAIL: out of range, dropped
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (tid + 1024) * 16, 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(v3, rs, (tid + 768) * 16, 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(v2, rs, (tid + 512) * 16, 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (tid + 256) * 16, 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(v0, rs, tid * 16, 0, AUX);
-#else
+        // (upwards: the plain path's downward order measured 1-5 % WORSE here, tail-first and alternating orders and a sleep between the
+        // stores nothing -- profiles/r06_store_counters.md, addendum 2)
         __builtin_amdgcn_raw_buffer_store_b128(v0, rs, tid * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (tid + 256) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v2, rs, (tid + 512) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v3, rs, (tid + 768) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (tid + 1024) * 16, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(v5, rs, (tid + 1280) * 16, 0, AUX);  // lanes >= TAIL: out of range, dropped
-#endif
     } else if constexpr (FMT == MG_OBS_U8_XYC) {
         const u32x4* lds16 = reinterpret_cast<const u32x4*>(frame);
         u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(obs) + (size_t)env * OBS_STRIDE_U8);
