@@ -1332,6 +1332,24 @@ __device__ __forceinline__ void spot_step_body(int i, const LaneCtx& L, const Sp
 #endif
 }
 
+#ifdef MG_LAB
+// Measurement (lab build, MEMGYM_SPOT_WARM=1; profiles/r06_spot.md): a launch behind the raster that reads exactly what the NEXT step
+// kernel's lanes will read first -- core record, generator stream, slot record -- with the same block -> instance mapping, so that the
+// step finds its state in its XCD's L2.  Only the step kernel's time is of interest (would a warm state be worth building into the
+// raster launch's tail?); this launch's own cost is not hidden.
+__global__ __launch_bounds__(256) void spot_warm_kernel(int n, SpotIO io) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid >> 4, ls = gid & 15;
+    if (i >= n) return;
+    const size_t k = (size_t)i * SLOTS + ls;
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(&io.core[i]);
+    uint64_t acc = c[ls] ^ c[(ls + 16) % 20];
+    acc ^= io.rng.s_hi[i] ^ io.rng.s_lo[i] ^ io.rng.inc_hi[i] ^ io.rng.inc_lo[i] ^ io.rng.buf[i];
+    acc ^= (uint64_t)io.sp_ang[k] ^ (uint64_t)io.sp_r[k] ^ (uint64_t)__double_as_longlong(io.sp_t[k]) ^ (uint64_t)__double_as_longlong(io.sp_speed[k]);
+    if (acc == 0x1234567812345678ull) io.err[0] |= 0;  // (never: keeps the loads alive)
+}
+#endif
+
 template <bool EN, bool PS>
 __global__ __launch_bounds__(256) void spot_step_kernel(SpotStepArgs a) {
     __shared__ int disc_lds[(256 / 16) * DISC_INTS];  // step_block() launches 256 lanes at most
@@ -1727,6 +1745,9 @@ class SpotFamily : public Family {
             raster(obs, s);
         }
         prof.end(1, s);
+#ifdef MG_LAB
+        if (lab_int("MEMGYM_SPOT_WARM", 0)) hipLaunchKernelGGL(spot_warm_kernel, sg, dim3(sb), 0, s, n_, io());
+#endif
     }
 
     std::vector<std::pair<void*, size_t>> state_blobs() override {
