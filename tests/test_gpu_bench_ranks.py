@@ -49,3 +49,24 @@ def test_killed_rank_mid_leg_keeps_the_headline():
     assert j["value_2000"]["steps"] == 200 and j["value_2000"]["value"] > 5e5
     assert j["config5"]["no_gather"]["value"] > 5e5
     assert "ended_early" in j or "failed" in json.dumps(j["config5"].get("gather_peer", ""))
+
+
+def test_under_torch_distributed_run_like_the_driver():
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with both ranks on GPU 0 and gloo in RCCL's place: one JSON line on the
+    launcher's stdout, from rank 0, with the N-rank headline, `ranks` and the config-5 legs."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MEMGYM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--backend", "gloo",
+                          "--settle", "30", "--envs-per-gpu", "4096", "--config5-envs", "4096", "--config5-steps", "24", "--long-window", "100"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line: %r" % out.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 5e5 and j["ranks"]["world"] == 2 and j["value_2000"]["steps"] == 100
+    assert j["config5"]["no_gather"]["value"] > 5e5 and "ended_early" not in j
