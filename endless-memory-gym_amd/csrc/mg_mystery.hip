@@ -1799,259 +1799,6 @@ __device__ void lane_segment(const MysteryIO& io, const LaneWS& W, int i, Myster
     EMP_PRE(s) = 0;  // the stream has moved: a record generated ahead of time no longer continues it
 }
 
-#ifdef MG_LAB_EMP_CLOCK  // measurement builds: phases of quad 0 of each background workgroup (tools/emp_timeline.py)
-static __device__ unsigned long long g_lab_quad_clock[8 * 1024];
-#define QUAD_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_lab_quad_clock[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
-#define QUAD_COUNT(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_lab_quad_clock[8 * blockIdx.x + (slot)] = (unsigned long long)(v); } while (0)
-#else
-#define QUAD_CLOCK(slot) do { } while (0)
-#define QUAD_COUNT(slot, v) do { } while (0)
-#endif
-// ---- Quad-per-job path generation (round 6; an EXPERIMENT, compiled with -DMG_LAB_EMP_QUAD=1 only) ---------------------------------
-// One lane per path lasts ~105 us whatever the wave carries (the path's own dependent chain), and the fused Endless-MysteryPath launch
-// ends with its background workgroups, not with its frames (profiles/r05_emp.md, section 3).  Here FOUR lanes share a path.  What the
-// reference does per neighbour (pygame_assets.py:700-724: the closed / wall test, the noisy cost, the open-list entry) happens on the
-// neighbour's lane; the search through the open list takes eight positions per round trip to LDS (two per lane); what is path-wide is
-// either computed by all four lanes from the same inputs or lives in LDS, and the lanes talk through quad permutes (DPP) only.
-//   * per node, one 16-bit record: g_cost | previous_node << 9 | blocked << 15; 0 = never seen.  "blocked" = wall or closed, "in the
-//     open list" = seen and not blocked, so the neighbour's lane learns everything about its node from one read.
-//   * the open list is append-only (lane_path): a taken entry becomes DEAD (a key no f is below), the list's first live entry is
-//     looked for again only when it was the one taken.
-//   * the draws of an expansion: the k-th expanded neighbour (Node.add_neighbors order) takes the k-th 32-bit draw.  PCG64 can be
-//     jumped (WaveRng above): lanes 0 / 1 compute the next 64-bit output (state * A + inc), lanes 2 / 3 the one behind it (state * A^2
-//     + inc * (A + 1)), lane j holds half j of the four; a neighbour's lane picks its half, and the stream goes on from the state of
-//     the last output a half was taken from.  integers(1, 9) has a span of 8 and never rejects.
-//   * the walls (16 + 4 or 8 bounded draws that can reject) are drawn by every lane in sequence, like lane_path.
-// Bit-exact (tests/test_gpu_mystery.py with MG_LAB_EMP_QUAD=1) and SLOWER than one lane per path beside the frames: an expansion takes
-// 1.4 us with the chip to itself and 2.4-3.4 us beside the raster's waves whichever way it is written -- profiles/r06_emp.md, section 5.
-constexpr int QW_KEY_STRIDE = 49;                             // uint32 key[49] (every node enters the list at most once): (fkey << 6) | node, by list position; later the path
-constexpr int QW_REC_STRIDE = 25;                             // uint16 rec[49] (+1), by node
-constexpr int QW_KEY = 0;
-constexpr int QW_NODE = QW_KEY + 64 * QW_KEY_STRIDE * 4;
-constexpr int QW_HFIX = QW_NODE + 64 * QW_REC_STRIDE * 4;     // uint32 hfix[80]
-constexpr int QW_BYTES = QW_HFIX + 80 * 4;
-constexpr uint32_t QW_DEAD = 0xFFFFFFFFu;                     // (keys stay below 2^26 << 6: tests/test_path_keys.py)
-constexpr uint32_t QW_BLOCKED = 0x8000u;
-struct QuadWS {
-    uint8_t* base;
-    int q, j;  // the path's slot in the workgroup (0 .. 63), the lane's place in its quad (0 .. 3)
-    __device__ __forceinline__ uint32_t& key(int p) const { return reinterpret_cast<uint32_t*>(base + QW_KEY)[q * QW_KEY_STRIDE + p]; }
-    __device__ __forceinline__ uint16_t& rec(int n) const { return reinterpret_cast<uint16_t*>(base + QW_NODE)[q * (2 * QW_REC_STRIDE) + n]; }
-    __device__ __forceinline__ uint32_t hfix(int d2) const { return reinterpret_cast<const uint32_t*>(base + QW_HFIX)[d2]; }
-};
-__device__ __forceinline__ void quad_ws_init(uint8_t* smem) {  // all threads of the block
-    for (int d = threadIdx.x; d < 80; d += blockDim.x)
-        reinterpret_cast<uint32_t*>(smem + QW_HFIX)[d] = (uint32_t)__double2ll_rn(sqrt((double)d) * 131072.0);
-    __syncthreads();
-}
-// LDS operations of one wave execute in order; what has to be kept is the COMPILER's order of one lane's reads behind another lane's writes
-#define QUAD_ORDER() asm volatile("" ::: "memory")
-// quad permutes: lane k of the quad to all four / a value from a lane chosen at run time / the OR over the quad
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
-__device__ __forceinline__ uint32_t quad_pick(uint32_t v, int k) {
-    const uint32_t b0 = quad_perm<0x00>(v), b1 = quad_perm<0x55>(v), b2 = quad_perm<0xAA>(v), b3 = quad_perm<0xFF>(v);
-    return k == 0 ? b0 : k == 1 ? b1 : k == 2 ? b2 : b3;
-}
-__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
-    v |= quad_perm<0xB1>(v);  // [1, 0, 3, 2]
-    v |= quad_perm<0x4E>(v);  // [2, 3, 0, 1]
-    return v;
-}
-constexpr u128 PCG_A1 = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
-constexpr u128 PCG_A2 = PCG_A1 * PCG_A1;
-
-// MysteryPath.__init__ (pygame_assets.py:606-724) by the four lanes of a quad; g (the instance's stream) and every argument
-// are the same in all four.  Returns the path length (-1: none); W.key(k), k < len, is the k-th path node (flat index x*7+y,
-// END first like the reference's list).
-__device__ int quad_path(Pcg& g, const QuadWS& W, int sx, int sy, int ex, int ey, uint64_t& wall_out) {
-    const int j = W.j;
-    uint64_t wall = 0;
-    for (int i = 1; i < G - 2; ++i)
-        for (int jj = 1; jj < G - 2; ++jj)
-            if (g.integers(0, 100) < 33) wall |= 1ull << (i * G + jj);
-    const int start = sx * G + sy, end = ex * G + ey;
-    const uint64_t ends = (1ull << start) | (1ull << end);
-    uint64_t outer = GM_BORDER & ~ends & ~cells_around4(ends) & ~cells_around8(wall);
-    int n_outer = __popcll(outer);
-    const int n_iter = g.integers(0, 2) == 0 ? 4 : 8;  // rng.choice([4, 8])
-    for (int it = 0; it < n_iter; ++it) {
-        if (n_outer > 0) {
-            const int k = g.integers(0, n_outer);
-            uint64_t m = outer;
-            for (int q = 0; q < k; ++q) m &= m - 1;
-            const uint64_t bit = m & (~m + 1);
-            wall |= bit;
-            outer &= ~bit;
-            --n_outer;
-        }
-    }
-    wall_out = wall;
-    QUAD_CLOCK(2);
-#ifdef MG_LAB_EMP_CLOCK
-    int lab_exp = 0, lab_rounds = 0;
-#endif
-    for (int n = j; n < G * G; n += 4) W.rec(n) = (uint16_t)(((wall >> n) & 1ull) ? QW_BLOCKED : 0u);
-    QUAD_ORDER();
-    if (j == 0) {
-        W.key(0) = (uint32_t)start;  // (only the order of the keys matters: the start is alone in the list when it is taken)
-        W.rec(start) = (uint16_t)(63u << 9);
-    }
-    QUAD_ORDER();
-    // the lane's share of an expansion: its neighbour (Node.add_neighbors order x+1, x-1, y+1, y-1) and its half of the next two outputs
-    const int nb_step = j == 0 ? G : j == 1 ? -G : j == 2 ? 1 : -1;
-    const int nb_edge = (j & 1) ? 0 : G - 1;  // the coordinate (x for lanes 0 / 1, y for 2 / 3) at which the neighbour does not exist
-    const u128 jump_m = j < 2 ? PCG_A1 : PCG_A2;
-    const u128 jump_c = j < 2 ? g.inc : g.inc * (PCG_A1 + 1);
-    u128 state = g.state;
-    uint32_t buf = g.buf;
-    int has = g.has ? 1 : 0;
-    const uint32_t below = (1u << j) - 1u;
-    int n_pos = 1, n_live = 1, head = 0, from = 0, scan = 1;
-    uint32_t khead = (uint32_t)start;
-    int len = -1;
-    for (;;) {
-        if (n_live == 0) break;  // "No valid path found"
-        if (head < 0) {  // the list's first entry was taken: the next live one, from position `from`
-            for (int p = from;; p += 8) {
-                const int pa = p + j, pb = p + 4 + j;
-                const uint32_t a = W.key(pa < G * G - 1 ? pa : G * G - 1), b = W.key(pb < G * G - 1 ? pb : G * G - 1);
-                const uint32_t m = quad_or(((pa < n_pos && a != QW_DEAD) ? 1u << j : 0u) | ((pb < n_pos && b != QW_DEAD) ? 16u << j : 0u));
-                if (m) {
-                    const int t = __builtin_ctz(m);
-                    head = p + t;
-                    khead = quad_pick(t < 4 ? a : b, t & 3);
-                    break;
-                }
-            }
-            scan = head + 1;
-        }
-        // "first i >= 1 with f[i] < f[0], else 0" (see lane_path): eight list positions per round
-        const uint32_t k0 = khead >> 6;
-        int w = head;
-        uint32_t kw = khead;
-        for (int p = scan; p < n_pos && w == head; p += 8) {
-            const int pa = p + j, pb = p + 4 + j;
-            const uint32_t a = W.key(pa < G * G - 1 ? pa : G * G - 1), b = W.key(pb < G * G - 1 ? pb : G * G - 1);
-            const uint32_t m = quad_or(((pa < n_pos && (a >> 6) < k0) ? 1u << j : 0u) | ((pb < n_pos && (b >> 6) < k0) ? 16u << j : 0u));
-            if (m) {  // the lowest qualifying position wins
-                const int t = __builtin_ctz(m);
-                w = p + t;
-                kw = quad_pick(t < 4 ? a : b, t & 3);
-            }
-#ifdef MG_LAB_EMP_CLOCK
-            ++lab_rounds;
-#endif
-        }
-        scan = w != head ? w + 1 : n_pos;
-        const int cur = (int)(kw & 63u);
-        if (cur == end) {
-            int t = cur;
-            len = 0;
-            for (;;) {
-                const int pv = (W.rec(t) >> 9) & 63;
-                if (j == 0) W.key(len) = (uint32_t)t;
-                ++len;
-                if (pv == 63) break;
-                t = pv;
-            }
-            break;
-        }
-#ifdef MG_LAB_EMP_CLOCK
-        ++lab_exp;
-#endif
-        // open_set.remove(current_node); closed_set.append(current_node)
-        if (j == 0) W.key(w) = QW_DEAD;
-        --n_live;
-        if (w == head) {
-            from = head + 1;
-            head = -1;
-        }
-        const int cx = cur / G, cy = cur - cx * G;
-        const bool exists = (j < 2 ? cx : cy) != nb_edge;
-        const int nb = exists ? cur + nb_step : cur;
-        const uint32_t rcur = W.rec(cur), rnb = W.rec(nb);
-        if (j == 0) W.rec(cur) = (uint16_t)(rcur | QW_BLOCKED);
-        const int gcur = (int)(rcur & 511u);
-        const bool mine = exists && !(rnb & QW_BLOCKED);   // `if neighbor in closed_set or neighbor.is_wall: continue`
-        const bool fresh = mine && rnb == 0;               // not in the open list yet
-        const uint32_t VN = quad_or((mine ? 1u << j : 0u) | (fresh ? 16u << j : 0u));
-        const uint32_t V = VN & 15u, NEW = VN >> 4;
-        // the lane's half of the next two outputs
-        const u128 st = state * jump_m + jump_c;
-        const uint64_t sh = (uint64_t)(st >> 64), sl = (uint64_t)st, sxr = sh ^ sl;
-        const unsigned rot = (unsigned)(sh >> 58);
-        const uint64_t o = (sxr >> rot) | (sxr << ((64 - rot) & 63));
-        const uint32_t half = (j & 1) ? (uint32_t)(o >> 32) : (uint32_t)o;
-        // the k-th expanded neighbour's draw: the buffered half first, if there is one
-        const int f = __popc(V & below) - has;
-        const uint32_t fresh_half = quad_pick(half, f < 0 ? 0 : f);
-        const uint32_t val = f < 0 ? buf : fresh_half;
-        const int cost = gcur + 1 + (int)(val >> 29);  // integers(1, 9)
-        // the stream behind the expansion's draws: t halves of new outputs were taken (numpy keeps the buffered half also once it is
-        // used: Pcg::next32)
-        {
-            const int c = __popc(V), t = c - has;
-            const uint32_t s0 = (uint32_t)st, s1 = (uint32_t)(st >> 32), s2 = (uint32_t)(st >> 64), s3 = (uint32_t)(st >> 96);
-            const uint32_t a0 = quad_perm<0x00>(s0), a1 = quad_perm<0x00>(s1), a2 = quad_perm<0x00>(s2), a3 = quad_perm<0x00>(s3);
-            const uint32_t b0 = quad_perm<0xAA>(s0), b1 = quad_perm<0xAA>(s1), b2 = quad_perm<0xAA>(s2), b3 = quad_perm<0xAA>(s3);
-            const uint32_t h1 = quad_perm<0x55>(half), h3 = quad_perm<0xFF>(half);  // the high halves of the two outputs
-            if (t > 2) {
-                state = ((u128)b3 << 96) | ((u128)b2 << 64) | ((u128)b1 << 32) | b0;
-                buf = h3;
-            } else if (t > 0) {
-                state = ((u128)a3 << 96) | ((u128)a2 << 64) | ((u128)a1 << 32) | a0;
-                buf = h1;
-            }
-            if (c > 0) has = t > 0 ? (t & 1) : 0;
-        }
-        if (mine) {
-            if (!fresh) {
-                if (cost < (int)(rnb & 511u)) W.rec(nb) = (uint16_t)((rnb & 511u) | (cur << 9));  // `neighbor.g = g` typo: g_cost stays
-            } else {
-                W.rec(nb) = (uint16_t)(cost | (cur << 9));
-                const int ax = nb / G - ex, ay = nb % G - ey;
-                W.key(n_pos + __popc(NEW & below)) = ((((uint32_t)cost << 17) + W.hfix(ax * ax + ay * ay)) << 6) | (uint32_t)nb;
-            }
-        }
-        {
-            const int cnt = __popc(NEW);
-            n_pos += cnt;
-            n_live += cnt;
-        }
-        QUAD_ORDER();
-    }
-    QUAD_ORDER();
-    QUAD_CLOCK(3);
-    QUAD_COUNT(5, lab_exp);
-    QUAD_COUNT(6, lab_rounds);
-    g.state = state;
-    g.buf = buf;
-    g.has = has != 0;
-    return len;
-}
-
-// The path's nodes into a segment record (lane_segment_record's layout: byte 0 = node count, then the path START first, then the
-// transition node): lane j writes words j, j + 4, ... of the record.
-__device__ __forceinline__ void quad_write_record(const QuadWS& W, int len, int ey, uint32_t* dst) {
-    for (int jw = W.j; jw < SEG_STRIDE / 4; jw += 4) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int p = 4 * jw + b;
-            uint32_t v = 0;
-            if (p == 0) v = (uint32_t)(len + 1);
-            else if (p <= len) {
-                const int nd = (int)W.key(len - p);
-                v = (uint32_t)((nd / G) | ((nd % G) << 3));
-            } else if (p == len + 1) v = (uint32_t)(7 | (ey << 3));
-            word |= v << (8 * b);
-        }
-        dst[jw] = word;
-    }
-    QUAD_ORDER();  // (the next path of the quad rewrites the list)
-}
-
 // The queued resets of a deferred step are served INSIDE the raster launch: its first PATH_WGS workgroups do not draw frames
 // but drain the queue, one wave per entry (entry w is wave w's first job, later ones come from a shared counter, the
 // last of them out clears the counters: see emp_serve_kernel), then leave their slots to frame workgroups.  Lane 0 plays the
@@ -2217,58 +1964,6 @@ __device__ __forceinline__ void lane_owed_segment(const MysteryIO& io, const Lan
     g.store(io.rng, i);
 }
 
-// The same background job by the four lanes of a quad (quad_path, -DMG_LAB_EMP_QUAD=1): every lane reads the instance's stream, lane 0
-// of the quad stores what one lane stores in lane_owed_segment, the segment record's words are written by all four.
-__device__ __forceinline__ void quad_owed_segment(const MysteryIO& io, const QuadWS& W, int i, bool ahead) {
-    // (Nothing but the stream is held across the path: the record's fields are read where they are used -- the whole 96-byte record,
-    // or the pointers derived from it, held across the A* loop cost that loop its registers.  The instance's record belongs to nobody
-    // else between its step and its next step.)
-    const MysteryCore* const cp = io.core + i;
-    const int owed = EMP_OWED(*cp);
-    const bool pre_job = owed <= 0;
-    if (pre_job && (!ahead || EMP_PRE(*cp))) return;
-    QUAD_CLOCK(0);
-    Pcg g;
-    g.load(io.rng, i);
-    // EndlessMysteryPath.add_path_segment (pygame_assets.py:544-604): a reset's first segment draws its start row
-    const int sy = (!pre_job && cp->have_start != 0) ? (int)cp->end_y : g.integers(0, G);
-    const int ey = g.integers(0, G);
-    QUAD_CLOCK(1);
-    uint64_t wl = 0;
-    int len = quad_path(g, W, 0, sy, G - 1, ey, wl);
-    if (len < 0) {
-        if (W.j == 0) raise_error(io.err, 2);
-        len = 0;
-    }
-    const bool room = cp->num_seg < io.seg_rows;
-    uint32_t* const rec = io.aux + (size_t)i * AUX_WORDS;
-    uint32_t* const dst = pre_job ? rec : (room ? reinterpret_cast<uint32_t*>(seg_ptr(io, i, cp->num_seg)) : nullptr);
-    if (dst) quad_write_record(W, len, ey, dst);
-    QUAD_CLOCK(4);
-    if (W.j != 0) return;
-    MysteryCore s = io.core[i];
-    if (pre_job) {
-        rec[13] = g.buf;
-        rec[14] = (g.has ? 1u : 0u) | ((uint32_t)ey << 8);
-        rec[16] = (uint32_t)g.state;
-        rec[17] = (uint32_t)(g.state >> 32);
-        rec[18] = (uint32_t)(g.state >> 64);
-        rec[19] = (uint32_t)(g.state >> 96);
-        EMP_PRE(s) = 1;  // (the instance's own stream stays where it is)
-        io.core[i] = s;
-        if (io.stats) atomicAdd(io.stats + 3, 1ull);  // mg_debug_counter "emp_ahead_records"
-        return;
-    }
-    if (room) s.num_seg++;
-    else raise_error(io.err, 4);
-    s.have_start = 1;
-    s.end_y = (int8_t)ey;
-    EMP_PRE(s) = 0;
-    EMP_OWED(s) = (uint8_t)(owed - 1);
-    io.core[i] = s;
-    g.store(io.rng, i);
-}
-
 // Everything still owed, for every instance (Family::sync_state: before the state is looked at)
 __global__ __launch_bounds__(64) void emp_flush_owed_kernel(MysteryParams P, MysteryIO io) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -2385,9 +2080,6 @@ constexpr int EMP_BG_WGS = 512;  // at most so many workgroups behind the servic
 #ifndef MG_LAB_EMP_BG_SPAN
 #define MG_LAB_EMP_BG_SPAN 256
 #endif
-#ifndef MG_LAB_EMP_QUAD  // measurement builds: -DMG_LAB_EMP_QUAD=1 = the background jobs on four lanes each (quad_path; measured slower: profiles/r06_emp.md, section 5)
-#define MG_LAB_EMP_QUAD 0
-#endif
 constexpr int EMP_BG_SPAN = MG_LAB_EMP_BG_SPAN;
 static_assert(EMP_BG_SPAN <= 256 || EMP_BG_SPAN % 256 == 0, "a background workgroup reads its span's flags 256 at a time");
 static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
@@ -2478,10 +2170,9 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
     if ((int)blockIdx.x < fb) {
         // (the list lives behind the lane generator's workspace in the frame buffer: 1 KB more of static LDS and the seventh workgroup
         // no longer fits a CU)
-        constexpr int GEN_BYTES = LW_BYTES > QW_BYTES ? LW_BYTES : QW_BYTES;
-        int* const bg_jobs = reinterpret_cast<int*>(smem + GEN_BYTES);
+        int* const bg_jobs = reinterpret_cast<int*>(smem + LW_BYTES);
         int* const bg_cnt = bg_jobs + EMP_BG_SPAN;
-        static_assert(GEN_BYTES + EMP_BG_SPAN * 4 + 16 <= v1::RASTER_LDS && GEN_BYTES % 16 == 0, "the job list must fit behind the path generator's workspace");
+        static_assert(LW_BYTES + EMP_BG_SPAN * 4 + 16 <= v1::RASTER_LDS && LW_BYTES % 16 == 0, "the job list must fit behind the lane generator's workspace");
         const int b = (int)blockIdx.x - svc;
 #ifdef MG_LAB_EMP_NOBG  // (measurement builds: what the launch costs without the background jobs; owed segments are never generated here)
         if (b >= 0) return;
@@ -2502,27 +2193,15 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
                 __syncthreads();  // (the counts are rewritten by the next chunk; the list is complete behind the last one)
             }
             if (total && !ws) {
-#if MG_LAB_EMP_QUAD
-                quad_ws_init(smem);
-#else
                 lane_ws_init(smem);
-#endif
                 ws = true;
             }
-            const int rot = total > 64 ? (int)((unsigned)turn * 61u % (unsigned)total) : 0;
-#if MG_LAB_EMP_QUAD  // experiment of round 6: a quad per job, up to 64 jobs on the workgroup's four waves (profiles/r06_emp.md, section 5)
-            if (P.svc_prio) __builtin_amdgcn_s_setprio(3);  // a long dependent chain next to memory-bound raster waves
-            {
-                const QuadWS QW{smem, tid >> 2, tid & 3};
-                if ((tid >> 2) < total) quad_owed_segment(io, QW, bg_jobs[((tid >> 2) + rot) % total], P.pre != 0);
-            }
-#else
             if (tid < 64) {
                 if (P.svc_prio) __builtin_amdgcn_s_setprio(3);  // a long dependent chain next to memory-bound raster waves
                 const LaneWS LW{smem, tid};
+                const int rot = total > 64 ? (int)((unsigned)turn * 61u % (unsigned)total) : 0;
                 if (tid < total) lane_owed_segment(io, LW, bg_jobs[(tid + rot) % total], 1, P.pre != 0);
             }
-#endif
             __syncthreads();  // (the list is rewritten by the next round)
         }
         LAB_CLOCK(1);
@@ -3088,9 +2767,6 @@ Family* make_mystery(int variant, int num_envs) { return new MysteryFamily(varia
 #ifdef MG_LAB_EMP_CLOCK
 extern "C" int mg_lab_step_clock(unsigned long long* host, int n_waves) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_step_clock), sizeof(unsigned long long) * 12 * (size_t)n_waves) == hipSuccess ? 0 : -1;
-}
-extern "C" int mg_lab_quad_clock(unsigned long long* host, int n_wgs) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_quad_clock), sizeof(unsigned long long) * 8 * (size_t)n_wgs) == hipSuccess ? 0 : -1;
 }
 extern "C" int mg_lab_emp_clock(unsigned long long* host, int n_wgs) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(mg::g_lab_emp_clock), sizeof(unsigned long long) * 3 * (size_t)n_wgs) == hipSuccess ? 0 : -1;

@@ -56,21 +56,6 @@ stats("frame WGs: start", (idx >= svc) & live, 0)
 stats("frame WGs: end", (idx >= svc) & live, 2)
 print("launch: %.1f us from the first start to the last end" % us[live, 2].max())
 
-# quad 0 of every background workgroup: phases of its path (quad-per-job generator, -DMG_LAB_EMP_QUAD=1 -DMG_LAB_EMP_CLOCK)
-if hasattr(_native.LIB, "mg_lab_quad_clock"):
-    qb = np.zeros(8 * 1024, np.uint64)
-    _native.LIB.mg_lab_quad_clock.argtypes = [C.c_void_p, C.c_int]
-    if _native.LIB.mg_lab_quad_clock(qb.ctypes.data, 1024) == 0:
-        qc = qb.reshape(1024, 8).astype(np.float64)
-        ok = (qc[:, 0] > 0) & (qc[:, 3] > qc[:, 0])
-        if ok.any():
-            for nm, a_, b_ in (("job start -> stream loaded", 0, 1), ("-> walls drawn", 1, 2), ("-> A* done", 2, 3), ("-> record written", 3, 4)):
-                dd = (qc[ok, b_] - qc[ok, a_]) / 100.0
-                print("quad 0 of %d bg WGs: %-28s median %6.2f  p90 %6.2f  max %6.2f us" % (ok.sum(), nm, np.median(dd), np.percentile(dd, 90), dd.max()))
-            print("  expansions per path: median %.0f  p90 %.0f  max %.0f;  list rounds per path: median %.0f  max %.0f;  us per expansion: median %.2f" % (
-                np.median(qc[ok, 5]), np.percentile(qc[ok, 5], 90), qc[ok, 5].max(), np.median(qc[ok, 6]), qc[ok, 6].max(),
-                np.median((qc[ok, 3] - qc[ok, 2]) / 100.0 / np.maximum(qc[ok, 5], 1))))
-
 # emp_step_kernel: phases per wave; every stamp follows an s_waitcnt 0, so a phase is what the wave waited for
 nw = n // 64
 K = 12
