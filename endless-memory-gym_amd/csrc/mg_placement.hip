@@ -456,7 +456,45 @@ int mg_store_probe(void* buf, size_t n_frames, int pattern, void* stream_) {
     return 0;
 }
 
+// Which zone (0 .. G - 1) each of the k pieces of an assembled range comes from: piece p lies in window w(p) of the frame walk (by its
+// centre; the buffer starts `lead` bytes into the range, a window = the bytes between two concurrently written fronts) as that window's
+// j-th piece and comes from zone (w + j) mod 2; with three zones, piece p from zone p mod 3 (mg_obs_alloc_for below).
+static void plan_zones(size_t k, size_t lead, size_t window, size_t G, std::vector<size_t>& want, std::vector<size_t>& count) {
+    want.assign(k, 0);
+    count.assign(G, 0);
+    size_t prev_w = (size_t)-1, j = 0;
+    for (size_t p = 0; p < k; ++p) {
+        const size_t centre = p * PIECE + PIECE / 2, w = centre > lead ? (centre - lead) / window : 0;
+        j = w == prev_w ? j + 1 : 0;
+        prev_w = w;
+        // (three zones: one after the other -- 3 has no common factor with the 1, 2 or 4 pieces of a window, the fronts of every format
+        // fall into different zones as they are; tests/test_obs_plan.py)
+        want[p] = G == 2 ? (w + j) % 2 : p % G;
+        ++count[want[p]];
+    }
+}
+static size_t range_lead(size_t k, size_t bytes) { return ((k * PIECE - bytes) / 2) & ~(size_t)(2 * MiB - 1); }
+
+int mg_obs_plan(size_t bytes, size_t frame_bytes, int zones, size_t* piece_bytes, size_t* lead_bytes, int* zone_of_piece, int max_pieces) {
+    if (bytes == 0 || zones < 2 || zones > 3) {
+        mg::set_error("mg_obs_plan: bad arguments");
+        return -1;
+    }
+    const size_t k = (bytes + PIECE - 1) / PIECE;
+    std::vector<size_t> want, count;
+    plan_zones(k, range_lead(k, bytes), (frame_bytes ? frame_bytes : (size_t)mg::FRAME_BYTES) * (size_t)PROBE_GRID, (size_t)zones, want, count);
+    if (piece_bytes) *piece_bytes = PIECE;
+    if (lead_bytes) *lead_bytes = range_lead(k, bytes);
+    for (size_t p = 0; p < k && (int)p < max_pieces; ++p)
+        if (zone_of_piece) zone_of_piece[p] = (int)want[p];
+    return (int)k;
+}
+
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out, mg_obs_alloc_info* info) {
+    return mg_obs_alloc_for(device, bytes, (size_t)mg::FRAME_BYTES, search_budget_bytes, out, info);
+}
+
+int mg_obs_alloc_for(int device, size_t bytes, size_t frame_bytes, size_t search_budget_bytes, void** out, mg_obs_alloc_info* info) {
     mg_obs_alloc_info I = {};
     try {
         if (!out || bytes == 0) {
@@ -677,17 +715,58 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
             plain(1);
             return 0;
         }
-        // choose: round-robin over the groups, largest first, under the strictest cap that still yields k pieces
+        // choose, under the strictest cap that still yields k pieces.  WHICH zone a piece of the range comes from follows the frame walk
+        // (round 6): a raster launch writes at FRONTS one window = RASTER_GRID frames apart (its persistent workgroups stride over the
+        // frames), and what is fast is a split of the concurrently written fronts over the zones (profiles/r02_zones.md).  A uint8 window is
+        // 0.95 pieces, so alternating pieces alternate the fronts -- rounds 2-5 mapped the groups round-robin.  A window of the 16-bit
+        // formats is 1.9 pieces: round-robin puts all five fronts into pieces of the same parity, i.e. into ONE zone at any time
+        // (bfloat16 at 65,536 instances: 0.72 of peak on a balanced buffer against 0.83 on a lucky plain one).  Piece p lies in window
+        // w(p) (by its centre) as that window's j-th piece and comes from zone (w + j) mod 2: neighbouring windows start in different
+        // zones and a window's pieces alternate; for a window of about one piece that is the round-robin order.  (Three groups, when the
+        // two largest cannot supply that: round-robin, which splits the fronts of every format as it is.)
         const size_t cap = usable(half) >= k ? half : (usable(loose_cap) >= k ? loose_cap : k);
         std::sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.pcs.size() > y.pcs.size(); });
+        const size_t lead = range_lead(k, bytes);  // the buffer sits in the MIDDLE of the range (below)
+        const size_t window = (frame_bytes ? frame_bytes : (size_t)mg::FRAME_BYTES) * (size_t)PROBE_GRID;  // (= the rasters' persistent grid, RASTER_GRID)
+        // Two zones are enough (measured: a 3 : 2 split of the fronts is as fast as 2 : 2 : 1); a third group joins the pattern only
+        // when the two largest cannot supply it (a search that found three groups of a third of the pieces each).
+        std::vector<size_t> want, count;
+        size_t zones_used = 0;
+        for (size_t G = 2; G <= std::min<size_t>(groups.size(), 3); ++G) {
+            plan_zones(k, lead, window, G, want, count);
+            zones_used = G;
+            std::vector<size_t> need(count);
+            std::sort(need.begin(), need.end(), [](size_t a, size_t b) { return a > b; });
+            bool fits = true;
+            for (size_t r = 0; r < G; ++r) fits = fits && need[r] <= std::min(groups[r].pcs.size(), cap);
+            if (fits) break;  // (else: one more zone, or -- behind the last try -- the fullest other group stands in below)
+        }
+        // the zone the pattern asks for most often = the largest group (groups are sorted), and so on
+        std::vector<size_t> by_count(zones_used), group_of(zones_used);
+        for (size_t z = 0; z < zones_used; ++z) by_count[z] = z;
+        std::stable_sort(by_count.begin(), by_count.end(), [&](size_t a, size_t b) { return count[a] > count[b]; });
+        for (size_t r = 0; r < zones_used; ++r) group_of[by_count[r]] = r;
+        std::vector<size_t> taken(groups.size(), 0);
         std::vector<std::pair<Piece, int>> order;
-        for (size_t round = 0; round < cap && order.size() < k; ++round)
-            for (auto& g : groups)
-                if (round < g.pcs.size() && order.size() < k) {
-                    g.pcs[round].unmap();
-                    order.push_back({g.pcs[round].piece, g.id});
-                    g.pcs[round].piece.h = nullptr;  // taken
+        for (size_t p = 0; p < k; ++p) {
+            size_t gi = group_of[want[p]];
+            if (taken[gi] >= std::min(groups[gi].pcs.size(), cap)) {  // that group has no piece left (an uneven search result): the fullest other one
+                size_t best = groups.size(), room = 0;
+                for (size_t g2 = 0; g2 < groups.size(); ++g2) {
+                    const size_t left = std::min(groups[g2].pcs.size(), cap) - std::min(taken[g2], std::min(groups[g2].pcs.size(), cap));
+                    if (left > room) {
+                        room = left;
+                        best = g2;
+                    }
                 }
+                if (best == groups.size()) throw std::runtime_error("mg_obs_alloc: internal error (pieces ran out while assembling)");
+                gi = best;
+            }
+            Cand& c = groups[gi].pcs[taken[gi]++];
+            c.unmap();
+            order.push_back({c.piece, groups[gi].id});
+            c.piece.h = nullptr;  // taken
+        }
         for (auto& g : groups) {
             std::vector<Cand> rest;
             for (auto& c : g.pcs)
@@ -720,7 +799,6 @@ int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** ou
         }
         // The buffer sits in the MIDDLE of the range: what the pieces hold beyond `bytes` is split between the first and
         // the last piece, so that a buffer of 1.1 pieces is half in one zone and half in the other, not 10 : 1.
-        const size_t lead = ((k * PIECE - bytes) / 2) & ~(size_t)(2 * MiB - 1);
         m.base = va;
         void* user = (char*)va + lead;
         g_live[user] = m;

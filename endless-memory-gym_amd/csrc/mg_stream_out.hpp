@@ -46,19 +46,6 @@ __device__ __forceinline__ int xcd_grouped_frame(int v, int n) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers inside a struct (HIP's uint4 class members end up in scratch)
 
-// 16-bit element of the half formats: IEEE half, or bfloat16 = the float32 quotient rounded to nearest even
-template <int FMT>
-__device__ __forceinline__ uint16_t to_half16(float q) {
-    if constexpr (FMT == MG_OBS_BF16_CYX) {
-        const uint32_t b = __float_as_uint(q);
-        return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
-    } else {
-        union { _Float16 h; uint16_t u; } c;
-        c.h = (_Float16)q;
-        return c.u;
-    }
-}
-
 // b / 255 as the correctly rounded float32 quotient, without the ~10 instructions of an IEEE division: the rounded
 // reciprocal, one residual, one correction (Markstein); equal to the division for all 256 bytes (tests/test_unit_division.py)
 __device__ __forceinline__ float byte_to_unit(uint8_t b) {
@@ -123,20 +110,61 @@ __device__ __forceinline__ void store_frame(const uint8_t* __restrict__ frame, v
             dst[q] = v;
         }
     } else {
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<uint16_t*>(obs) + (size_t)env * FRAME_BYTES);
-        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 8 halves (two 4-x groups) per 16-B store
+        // The 16-bit formats move half the bytes of float32 behind the same gather and were bound by the vector unit, not by the memory
+        // (round 6, profiles/r06_float_formats.md).  Per element now: one byte read, one conversion, ONE multiply -- byte * (1/255)f rounds to
+        // the same bfloat16 / half as the correctly rounded float32 quotient for all 256 bytes (tests/test_unit_division.py), so the
+        // two-instruction correction of byte_to_unit is the float32 format's alone -- the 16-bit rounding, half a pack; the (row, column
+        // group) of a lane's stores advances by additions (512 groups = 24 rows + 8 groups per round) instead of two divisions per group.
+        u32x4* dst = reinterpret_cast<u32x4*>(static_cast<uint16_t*>(obs) + (size_t)env * FRAME_BYTES);
+        constexpr int PER_ROW = SCREEN / 4, TOTAL = 3 * SCREEN * PER_ROW / 2;  // 21 four-x groups per (c, y) row; 8 halves (two groups) per 16-B store
+        constexpr int ROWS_PER_ROUND = (2 * 256) / PER_ROW, GROUPS_PER_ROUND = (2 * 256) % PER_ROW;  // 24, 8
+        int xg[2], y[2], at[2];  // column group, row, and the LDS offset of the group's first byte: x0 * 252 + y * 3 + c
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int qq = 2 * tid + g, row = qq / PER_ROW;
+            xg[g] = qq - row * PER_ROW;
+            const int c0 = row / SCREEN;
+            y[g] = row - c0 * SCREEN;
+            at[g] = xg[g] * (4 * COL_BYTES) + y[g] * 3 + c0;
+        }
         for (int q = tid; q < TOTAL; q += 256) {
-            union { uint16_t h[8]; uint4 v; } u;
+            uint32_t w[4];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const int qq = 2 * q + g;
-                const int row = qq / PER_ROW, x0 = (qq - row * PER_ROW) * 4;
-                const int c = row / SCREEN, y = row - c * SCREEN;
-                const uint8_t* src = frame + x0 * COL_BYTES + y * 3 + c;
+                const uint8_t* src = frame + at[g];
+                float f[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) u.h[g * 4 + k] = to_half16<FMT>(byte_to_unit(src[k * COL_BYTES]));
+                for (int k = 0; k < 4; ++k) f[k] = (float)src[k * COL_BYTES] * (1.0f / 255.0f);
+                // two elements per conversion (gfx950: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 lo = {f[0], f[1]}, hi = {f[2], f[3]};
+                if constexpr (FMT == MG_OBS_BF16_CYX) {
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    union { bf16x2 v; uint32_t u; } a, b;
+                    a.v = __builtin_convertvector(lo, bf16x2);
+                    b.v = __builtin_convertvector(hi, bf16x2);
+                    w[2 * g] = a.u;
+                    w[2 * g + 1] = b.u;
+                } else {
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    union { f16x2 v; uint32_t u; } a, b;
+                    a.v = __builtin_convertvector(lo, f16x2);
+                    b.v = __builtin_convertvector(hi, f16x2);
+                    w[2 * g] = a.u;
+                    w[2 * g + 1] = b.u;
+                }
+                // the lane's next store, 512 groups on: 24 rows down and 8 groups to the right, by additions only
+                xg[g] += GROUPS_PER_ROUND;
+                const bool carry = xg[g] >= PER_ROW;  // past the row's end: the next row's start
+                xg[g] -= carry ? PER_ROW : 0;
+                y[g] += ROWS_PER_ROUND + (carry ? 1 : 0);
+                const bool wrap = y[g] >= SCREEN;     // past the channel's last row: the next channel
+                y[g] -= wrap ? SCREEN : 0;
+                at[g] += GROUPS_PER_ROUND * (4 * COL_BYTES) + ROWS_PER_ROUND * 3 + (carry ? 3 - PER_ROW * (4 * COL_BYTES) : 0) + (wrap ? 1 - SCREEN * 3 : 0);
             }
-            dst[q] = u.v;
+            u32x4 v;
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+            dst[q] = v;
         }
     }
 }

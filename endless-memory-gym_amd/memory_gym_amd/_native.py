@@ -71,6 +71,9 @@ def _load():
     L.mg_poll_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mg_peek_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mg_obs_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(ObsAllocInfo)]
+    if hasattr(L, "mg_obs_alloc_for"):  # round 6 (absent from the older builds tools/ A/B against through MEMGYM_HIP_LIB)
+        L.mg_obs_alloc_for.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(ObsAllocInfo)]
+        L.mg_obs_plan.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_int]
     L.mg_obs_free.argtypes = [C.c_void_p]
     L.mg_obs_debug_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     if hasattr(L, "mg_single_open"):  # round 5

@@ -85,9 +85,11 @@ class _ObsMemory:
             pass
 
 
-def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
-    """A tensor of `shape` / `dtype` on `device` whose memory comes from mg_obs_alloc (pieces from two HBM zones, see
+def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None, frame_bytes=None):
+    """A tensor of `shape` / `dtype` on `device` whose memory comes from mg_obs_alloc_for (pieces from two HBM zones, see
     include/memgym.h); returns (tensor, info dict).  The memory is released when the last tensor viewing it goes away.
+    `frame_bytes`: bytes of one instance's observation (default: what `shape[1:]` and `dtype` say) -- the pieces are dealt to the zones
+    by the raster launch's windows of 14,336 observations.
     MEMGYM_OBS_SEARCH_MS bounds the search in time (default 1,500 ms), MEMGYM_OBS_SEARCH_GB its transient filler allocations
     (default: half of the free memory, at
     most 128 GiB -- VRAM that other processes on the GPU cannot have for the few milliseconds the search lasts; 0 = do not
@@ -104,7 +106,16 @@ def alloc_obs_buffer(shape, dtype, device, search_budget_bytes=None):
     ptr, info = C.c_void_p(), _native.ObsAllocInfo()
     with torch.cuda.device(device):
         torch.cuda.current_stream().synchronize()
-        _native.check(_native.LIB.mg_obs_alloc(device.index or 0, nbytes, C.c_size_t(search_budget_bytes), C.byref(ptr), C.byref(info)), "mg_obs_alloc")
+        if frame_bytes is None:
+            frame_bytes = int(np.prod(shape[1:])) * elem if len(shape) > 1 else 84 * 84 * 3
+        lab = os.environ.get("MEMGYM_OBS_FRAME_BYTES")  # tools/fmt_ab.sh: the piece order of another format (A/B of the window rule)
+        if lab:
+            frame_bytes = int(lab)
+        if hasattr(_native.LIB, "mg_obs_alloc_for"):
+            _native.check(_native.LIB.mg_obs_alloc_for(device.index or 0, nbytes, C.c_size_t(frame_bytes), C.c_size_t(search_budget_bytes), C.byref(ptr),
+                                                       C.byref(info)), "mg_obs_alloc_for")
+        else:  # (a build of an earlier round, loaded through MEMGYM_HIP_LIB by tools/)
+            _native.check(_native.LIB.mg_obs_alloc(device.index or 0, nbytes, C.c_size_t(search_budget_bytes), C.byref(ptr), C.byref(info)), "mg_obs_alloc")
     # bfloat16 has no array-interface typestr: expose the bytes and view them
     owner = _ObsMemory(ptr.value, (nbytes,), "|u1", {k: getattr(info, k) for k, _ in info._fields_})
     t = torch.as_tensor(owner, device=device).view(dtype).view(tuple(shape))

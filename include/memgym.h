@@ -290,6 +290,17 @@ typedef struct mg_obs_alloc_info {
 } mg_obs_alloc_info;
 #define MG_OBS_SEARCH_DEFAULT ((size_t)-1)
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out_dev, mg_obs_alloc_info* info);
+/* The same for a buffer whose observations are `frame_bytes` each (mg_obs_bytes / instances: 21,168 for MG_OBS_U8_XYC -- what
+ * mg_obs_alloc assumes --, 42,336 for the 16-bit formats, 84,672 for MG_OBS_F32_CYX).  A raster launch writes at fronts that are one
+ * WINDOW = 14,336 observations apart, and the split that is fast is the one of the concurrently written fronts: pieces are dealt to the
+ * zones window by window (neighbouring windows start in different zones, a window's pieces alternate).  For windows of about one
+ * piece that is mg_obs_alloc's alternating order; for the 16-bit formats (1.9 pieces per window) the alternating order leaves all
+ * fronts in one zone at any time (round 6: bfloat16 observations at 65,536 instances 0.72 -> 0.83 of peak). */
+int mg_obs_alloc_for(int device, size_t bytes, size_t frame_bytes, size_t search_budget_bytes, void** out_dev, mg_obs_alloc_info* info);
+/* The order mg_obs_alloc_for would use, without allocating anything (no GPU needed): returns the number of pieces k of a buffer of
+ * `bytes` and, for the first max_pieces of them, the zone (0 .. zones - 1; zones = 2 or 3) each is taken from; *lead_bytes = where in the
+ * assembled range the buffer starts (it sits in the middle of the k pieces).  tests/test_obs_plan.py walks the fronts of a launch over it. */
+int mg_obs_plan(size_t bytes, size_t frame_bytes, int zones, size_t* piece_bytes, size_t* lead_bytes, int* zone_of_piece, int max_pieces);
 int mg_obs_free(void* obs_dev);
 int mg_obs_set_search_ms(double ms);  /* process-wide; >= 0 */
 /* Measurement hook (bench.py's per-box control: roofline.box_probe_GBps).  DESTROYS THE BUFFER'S CONTENTS: the n_frames x 21,168
