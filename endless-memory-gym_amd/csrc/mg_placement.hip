@@ -728,44 +728,59 @@ int mg_obs_alloc_for(int device, size_t bytes, size_t frame_bytes, size_t search
         std::sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.pcs.size() > y.pcs.size(); });
         const size_t lead = range_lead(k, bytes);  // the buffer sits in the MIDDLE of the range (below)
         const size_t window = (frame_bytes ? frame_bytes : (size_t)mg::FRAME_BYTES) * (size_t)PROBE_GRID;  // (= the rasters' persistent grid, RASTER_GRID)
-        // Two zones are enough (measured: a 3 : 2 split of the fronts is as fast as 2 : 2 : 1); a third group joins the pattern only
-        // when the two largest cannot supply it (a search that found three groups of a third of the pieces each).
         std::vector<size_t> want, count;
-        size_t zones_used = 0;
-        for (size_t G = 2; G <= std::min<size_t>(groups.size(), 3); ++G) {
-            plan_zones(k, lead, window, G, want, count);
-            zones_used = G;
-            std::vector<size_t> need(count);
-            std::sort(need.begin(), need.end(), [](size_t a, size_t b) { return a > b; });
-            bool fits = true;
-            for (size_t r = 0; r < G; ++r) fits = fits && need[r] <= std::min(groups[r].pcs.size(), cap);
-            if (fits) break;  // (else: one more zone, or -- behind the last try -- the fullest other group stands in below)
-        }
-        // the zone the pattern asks for most often = the largest group (groups are sorted), and so on
-        std::vector<size_t> by_count(zones_used), group_of(zones_used);
-        for (size_t z = 0; z < zones_used; ++z) by_count[z] = z;
-        std::stable_sort(by_count.begin(), by_count.end(), [&](size_t a, size_t b) { return count[a] > count[b]; });
-        for (size_t r = 0; r < zones_used; ++r) group_of[by_count[r]] = r;
-        std::vector<size_t> taken(groups.size(), 0);
+        plan_zones(k, lead, window, 2, want, count);
+        bool alternating = true;
+        for (size_t p = 0; p < k; ++p) alternating = alternating && want[p] == p % 2;
         std::vector<std::pair<Piece, int>> order;
-        for (size_t p = 0; p < k; ++p) {
-            size_t gi = group_of[want[p]];
-            if (taken[gi] >= std::min(groups[gi].pcs.size(), cap)) {  // that group has no piece left (an uneven search result): the fullest other one
-                size_t best = groups.size(), room = 0;
-                for (size_t g2 = 0; g2 < groups.size(); ++g2) {
-                    const size_t left = std::min(groups[g2].pcs.size(), cap) - std::min(taken[g2], std::min(groups[g2].pcs.size(), cap));
-                    if (left > room) {
-                        room = left;
-                        best = g2;
+        if (alternating) {
+            // windows of about one piece (the uint8 frames every headline number is measured on): exactly the order of rounds 2-5 --
+            // round-robin over ALL groups, largest first
+            for (size_t round = 0; round < cap && order.size() < k; ++round)
+                for (auto& g : groups)
+                    if (round < g.pcs.size() && order.size() < k) {
+                        g.pcs[round].unmap();
+                        order.push_back({g.pcs[round].piece, g.id});
+                        g.pcs[round].piece.h = nullptr;  // taken
                     }
-                }
-                if (best == groups.size()) throw std::runtime_error("mg_obs_alloc: internal error (pieces ran out while assembling)");
-                gi = best;
+        } else {
+            // Two zones are enough (measured: a 3 : 2 split of the fronts is as fast as 2 : 2 : 1); a third group joins the pattern only
+            // when the two largest cannot supply it (a search that found three groups of a third of the pieces each).
+            size_t zones_used = 0;
+            for (size_t G = 2; G <= std::min<size_t>(groups.size(), 3); ++G) {
+                plan_zones(k, lead, window, G, want, count);
+                zones_used = G;
+                std::vector<size_t> need(count);
+                std::sort(need.begin(), need.end(), [](size_t a, size_t b) { return a > b; });
+                bool fits = true;
+                for (size_t r = 0; r < G; ++r) fits = fits && need[r] <= std::min(groups[r].pcs.size(), cap);
+                if (fits) break;  // (else: one more zone, or -- behind the last try -- the fullest other group stands in below)
             }
-            Cand& c = groups[gi].pcs[taken[gi]++];
-            c.unmap();
-            order.push_back({c.piece, groups[gi].id});
-            c.piece.h = nullptr;  // taken
+            // the zone the pattern asks for most often = the largest group (groups are sorted), and so on
+            std::vector<size_t> by_count(zones_used), group_of(zones_used);
+            for (size_t z = 0; z < zones_used; ++z) by_count[z] = z;
+            std::stable_sort(by_count.begin(), by_count.end(), [&](size_t a, size_t b) { return count[a] > count[b]; });
+            for (size_t r = 0; r < zones_used; ++r) group_of[by_count[r]] = r;
+            std::vector<size_t> taken(groups.size(), 0);
+            for (size_t p = 0; p < k; ++p) {
+                size_t gi = group_of[want[p]];
+                if (taken[gi] >= std::min(groups[gi].pcs.size(), cap)) {  // that group has no piece left (an uneven search result): the fullest other one
+                    size_t best = groups.size(), room = 0;
+                    for (size_t g2 = 0; g2 < groups.size(); ++g2) {
+                        const size_t lim = std::min(groups[g2].pcs.size(), cap), left = lim - std::min(taken[g2], lim);
+                        if (left > room) {
+                            room = left;
+                            best = g2;
+                        }
+                    }
+                    if (best == groups.size()) throw std::runtime_error("mg_obs_alloc: internal error (pieces ran out while assembling)");
+                    gi = best;
+                }
+                Cand& c = groups[gi].pcs[taken[gi]++];
+                c.unmap();
+                order.push_back({c.piece, groups[gi].id});
+                c.piece.h = nullptr;  // taken
+            }
         }
         for (auto& g : groups) {
             std::vector<Cand> rest;
