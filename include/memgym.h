@@ -290,7 +290,7 @@ typedef struct mg_obs_alloc_info {
 } mg_obs_alloc_info;
 #define MG_OBS_SEARCH_DEFAULT ((size_t)-1)
 int mg_obs_alloc(int device, size_t bytes, size_t search_budget_bytes, void** out_dev, mg_obs_alloc_info* info);
-/* The same for a buffer whose observations are `frame_bytes` each (mg_obs_bytes / instances: 21,168 for MG_OBS_U8_XYC -- what
+/* The same for a buffer whose observations are `frame_bytes` each (= mg_obs_bytes of the handle: 21,168 for MG_OBS_U8_XYC -- what
  * mg_obs_alloc assumes --, 42,336 for the 16-bit formats, 84,672 for MG_OBS_F32_CYX).  A raster launch writes at fronts that are one
  * WINDOW = 14,336 observations apart, and the split that is fast is the one of the concurrently written fronts: pieces are dealt to the
  * zones window by window (neighbouring windows start in different zones, a window's pieces alternate).  For windows of about one

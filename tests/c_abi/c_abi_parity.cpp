@@ -177,6 +177,41 @@ int main(int argc, char** argv) {
             return 1;
         }
     }
+    {   // (round 6) a float output format into a buffer from mg_obs_alloc_for: two 304-MiB pieces told that an observation is 42,336 bytes,
+        // the n observations laid ACROSS the boundary between the pieces; bfloat16 = the float32 quotient byte / 255 rounded to nearest even
+        const size_t fb = frame * 2, piece = (size_t)304 << 20, bytes = 2 * piece;
+        int zones[4] = {-1, -1, -1, -1};
+        size_t pb = 0, lead = 0;
+        if (mg_obs_plan(bytes, fb, 2, &pb, &lead, zones, 4) != 2 || pb != piece || lead != 0 || zones[0] == zones[1]) {
+            printf("mg_obs_plan: two pieces of one window must come from different zones (%d %d, piece %zu, lead %zu)\n", zones[0], zones[1], pb, lead);
+            return 1;
+        }
+        void* big = nullptr;
+        mg_obs_alloc_info ai;
+        MG_OK(mg_obs_alloc_for(0, bytes, fb, MG_OBS_SEARCH_DEFAULT, &big, &ai));
+        uint8_t* at = static_cast<uint8_t*>(big) + piece - (size_t)(n / 2) * fb;
+        MG_OK(mg_set_obs_format(env, MG_OBS_BF16_CYX));
+        if (mg_obs_bytes(env) != fb) { printf("mg_obs_bytes: %zu for a bfloat16 observation\n", mg_obs_bytes(env)); return 1; }
+        MG_OK(mg_render(env, at, stream));
+        std::vector<uint16_t> got((size_t)frame * n);
+        HIP_OK(hipMemcpyAsync(got.data(), at, fb * n, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c)
+                for (int y = 0; y < 84; ++y)
+                    for (int x = 0; x < 84; ++x) {
+                        const float q = (float)want[frame * i + ((size_t)x * 84 + y) * 3 + c] / 255.0f;  // the oracle's frame is [x][y][c]
+                        uint32_t b;
+                        memcpy(&b, &q, 4);
+                        const uint16_t w = (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+                        if (got[frame * i + ((size_t)c * 84 + y) * 84 + x] != w) {
+                            printf("MISMATCH in the bfloat16 observation of instance %d at (c %d, y %d, x %d)\n", i, c, y, x);
+                            return 1;
+                        }
+                    }
+        MG_OK(mg_set_obs_format(env, MG_OBS_U8_XYC));
+        MG_OK(mg_obs_free(big));
+    }
     printf("OK %s: %d instances x %d steps, %ld episodes finished, bit-exact through the C ABI\n", env_id, n, steps, episodes);
     (void)hipFree(rew64_d);
     (void)hipFree(cap_d);
