@@ -21,4 +21,10 @@ inline int lab_int(const char* name, int dflt) {
     const char* e = lab_env(name);
     return e ? atoi(e) : dflt;
 }
+// MEMGYM_SPARSE_RASTER=0 (lab build): masked resets draw their frames with the dense persistent launch of rounds 1-5, and a
+// gymnasium-convention step (mg_info_buffers.final_obs_dev) re-draws the terminal frames instead of copying them (A/B, bit-exactness tests)
+inline bool sparse_masked_raster() {
+    static const bool on = lab_int("MEMGYM_SPARSE_RASTER", 1) != 0;
+    return on;
+}
 }  // namespace mg

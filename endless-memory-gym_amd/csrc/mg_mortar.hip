@@ -895,7 +895,10 @@ class MortarFamily : public Family {
             hipLaunchKernelGGL(mortar_reset_kernel<true>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), seeds, mask, gt_dim() ? gt : nullptr);
         else
             hipLaunchKernelGGL(mortar_reset_kernel<false>, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, n_, io(), seeds, mask, gt_dim() ? gt : nullptr);
-        raster(obs, s);
+        if (mask && sparse_masked_raster()) {  // few frames of many: by the mask, not by a walk over every descriptor (mg_raster_v1.hpp)
+            launch_raster_sparse<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, mask);
+            MG_HIP(hipGetLastError());
+        } else raster(obs, s);
     }
 
     void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,

@@ -2406,7 +2406,11 @@ class MysteryFamily : public Family {
             if (ps) hipLaunchKernelGGL(mystery_reset_kernel<true>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
             else hipLaunchKernelGGL(mystery_reset_kernel<false>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), seeds, mask, nullptr, lpw());
         }
-        raster(obs, s);
+        if (mask && sparse_masked_raster()) {  // few frames of many: by the mask, not by a walk over every descriptor (mg_raster_v1.hpp)
+            if (big_sprites_) launch_raster_sparse<MysteryBigComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, mask);
+            else launch_raster_sparse<MysteryComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, mask);
+            MG_HIP(hipGetLastError());
+        } else raster(obs, s);
     }
 
     void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,

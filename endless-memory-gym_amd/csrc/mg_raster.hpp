@@ -20,6 +20,7 @@
 //   zero_mask / hole_fetch8 / hole_apply8 / hole_mask   the lit discs as an 84x84 bit mask
 //   darken2 / darken4                SDL's surface-alpha rule d - floor(d*alpha/255), two bytes per multiply
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -345,6 +346,41 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     }
 }
 
+// A launch that draws FEW of the n frames (a masked reset; round 6, see mg_raster_v1.hpp: raster_sparse_kernel): a workgroup owns
+// SPARSE_CHUNK consecutive instances, reads their descriptors (and the caller's mask) with one vector load and draws the ones a ballot names.
+constexpr int SPARSE_CHUNK = 32;
+template <class Composer, int FMT>
+__global__ __launch_bounds__(256) void raster_sparse_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
+                                                          void* __restrict__ obs, int n, const uint8_t* __restrict__ only) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = as_const(A.tables);
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const cptr<typename Composer::Desc> cdescs = as_const(descs);
+    Composer::recycle(R);  // scratch state compose() expects (e.g. a zeroed hole mask); published by the barriers below
+    __syncthreads();
+    for (int base = blockIdx.x * SPARSE_CHUNK; base < n; base += gridDim.x * SPARSE_CHUNK) {
+        const int e = base + (tid & (SPARSE_CHUNK - 1));  // (every wave looks at the same SPARSE_CHUNK instances: the same list in all four)
+        const bool want = e < n && !Composer::skip(cdescs + e) && (!only || only[e]);
+        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__ballot(want));
+        while (m) {
+            const int env = base + __builtin_ctz(m);
+            m &= m - 1;
+            typename Composer::Pre P;
+            Composer::prefetch(cdescs + env, R, P);
+            Composer::compose(cdescs + env, P, R);
+            __syncthreads();
+            Composer::recycle(R);
+            store_frame<FMT, false, true>(smem, obs, env, tid);
+            __syncthreads();  // the LDS frame is reused by the next iteration
+        }
+    }
+}
+
 // Workgroups of a raster launch over n frames (MEMGYM_RASTER_GRID overrides: tuning experiments).  A workgroup that draws
 // several frames has each next frame's loads queued behind its own stores (gfx9 counts both in vmcnt), a launch of one
 // workgroup per frame pays ~14,000 wave launches: the optimum lies in between and moves with the launch size.  Round 3,
@@ -398,6 +434,20 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC, true>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC, false>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+}
+
+template <class Composer>
+inline void launch_raster_sparse(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s,
+                                 const uint8_t* only) {
+    const int grid = std::min((n + SPARSE_CHUNK - 1) / SPARSE_CHUNK, 8192);
+    if (fmt == MG_OBS_F32_CYX)
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else if (fmt == MG_OBS_BF16_CYX)
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else if (fmt == MG_OBS_F16_CYX)
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
 }
 
 }  // namespace mg

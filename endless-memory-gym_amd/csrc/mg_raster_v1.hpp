@@ -25,6 +25,7 @@
 // (The spotlight family's layers live in generation 2, mg_raster.hpp; the hole-mask words stay part of this
 // skeleton's LDS request because its occupancy and pacing were tuned with them: profiles/r01c_raster_generations.md.)
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -189,6 +190,37 @@ __global__ __launch_bounds__(256, 7) void raster_kernel(const typename Composer:
     }
 }
 
+// The same for a launch that draws FEW of the n frames (a masked reset; round 6): the persistent loop above has every workgroup look at
+// its n / grid descriptors one after the other -- ~0.7 us each, 28 us for the ~1,400 frames a gymnasium-convention step of 65,536 instances
+// resets.  Here a workgroup owns SPARSE_CHUNK consecutive instances, reads their descriptors (and the caller's mask) with one vector load
+// and draws the ones a ballot names.  (A kernel of its own: the dense launches are the measured ones and stay as they are.)
+constexpr int SPARSE_CHUNK = 32;
+template <class Composer, int FMT>
+__global__ __launch_bounds__(256) void raster_sparse_kernel(const typename Composer::Desc* __restrict__ descs, RasterAtlas A,
+                                                          void* __restrict__ obs, int n, const uint8_t* __restrict__ only) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RasterCtx R;
+    R.frame = smem;
+    R.mask = reinterpret_cast<uint32_t*>(smem + FRAME_BYTES);
+    R.A = A;
+    R.T = A.tables;
+    R.tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    for (int base = blockIdx.x * SPARSE_CHUNK; base < n; base += gridDim.x * SPARSE_CHUNK) {
+        const int e = base + (tid & (SPARSE_CHUNK - 1));  // (every wave looks at the same SPARSE_CHUNK instances: the same list in all four)
+        const bool want = e < n && !Composer::skip(descs + e) && (!only || only[e]);
+        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__ballot(want));
+        while (m) {
+            const int env = base + __builtin_ctz(m);
+            m &= m - 1;
+            Composer::compose(descs + env, R);
+            __syncthreads();
+            store_frame<FMT, false>(smem, obs, env, tid);
+            __syncthreads();  // the LDS frame is reused by the next iteration
+        }
+    }
+}
+
 // Workgroups of a raster launch over n frames (MEMGYM_RASTER_GRID overrides: tuning experiments)
 inline int raster_grid(int n) {
     static const int forced = [] {
@@ -219,6 +251,20 @@ inline void launch_raster(const typename Composer::Desc* descs, const RasterAtla
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
     else
         hipLaunchKernelGGL((raster_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), lds, s, descs, atlas, obs, n, only);
+}
+
+template <class Composer>
+inline void launch_raster_sparse(const typename Composer::Desc* descs, const RasterAtlas& atlas, void* obs, int fmt, int n, hipStream_t s,
+                                 const uint8_t* only) {
+    const int grid = std::min((n + SPARSE_CHUNK - 1) / SPARSE_CHUNK, 8192);
+    if (fmt == MG_OBS_F32_CYX)
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else if (fmt == MG_OBS_BF16_CYX)
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else if (fmt == MG_OBS_F16_CYX)
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
+    else
+        hipLaunchKernelGGL((raster_sparse_kernel<Composer, MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, descs, atlas, obs, n, only);
 }
 
 }  // namespace v1

@@ -1702,7 +1702,11 @@ class SpotFamily : public Family {
             if (per_set()) hipLaunchKernelGGL((spot_reset_kernel<false, true>), rg, dim3(256), 0, s, P_, io(), seeds, mask, gt);
             else hipLaunchKernelGGL((spot_reset_kernel<false, false>), rg, dim3(256), 0, s, P_, io(), seeds, mask, gt);
         }
-        raster(obs, s);
+        if (mask && sparse_masked_raster()) {  // few frames of many: by the mask, not by a walk over every descriptor (mg_raster.hpp)
+            if (P_.ordered_holes) launch_raster_sparse<SpotBorderComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, mask);
+            else launch_raster_sparse<SpotComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, mask);
+            MG_HIP(hipGetLastError());
+        } else raster(obs, s);
     }
 
     void step(const int32_t* actions, void* obs, float* reward, uint8_t* done, float* gt, const mg_info_buffers* info,

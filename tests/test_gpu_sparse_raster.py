@@ -1,0 +1,28 @@
+"""GPU (-m gpu): frames of a masked reset drawn by the mask (round 6: raster_sparse_kernel, a workgroup per 32 instances) and terminal
+observations copied instead of drawn again (mg_step with final_obs_dev) must be, byte for byte, what the dense persistent launches of
+rounds 1-5 deliver: six env ids at sizes that are no multiple of anything, the gymnasium vector convention for 25-30 steps and masked
+resets of 1 %, 50 % and 99.9 % of the instances, in two fresh processes of the lab build (MEMGYM_SPARSE_RASTER=0 / default).  Against
+the ORACLE the new path runs in tests/test_gpu_vector_api.py (every terminal frame of seven ids) and wherever a test resets with a mask."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LAB_LIB = os.path.join(os.path.dirname(HERE), "endless-memory-gym_amd", "lib", "lab", "libmemgym_hip_lab.so")
+
+
+def digests(sparse):
+    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB, MEMGYM_SPARSE_RASTER="1" if sparse else "0")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "sparse_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok: all cases" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    return [ln for ln in r.stdout.splitlines() if ln.startswith("digest ")]
+
+
+def test_sparse_launches_equal_the_dense_ones():
+    dense, sparse = digests(False), digests(True)
+    assert len(dense) == 6 and dense == sparse, "\n".join(a + "\n" + b for a, b in zip(dense, sparse) if a != b)
+    assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in dense)  # (episodes did finish in every case)
