@@ -261,19 +261,33 @@ int mg_render(mg_env* env, void* obs_dev, void* stream) {
 }
 
 // Rows of the observation buffer whose flag is set, copied to the same rows of another buffer (mg_step with mg_info_buffers.final_obs_dev:
-// after a step without auto-reset the rows of the finished instances ARE the terminal observations).  A workgroup looks at 32 flags with one
-// load and copies the rows a ballot names; rows are whole 16-byte vectors in every output format.
+// after a step without auto-reset the rows of the finished instances ARE the terminal observations).  A workgroup looks at 16 flags with one
+// load and copies the rows a ballot names, six 16-byte vectors per lane in flight (a uint8 row is 1,323 vectors: one round); rows are whole
+// vectors in every output format.
 typedef uint32_t row_vec16 __attribute__((ext_vector_type(4)));
+constexpr int COPY_CHUNK = 16;
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ flags, const row_vec16* __restrict__ src, row_vec16* __restrict__ dst,
                                                       int n, int vec_per_row) {
     const int tid = threadIdx.x;
-    for (int base = blockIdx.x * 32; base < n; base += gridDim.x * 32) {
-        const int e = base + (tid & 31);
-        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__ballot(e < n && flags[e] != 0));
+    for (int base = blockIdx.x * COPY_CHUNK; base < n; base += gridDim.x * COPY_CHUNK) {
+        const int e = base + (tid & (COPY_CHUNK - 1));
+        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__ballot(e < n && flags[e] != 0)) & ((1u << COPY_CHUNK) - 1u);
         while (m) {
             const size_t row = (size_t)(base + __builtin_ctz(m)) * (size_t)vec_per_row;
             m &= m - 1;
-            for (int q = tid; q < vec_per_row; q += 256) dst[row + q] = src[row + q];
+            for (int q0 = 0; q0 < vec_per_row; q0 += 6 * 256) {
+                row_vec16 v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int q = q0 + tid + 256 * k;
+                    if (q < vec_per_row) v[k] = src[row + q];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int q = q0 + tid + 256 * k;
+                    if (q < vec_per_row) dst[row + q] = v[k];
+                }
+            }
         }
     }
 }
@@ -331,7 +345,7 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
             f->step(actions_dev, obs_dev, reward_dev, done_dev, gt_dev, &ib, 0, st);
             if (mg::sparse_masked_raster()) {  // the rows are there: copied, not drawn again (round 6)
                 const int n = env->num_envs, vec_per_row = (int)(mg_obs_bytes(env) / 16);
-                hipLaunchKernelGGL(copy_rows_kernel, dim3(std::min((n + 31) / 32, 8192)), dim3(256), 0, st, done_dev, (const row_vec16*)obs_dev,
+                hipLaunchKernelGGL(copy_rows_kernel, dim3(std::min((n + COPY_CHUNK - 1) / COPY_CHUNK, 16384)), dim3(256), 0, st, done_dev, (const row_vec16*)obs_dev,
                                    (row_vec16*)ib.final_obs_dev, n, vec_per_row);
                 MG_HIP(hipGetLastError());
             } else f->raster_only(ib.final_obs_dev, done_dev, st);
