@@ -1552,6 +1552,55 @@ __global__ __launch_bounds__(256) void emp_enqueue_kernel(int n, MysteryIO io, c
     else io.desc[i].valid = 0;
 }
 
+// reset(seed=None, mask) the way the auto-reset STEP resets (round 6): an instance whose next episode's first segment exists already
+// (EMP_PRE, nothing owed) is reset right here from that record -- the same stores as emp_step_b<true>'s own reset: the record becomes segment
+// 0, the instance's stream becomes the record's, two segments are owed -- and everybody else becomes a queue entry (served lazily: one
+// segment, two owed).  A step in the gymnasium vector convention (mg_step with final_obs_dev) is a step without auto-reset plus this masked
+// reset: through emp_enqueue_kernel every finishing instance was three cooperative paths of the queue server, 92 us per step at 32,768.
+__global__ __launch_bounds__(256) void emp_masked_reset_kernel(MysteryParams P, MysteryIO io, const uint8_t* mask, float* gt) {
+    typedef uint32_t q4 __attribute__((ext_vector_type(4)));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    if (!mask[i]) {
+        io.desc[i].valid = 0;
+        return;
+    }
+    MysteryCore s = load_core(&io.core[i]);
+    if (!(P.pre && EMP_PRE(s) && EMP_OWED(s) == 0)) {
+        queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
+        return;
+    }
+    const q4* aq = reinterpret_cast<const q4*>(io.aux + (size_t)i * AUX_WORDS);
+    const q4 a0 = aq[0], a1 = aq[1], a2 = aq[2], a3 = aq[3], a4 = aq[4];  // the record generated ahead of time (AUX_WORDS layout above)
+    emp_pre_reset(s);
+    SegRec R, none;
+    none.seg = -1;
+    R.w[0] = a0.x | 0x4000u;  // the first node of the path shall not yield any reward
+    R.w[1] = a0.y; R.w[2] = a0.z; R.w[3] = a0.w;
+    R.w[4] = a1.x; R.w[5] = a1.y; R.w[6] = a1.z; R.w[7] = a1.w;
+    R.w[8] = a2.x; R.w[9] = a2.y; R.w[10] = a2.z; R.w[11] = a2.w;
+    R.w[12] = a3.x;
+    R.seg = 0;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(seg_ptr(io, i, 0));
+#pragma unroll
+    for (int j = 0; j < SEG_STRIDE / 4; ++j) dst[j] = R.w[j];
+    io.rng.s_lo[i] = (uint64_t)a4.x | ((uint64_t)a4.y << 32);
+    io.rng.s_hi[i] = (uint64_t)a4.z | ((uint64_t)a4.w << 32);
+    io.rng.buf[i] = (uint64_t)a3.y | ((uint64_t)(a3.z & 1u) << 32);
+    s.num_seg = 1;
+    s.have_start = 1;
+    s.end_y = (int8_t)((a3.z >> 8) & 0xFFu);
+    EMP_OWED(s) = 2;
+    if (LAB_BUILD && io.stats) atomicAdd(io.stats + 2, 1ull);  // mg_debug_counter "emp_own_resets" (lab build: tests)
+    emp_post_reset_state(P, io, i, s, gt ? gt + 3 * i : nullptr, R);
+    MysteryDesc d;
+    emp_fill_desc<false>(P, io, i, s, d, s.ax / P.tile, R, none);
+    d.cross_on = 0;
+    if (P.show_stamina) d.stamina_red = 0;
+    io.core[i] = s;
+    io.desc[i] = d;
+}
+
 // One queue entry, served by one converged wave whose lane 0 plays the instance's lane: "append a segment, finish the step"
 // and / or "reset" (three segments), state, stream and frame descriptor written back.
 __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int entry, const int64_t* seeds, float* reward_out,
@@ -2380,11 +2429,20 @@ class MysteryFamily : public Family {
         if (P_.endless) {
             mg_info_buffers none;
             memset(&none, 0, sizeof(none));
-            P_.lazy = 0;  // an explicit reset generates all three segments (whatever an old episode is owed comes first)
-            P_.pre = 0;
+            // a masked reset(seed=None) of a handle whose steps run the fused arrangement: reset like the auto-reset step resets (lazy
+            // segments, records ahead of time: emp_masked_reset_kernel); lab MEMGYM_EMP_MASKED_FAST=0: through the queue server like any other
+            static const bool fast_wanted = lab_int("MEMGYM_EMP_MASKED_FAST", 1) != 0;
+            const bool fast = fast_wanted && mask && !seeds && !ps && lazy_wanted_ && fuse_serve() && obs_format == MG_OBS_U8_XYC && !big_sprites_;
+            P_.lazy = fast ? 1 : 0;  // (otherwise an explicit reset generates all three segments; whatever an old episode is owed comes first)
+            P_.pre = (fast && pre_wanted_) ? 1 : 0;
             P_.lazy_append = 0;
+            if (fast) owed_possible_ = true;
             upload_sets(s);
-            if (mask) {
+            if (fast) {
+                hipLaunchKernelGGL(emp_masked_reset_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, P_, io(), mask, gt);
+                hipLaunchKernelGGL(emp_serve_kernel<false>, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,
+                                   (uint8_t*)nullptr, gt, none, 0);
+            } else if (mask) {
                 hipLaunchKernelGGL(emp_enqueue_kernel, dim3((n_ + 255) / 256), dim3(256), 0, s, n_, io(), mask);
                 if (ps)
                     hipLaunchKernelGGL(emp_serve_kernel<true>, dim3(servers(false)), dim3(256), WS_BYTES, s, P_, io(), seeds, 0, (float*)nullptr,

@@ -42,6 +42,9 @@ def upd(h, t):
     h.update(np.array([int((per_row * w2).sum()), int(per_row.sum()), int(v.sum())], dtype=np.int64).tobytes())
 
 
+if os.environ.get("MEMGYM_SPARSE_CASES") == "emp_big":  # test_emp_masked_resets_...: the arrangement of launches above ~20,000 instances
+    CASES = [("Endless-MysteryPath-v0", 32768, 60, "u8_xyc", None)]
+
 for env_id, n, steps, fmt, options in CASES:
     h = hashlib.sha256()
     vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
@@ -61,6 +64,7 @@ for env_id, n, steps, fmt, options in CASES:
         finished += int(d.sum())
         if d.any():
             upd(h, vis(infos["final_observation"])[d])
+    own = envs.env.debug_counter("emp_own_resets") if env_id == "Endless-MysteryPath-v0" else 0
     for i in (0, n // 2, n - 1):
         h.update(np.asarray(envs.env.rng_words(i)).tobytes())
     envs.close()
@@ -76,4 +80,5 @@ for env_id, n, steps, fmt, options in CASES:
     env.check_errors()
     env.close()
     print("digest %s %d %s %s finished=%d" % (env_id, n, fmt, h.hexdigest(), finished), flush=True)
+    print("own_resets %d" % own, flush=True)
 print("ok: all cases")

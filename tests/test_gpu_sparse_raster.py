@@ -15,10 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LAB_LIB = os.path.join(os.path.dirname(HERE), "endless-memory-gym_amd", "lib", "lab", "libmemgym_hip_lab.so")
 
 
-def digests(sparse):
-    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB, MEMGYM_SPARSE_RASTER="1" if sparse else "0")
+def digests(sparse, **more):
+    env = dict(os.environ, MEMGYM_HIP_LIB=LAB_LIB, MEMGYM_SPARSE_RASTER="1" if sparse else "0", **more)
     r = subprocess.run([sys.executable, os.path.join(HERE, "sparse_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok: all cases" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    if more:
+        return [ln for ln in r.stdout.splitlines() if ln.startswith(("digest ", "own_resets "))]
     return [ln for ln in r.stdout.splitlines() if ln.startswith("digest ")]
 
 
@@ -26,3 +28,15 @@ def test_sparse_launches_equal_the_dense_ones():
     dense, sparse = digests(False), digests(True)
     assert len(dense) == 6 and dense == sparse, "\n".join(a + "\n" + b for a, b in zip(dense, sparse) if a != b)
     assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in dense)  # (episodes did finish in every case)
+
+
+def test_emp_masked_resets_like_the_auto_reset_step():
+    """Endless-MysteryPath-v0, 32,768 instances in the gymnasium vector convention: a masked reset(seed=None) resets an instance from the
+    record generated ahead of time, like the auto-reset step (emp_masked_reset_kernel), or queues it for ONE lazily served segment --
+    everything the caller sees (observations, terminal observations, rewards, dones, RNG words) equal to the run in which every masked
+    instance is three cooperative paths of the queue server (lab MEMGYM_EMP_MASKED_FAST=0), and the fast path did reset instances itself."""
+    slow = digests(True, MEMGYM_SPARSE_CASES="emp_big", MEMGYM_EMP_MASKED_FAST="0")
+    fast = digests(True, MEMGYM_SPARSE_CASES="emp_big", MEMGYM_EMP_MASKED_FAST="1")
+    assert slow[0] == fast[0] and slow[0].startswith("digest Endless-MysteryPath-v0 32768"), slow[0] + "\n" + fast[0]
+    assert int(fast[0].rsplit("=", 1)[1]) > 32768  # (finished episodes: several per instance)
+    assert int(slow[1].split()[1]) == 0 and int(fast[1].split()[1]) > 1000, (slow[1], fast[1])
