@@ -203,8 +203,15 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
         from memory_gym_amd.vec_env import alloc_obs_buffer
         big, _ = alloc_obs_buffer((n_local + pad, 84, 84, 3), torch.uint8, dev)
         own_buffer = big[:n_local]
-    env = memory_gym_amd.make(env_id, num_envs=n_local, device=dev.index, obs_format=obs_format,
-                              obs_buffer=peer.local if peer else own_buffer)
+    venv = None
+    if policy == "vector_api":  # the gymnasium-0.29 vector convention over the same handle (terminal observations + same-call resets)
+        from memory_gym_amd.vector import GymnasiumVectorEnv
+        assert peer is None and own_buffer is None and gather is None
+        venv = GymnasiumVectorEnv(env_id, n_local, device=dev.index, obs_format=obs_format)
+        env, policy = venv.env, None
+    else:
+        env = memory_gym_amd.make(env_id, num_envs=n_local, device=dev.index, obs_format=obs_format,
+                                  obs_buffer=peer.local if peer else own_buffer)
     # instance i (global index) is seeded i whatever the world size -> results are world-size invariant
     env.reset(seed=shard_seeds(n_total, rank, world, base_seed=0, device=dev))
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -234,6 +241,9 @@ def run_workload(env_id, n_local, K, W, settle, world, rank, dev, obs_format="u8
             return
         if gatherer is not None:
             gatherer.step(acts[k % n_act_bufs])
+            return
+        if venv is not None:
+            venv.step(acts[k % n_act_bufs])
             return
         env.step(acts[k % n_act_bufs])
         if peer is not None:  # the frames are already in rank 0's memory; the gather of the packed rewards / dones orders the streams
@@ -464,13 +474,14 @@ def other_workloads(primary, dev, settle):
     """Informational entries measured like the secondary workloads, without the PMC child passes (profiles/ holds those):
     the three env ids that are in no BASELINE config; Endless-MysteryPath-v0 once more under an agent that FOLLOWS its path (round 6:
     the regime a trained agent puts the library in -- segments appended every few steps, hardly a reset -- next to the random-action
-    one, so that a store flavour or a generator is judged on both); and the headline workload in the two fused float formats
+    one, so that a store flavour or a generator is judged on both); the headline workload in the two fused float formats
     (value / 255 in CHW order written by the raster's stream-out instead of a second pass), priced at the bytes they
-    write per instance."""
+    write per instance; and the headline workload behind the gymnasium vector front end (terminal observations)."""
     out = []
     plan = [(env_id, "u8_xyc", None) for env_id in ("SearingSpotlights-v0", "Endless-MysteryPath-v0", "MysteryPath-Grid-v0") if env_id != primary]
     plan.append(("Endless-MysteryPath-v0", "u8_xyc", "follower:0.02"))
     plan += [("MortarMayhem-Grid-v0", "f32_chw", None), ("MortarMayhem-Grid-v0", "bf16_chw", None)]
+    plan.append(("MortarMayhem-Grid-v0", "u8_xyc", "vector_api"))  # (round 6) the same handle behind GymnasiumVectorEnv.step
     for env_id, fmt, policy in plan:
         r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev, obs_format=fmt, policy=policy)
         algo = FRAME * OBS_ELEM[fmt] + DESC_BYTES[env_id]  # algorithmic bytes of the dominant launch per instance-step (frame + descriptor)
@@ -487,7 +498,14 @@ def other_workloads(primary, dev, settle):
              "policy": policy or "uniform random", "value": r["value"], "unit": "env steps/s", "ms_per_step": r["ms_per_step"],
              "raster_avg_ms": r["raster_avg_ms"], "logic_avg_ms": r["logic_avg_ms"], "value_windows": r["value_windows"],
              "obs_placement_zones": (r["obs_placement"] or {}).get("zones"), "roofline": rl}
-        if policy:
+        if policy == "vector_api":
+            e["policy"] = "uniform random"
+            e["api"] = "memory_gym_amd.vector.GymnasiumVectorEnv.step"
+            e["workload"] += ", gymnasium vector convention"
+            e["api_note"] = ("terminal observations kept in infos['final_observation'] (copied out of the observation buffer), finished instances "
+                             "reset in the same call (masked reset, frames drawn by the mask); the dominant launch is the step's, the rest of "
+                             "ms_per_step is what the convention adds")
+        elif policy:
             e["policy_note"] = ("actions from the previous step's info['ground_truth'] (one-hot right / up / down), a random one with probability %s; "
                                 "the policy's three small torch kernels per step run on the launch stream inside the timed region" % policy.split(":")[1])
         out.append(e)
