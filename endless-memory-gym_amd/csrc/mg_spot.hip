@@ -1419,10 +1419,10 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
     if (service && (int)blockIdx.x * batch >= count) return;
     Composer::recycle(R);
     __syncthreads();
-    auto draw = [&](int env) {
+    auto draw = [&](cptr<SpotDesc> from, int env) {
         typename Composer::Pre Pq;
-        Composer::prefetch(cdescs + env, R, Pq);
-        Composer::compose(cdescs + env, Pq, R);
+        Composer::prefetch(from + env, R, Pq);
+        Composer::compose(from + env, Pq, R);
         __syncthreads();
         Composer::recycle(R);
         store_frame<MG_OBS_U8_XYC, NT, true>(smem, obs, env, tid);
@@ -1458,14 +1458,24 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
                 }
             }
             // The descriptors just stored are read back by THIS workgroup's composers through the scalar cache: the stores have to
-            // have reached the L2 (workgroup-scope release = s_waitcnt vmcnt(0); the vector L1 writes through) and the scalar cache
+            // have reached the L2 (s_waitcnt vmcnt(0); the vector L1 writes through) and the scalar cache
             // must not answer from an older copy (s_dcache_inv).  NOT __threadfence(): at agent scope that is buffer_wbl2 +
             // buffer_inv -- a write-back of the whole L2, which holds the launch's observation stream (round 4: the cost of the
             // launch grew with the number of workgroups that served resets, profiles/r04_spot_serve.md).
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // Round 6 (a race the round-4 form had, found by tools/vector_soak.py: one reset frame in ~10^7 drawn from the OLD descriptor or
+            // from a half-written one): the workgroup-scope release fence this stood on compiles to s_waitcnt lgkmcnt(0) only -- outside
+            // tgsplit mode the vector L1 is coherent among a workgroup's waves, so LLVM's memory model leaves vmcnt out -- but the readers here
+            // are SCALAR loads, which bypass the vector L1 and could reach the L2 before the stores did.  So: wait for the stores' acknowledgement
+            // by hand, and for the invalidation (an SMEM operation, asynchronous like any other) before the first scalar load is issued;
+            // the descriptor pointer passes through an opaque copy behind it, so that no load of the (constant-address-space, "invariant")
+            // descriptor can be scheduled above the invalidation.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             __builtin_amdgcn_s_dcache_inv();
-            for (int k = 0; k < batch && base + k < count; ++k) draw(io.queue[base + k]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cptr<SpotDesc> fresh = cdescs;
+            asm volatile("" : "+s"(fresh));
+            for (int k = 0; k < batch && base + k < count; ++k) draw(fresh, io.queue[base + k]);
         }
         const int busy = (count + batch - 1) / batch < SPOT_SVC_WGS ? (count + batch - 1) / batch : SPOT_SVC_WGS;
         if (tid == 0 && atomicAdd(&a.io.qctr[SQ_LEFT], 1) == busy - 1) {  // last service workgroup out
@@ -1477,7 +1487,7 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
     const int stride = (int)gridDim.x - SPOT_SVC_WGS;
     for (int env = (int)blockIdx.x - SPOT_SVC_WGS; env < n; env += stride) {
         if (cdescs[env].valid != 1u) continue;  // masked, or drawn by the workgroup that serves its reset
-        draw(env);
+        draw(cdescs, env);
     }
 }
 

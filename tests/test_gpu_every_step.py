@@ -1,0 +1,50 @@
+"""GPU (-m gpu): every frame of every instance after EVERY step, for thousands of steps -- by letting two independent launch arrangements
+of the library check each other on the device (a comparison costs 0.1 ms; against the CPU oracle the full-batch tests can afford all frames
+only every 20-32 steps).  The gymnasium vector convention (step without auto-reset, terminal rows copied, masked reset, frames drawn by the
+mask: tests/test_gpu_vector_api.py pins it to the oracle) must deliver the same observations, rewards and dones as the same-step auto-reset
+arrangement bench.py measures (pinned to the oracle by tests/test_gpu_full_batch.py).
+
+Round 6: this is how a race of the round-4 fused spotlight launch was found (tools/vector_soak.py) -- a reset frame drawn from the old or a
+half-written descriptor, one frame in ~10^7, which frames compared every 20th step of a 200-step run meet with a probability of a few
+per cent per run (csrc/mg_spot.hip spot_raster_serve_kernel: scalar loads behind vector stores of the same workgroup)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("SearingSpotlights-v0", 16385, 3000),          # resets served inside the raster launch (the arrangement that raced)
+         ("Endless-SearingSpotlights-v0", 20001, 1500),  # ... the endless variant takes that arrangement above 16,384 instances
+         ("Endless-SearingSpotlights-v0", 16384, 600),   # C4's own: resets in the step kernel
+         ("MortarMayhem-Grid-v0", 65536, 400),           # one launch per step (claim words)
+         ("Endless-MysteryPath-v0", 32768, 400),         # lazy segments, records ahead of time
+         ("MysteryPath-v0", 32768, 560)]                 # (episodes of 512 steps: every instance is truncated in the same step once)
+
+
+@pytest.mark.parametrize("env_id,n,steps", CASES)
+def test_two_arrangements_agree_after_every_step(env_id, n, steps):
+    import memory_gym_amd
+    import torch
+    from memory_gym_amd.vector import GymnasiumVectorEnv
+
+    venv = GymnasiumVectorEnv(env_id, n, device=0)
+    fused = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    adim = fused.action_dim
+    n_act = 4 if adim == 1 else 3
+    o1, _ = venv.reset(seed=5)
+    o2, _ = fused.reset(seed=5)
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    finished = 0
+    for t in range(steps):
+        a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+        o1, r1, d1, _, _ = venv.step(a)
+        o2, r2, d2, _, _ = fused.step(a)
+        if not torch.equal(o1, o2):
+            bad = (o1 != o2).flatten(1).any(1).nonzero().flatten()[:4].tolist()
+            pytest.fail("%s: observations of instances %s differ after step %d (done: %s)" % (env_id, bad, t, d1[bad].tolist()))
+        assert torch.equal(r1, r2) and torch.equal(d1, d2), "%s step %d" % (env_id, t)
+        finished += int(d1.sum())
+    assert finished > 0
+    venv.env.check_errors()
+    fused.check_errors()
+    venv.close()
+    fused.close()
