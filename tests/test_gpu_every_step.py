@@ -48,3 +48,40 @@ def test_two_arrangements_agree_after_every_step(env_id, n, steps):
     fused.check_errors()
     venv.close()
     fused.close()
+
+
+FORMAT_CASES = [("MortarMayhem-Grid-v0", 65536, 250), ("Endless-MysteryPath-v0", 32768, 250), ("SearingSpotlights-v0", 16385, 400),
+                ("Endless-SearingSpotlights-v0", 20001, 300), ("Endless-MortarMayhem-v0", 32768, 200)]
+
+
+@pytest.mark.parametrize("env_id,n,steps", FORMAT_CASES)
+def test_fused_uint8_launches_agree_with_the_plain_float_arrangement(env_id, n, steps):
+    """The uint8 handle runs the fused launches (one launch per step, resets / paths served inside the raster launch, lazy segments); an
+    f32_chw handle of the same id takes the plain arrangements (step kernel, queue server, plain raster) and the float stream-out.  After
+    every step: obs_f32 == obs_u8 / 255 in CHW order, for every instance (tools/arrangement_soak.py formats)."""
+    import memory_gym_amd
+    import torch
+
+    a_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format="f32_chw")
+    div = torch.tensor(255.0, device="cuda")  # (a device divisor: with a Python scalar torch multiplies by the rounded reciprocal)
+
+    def same(x, y):
+        return torch.equal(x.permute(0, 3, 2, 1).to(torch.float32) / div, y)
+    seeds = torch.arange(n, dtype=torch.int64, device="cuda") + 3
+    oa, _ = a_env.reset(seed=seeds)
+    ob, _ = b_env.reset(seed=seeds)
+    assert same(oa, ob)
+    adim = a_env.action_dim
+    n_act = 4 if adim == 1 else 3
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for t in range(steps):
+        a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+        oa, ra, da, _, _ = a_env.step(a)
+        ob, rb, db, _, _ = b_env.step(a)
+        assert same(oa, ob), "%s: frames differ after step %d" % (env_id, t)
+        assert torch.equal(ra, rb) and torch.equal(da, db), "%s step %d" % (env_id, t)
+    a_env.check_errors()
+    b_env.check_errors()
+    a_env.close()
+    b_env.close()

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""tools/arrangement_soak.py MODE [STEPS] -- one-off hunts (round 6) in the manner of tools/vector_soak.py: two handles of the same id that the
+library runs through DIFFERENT launch arrangements, stepped with the same actions, every frame of every instance compared on the device after
+every step.
+  formats  a uint8 handle (the fused launches: one launch per step, resets / paths served inside the raster launch, lazy segments) against an
+           f32_chw handle (the float formats take the plain arrangements: step kernel, queue server, plain raster): obs_f32 == obs_u8 / 255 in CHW
+  sets     a default handle against one whose odd instances run under a second option set that differs in a reward only (per-instance option
+           sets: the <PS> forms of the kernels, none of the fused launches): observations and dones equal, rewards equal on the even instances
+Sizes choose the large-launch arrangements of the uint8 / default handle."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "endless-memory-gym_amd"))
+import memory_gym_amd  # noqa: E402
+
+mode = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+CASES = [("MortarMayhem-Grid-v0", 65536), ("MortarMayhem-v0", 20001), ("Endless-MortarMayhem-v0", 32768), ("MysteryPath-v0", 32768),
+         ("MysteryPath-Grid-v0", 24577), ("Endless-MysteryPath-v0", 32768), ("SearingSpotlights-v0", 16385), ("Endless-SearingSpotlights-v0", 20001),
+         ("Endless-SearingSpotlights-v0", 16384), ("MortarMayhemB-Grid-v0", 12289), ("MortarMayhemB-v0", 8193)]
+if os.environ.get("SOAK_ONLY"):
+    CASES = [c for c in CASES if c[0] in os.environ["SOAK_ONLY"].split(",")]
+OTHER = {"MortarMayhem": {"reward_command_success": 0.25}, "MysteryPath": {"reward_fall_off": -0.5}, "SearingSpotlights": {"reward_inside_spotlight": -0.125}}
+DIV = torch.tensor(255.0, device="cuda")
+vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
+for env_id, n in CASES:
+    a_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    if mode == "formats":
+        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format="f32_chw")
+    else:
+        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    seeds = torch.arange(n, dtype=torch.int64, device="cuda") + 3
+    oa, _ = a_env.reset(seed=seeds)
+    if mode == "sets":
+        odd = (torch.arange(n, device="cuda") % 2) == 1
+        opt = next(v for k, v in OTHER.items() if k in env_id)
+        b_env.reset(seed=seeds, mask=~odd)
+        ob, _ = b_env.reset(seed=seeds, options=opt, mask=odd)
+    else:
+        ob, _ = b_env.reset(seed=seeds)
+
+    def same(x, y):
+        x, y = vis(x), vis(y)
+        if mode == "formats":  # [N, 84 x, 84 y, 3] uint8 -> [N, 3, 84 y, 84 x] float32 = value / 255 (the correctly rounded quotient)
+            # (a DEVICE divisor: with a Python scalar torch multiplies by the rounded reciprocal, which is not the quotient for 126 bytes)
+            return torch.equal(x.permute(0, 3, 2, 1).to(torch.float32) / DIV, y)
+        return torch.equal(x, y)
+    assert same(oa, ob), env_id + ": reset frames"
+    adim = a_env.action_dim
+    n_act = 4 if adim == 1 else 3
+    g = torch.Generator(device="cuda").manual_seed(17)
+    finished = 0
+    for t in range(steps):
+        a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+        oa, ra, da, _, _ = a_env.step(a)
+        ob, rb, db, _, _ = b_env.step(a)
+        ok = same(oa, ob) and torch.equal(da, db) and (torch.equal(ra, rb) if mode == "formats" else torch.equal(ra[::2], rb[::2]))
+        if not ok:
+            print("MISMATCH %s (%s) step %d: obs %s dones %s" % (env_id, mode, t, same(oa, ob), torch.equal(da, db)))
+            sys.exit(1)
+        finished += int(da.sum())
+    for i in (0, n // 3, n - 1):
+        assert np.array_equal(a_env.rng_words(i), b_env.rng_words(i)), (env_id, i)
+    a_env.check_errors()
+    b_env.check_errors()
+    print("ok %-30s %6d instances x %d steps (%s), %d episodes finished" % (env_id, n, steps, mode, finished), flush=True)
+    a_env.close()
+    b_env.close()
