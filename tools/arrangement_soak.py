@@ -6,6 +6,9 @@ every step.
            f32_chw handle (the float formats take the plain arrangements: step kernel, queue server, plain raster): obs_f32 == obs_u8 / 255 in CHW
   sets     a default handle against one whose odd instances run under a second option set that differs in a reward only (per-instance option
            sets: the <PS> forms of the kernels, none of the fused launches): observations and dones equal, rewards equal on the even instances
+  sizes    a handle of n instances against a handle of the first m = 4,099 of them (an instance's episode does not depend on how many others
+           there are; the library chooses its launch arrangement by the size: queue entries or lane jobs, resets inside the raster launch or in
+           the step kernel, small or large raster grids): obs[:m], rewards[:m], dones[:m] equal
 Sizes choose the large-launch arrangements of the uint8 / default handle."""
 import os
 import sys
@@ -29,10 +32,11 @@ DIV = torch.tensor(255.0, device="cuda")
 vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
 for env_id, n in CASES:
     a_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    m = 4099 if mode == "sizes" else n
     if mode == "formats":
         b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format="f32_chw")
     else:
-        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+        b_env = memory_gym_amd.make(env_id, num_envs=m, device=0)
     seeds = torch.arange(n, dtype=torch.int64, device="cuda") + 3
     oa, _ = a_env.reset(seed=seeds)
     if mode == "sets":
@@ -41,29 +45,34 @@ for env_id, n in CASES:
         b_env.reset(seed=seeds, mask=~odd)
         ob, _ = b_env.reset(seed=seeds, options=opt, mask=odd)
     else:
-        ob, _ = b_env.reset(seed=seeds)
+        ob, _ = b_env.reset(seed=seeds[:m])
 
     def same(x, y):
         x, y = vis(x), vis(y)
         if mode == "formats":  # [N, 84 x, 84 y, 3] uint8 -> [N, 3, 84 y, 84 x] float32 = value / 255 (the correctly rounded quotient)
             # (a DEVICE divisor: with a Python scalar torch multiplies by the rounded reciprocal, which is not the quotient for 126 bytes)
             return torch.equal(x.permute(0, 3, 2, 1).to(torch.float32) / DIV, y)
-        return torch.equal(x, y)
+        return torch.equal(x[:m], y)
     assert same(oa, ob), env_id + ": reset frames"
     adim = a_env.action_dim
     n_act = 4 if adim == 1 else 3
     g = torch.Generator(device="cuda").manual_seed(17)
+    follow = a_env.gt.clone() if (os.environ.get("SOAK_POLICY") == "follower" and a_env.gt_dim == 3) else None
     finished = 0
     for t in range(steps):
         a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
-        oa, ra, da, _, _ = a_env.step(a)
-        ob, rb, db, _, _ = b_env.step(a)
-        ok = same(oa, ob) and torch.equal(da, db) and (torch.equal(ra, rb) if mode == "formats" else torch.equal(ra[::2], rb[::2]))
+        if follow is not None:  # SOAK_POLICY=follower: the way the ground truth names, a random action with probability 0.02 (deep episodes)
+            a = torch.where(torch.rand(n, device="cuda", generator=g) < 0.02, a, follow.argmax(1).to(torch.int32) + 1)
+        oa, ra, da, _, ia = a_env.step(a)
+        if follow is not None:
+            follow = ia["ground_truth"]
+        ob, rb, db, _, _ = b_env.step(a[:m])
+        ok = same(oa, ob) and torch.equal(da[:m], db) and (torch.equal(ra[:m], rb) if mode != "sets" else torch.equal(ra[::2], rb[::2]))
         if not ok:
-            print("MISMATCH %s (%s) step %d: obs %s dones %s" % (env_id, mode, t, same(oa, ob), torch.equal(da, db)))
+            print("MISMATCH %s (%s) step %d: obs %s dones %s" % (env_id, mode, t, same(oa, ob), torch.equal(da[:m], db)))
             sys.exit(1)
         finished += int(da.sum())
-    for i in (0, n // 3, n - 1):
+    for i in (0, m // 3, m - 1):
         assert np.array_equal(a_env.rng_words(i), b_env.rng_words(i)), (env_id, i)
     a_env.check_errors()
     b_env.check_errors()

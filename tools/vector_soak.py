@@ -31,12 +31,17 @@ for env_id, n in CASES:
     o2, _ = fused.reset(seed=5)
     assert torch.equal(vis(o1), vis(o2))
     g = torch.Generator(device="cuda").manual_seed(9)
+    follow = fused.gt.clone() if (os.environ.get("SOAK_POLICY") == "follower" and fused.gt_dim == 3) else None
     finished = 0
     for t in range(steps):
         a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+        if follow is not None:  # SOAK_POLICY=follower: the way the ground truth names, a random action with probability 0.02 (deep episodes)
+            a = torch.where(torch.rand(n, device="cuda", generator=g) < 0.02, a, follow.argmax(1).to(torch.int32) + 1)
         prev2 = vis(o2).clone() if os.environ.get("VECTOR_SOAK_DIAG") else None
         o1, r1, d1, tr, infos = venv.step(a)
         o2, r2, d2, _, i2 = fused.step(a)
+        if follow is not None:
+            follow = i2["ground_truth"]
         if not (torch.equal(vis(o1), vis(o2)) and torch.equal(r1, r2) and torch.equal(d1, d2)):
             bad = (vis(o1) != vis(o2)).flatten(1).any(1).nonzero().flatten()[:5].tolist()
             print("MISMATCH %s step %d instances %s (obs); rewards equal %s, dones equal %s; done of those %s; differing bytes %s" % (
