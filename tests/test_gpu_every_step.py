@@ -85,3 +85,31 @@ def test_fused_uint8_launches_agree_with_the_plain_float_arrangement(env_id, n, 
     b_env.check_errors()
     a_env.close()
     b_env.close()
+
+
+@pytest.mark.parametrize("env_id,n,steps", [("SearingSpotlights-v0", 16385, 2000), ("Endless-SearingSpotlights-v0", 20001, 1000),
+                                            ("MortarMayhem-Grid-v0", 65536, 300), ("Endless-MysteryPath-v0", 32768, 300)])
+def test_render_reproduces_every_frame_of_every_step(env_id, n, steps):
+    """mg_render draws the descriptors that lie in memory with the plain raster launch; the step's own launch drew its frames from them
+    too -- fused with the step, beside the resets or the path service.  After every step the two must agree on every instance (the
+    pre-fix spot_raster_serve_kernel fails this within a few hundred steps: tools/arrangement_soak.py render)."""
+    import memory_gym_amd
+    import torch
+    from memory_gym_amd import _native
+
+    env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    obs, _ = env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda") + 3)
+    adim = env.action_dim
+    n_act = 4 if adim == 1 else 3
+    g = torch.Generator(device="cuda").manual_seed(23)
+    again = torch.empty_like(obs)
+    for t in range(steps):
+        a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+        obs, _, d, _, _ = env.step(a)
+        again.fill_(7)
+        _native.check(_native.LIB.mg_render(env._h, again.data_ptr(), env._stream()), "mg_render")
+        if not torch.equal(again, obs):
+            bad = (again != obs).flatten(1).any(1).nonzero().flatten()[:4].tolist()
+            pytest.fail("%s: mg_render and the step disagree on instances %s after step %d (done: %s)" % (env_id, bad, t, d[bad].tolist()))
+    env.check_errors()
+    env.close()

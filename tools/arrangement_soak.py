@@ -9,6 +9,10 @@ every step.
   sizes    a handle of n instances against a handle of the first m = 4,099 of them (an instance's episode does not depend on how many others
            there are; the library chooses its launch arrangement by the size: queue entries or lane jobs, resets inside the raster launch or in
            the step kernel, small or large raster grids): obs[:m], rewards[:m], dones[:m] equal
+  render   ONE handle: after every step mg_render (the plain raster over the descriptors in memory) into a second buffer must reproduce the
+           observations the step's own launch drew (a frame drawn from a stale or half-written descriptor shows up here too)
+  checkpoint  a handle against a second one that takes over its state_dict() every 61 steps and must then follow it frame for frame
+           (Family::sync_state: owed segments generated, queues drained, at full size)
 Sizes choose the large-launch arrangements of the uint8 / default handle."""
 import os
 import sys
@@ -32,6 +36,40 @@ DIV = torch.tensor(255.0, device="cuda")
 vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
 for env_id, n in CASES:
     a_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    if mode in ("render", "checkpoint"):
+        from memory_gym_amd import _native
+        adim = a_env.action_dim
+        n_act = 4 if adim == 1 else 3
+        g = torch.Generator(device="cuda").manual_seed(23)
+        obs, _ = a_env.reset(seed=torch.arange(n, dtype=torch.int64, device="cuda") + 3)
+        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0) if mode == "checkpoint" else None
+        again = torch.empty_like(vis(obs))
+        following = False
+        for t in range(steps):
+            a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+            obs, r, d, _, _ = a_env.step(a)
+            if mode == "render":
+                again.fill_(7)
+                _native.check(_native.LIB.mg_render(a_env._h, again.data_ptr(), a_env._stream()), "mg_render")
+                if not torch.equal(again, vis(obs)):
+                    bad = (again != vis(obs)).flatten(1).any(1).nonzero().flatten()[:4].tolist()
+                    print("MISMATCH %s (render) step %d instances %s done %s" % (env_id, t, bad, d[bad].tolist()))
+                    sys.exit(1)
+            else:
+                if following:
+                    ob, rb, db, _, _ = b_env.step(a)
+                    if not (torch.equal(vis(ob), vis(obs)) and torch.equal(rb, r) and torch.equal(db, d)):
+                        print("MISMATCH %s (checkpoint) step %d" % (env_id, t))
+                        sys.exit(1)
+                if t % 61 == 60:
+                    b_env.load_state_dict(a_env.state_dict())
+                    following = True
+        a_env.check_errors()
+        print("ok %-30s %6d instances x %d steps (%s)" % (env_id, n, steps, mode), flush=True)
+        a_env.close()
+        if b_env is not None:
+            b_env.close()
+        continue
     m = 4099 if mode == "sizes" else n
     if mode == "formats":
         b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format="f32_chw")
