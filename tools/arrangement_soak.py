@@ -13,6 +13,8 @@ every step.
            observations the step's own launch drew (a frame drawn from a stale or half-written descriptor shows up here too)
   checkpoint  a handle against a second one that takes over its state_dict() every 61 steps and must then follow it frame for frame
            (Family::sync_state: owed segments generated, queues drained, at full size)
+  streams  two handles of the same id and seeds stepped CONCURRENTLY on two streams (no synchronisation between the two launches of a
+           step): both must draw the same frames -- nothing of a handle (queues, claim words, atlases, pooled buffers) may be shared
 Sizes choose the large-launch arrangements of the uint8 / default handle."""
 import os
 import sys
@@ -33,9 +35,40 @@ if os.environ.get("SOAK_ONLY"):
     CASES = [c for c in CASES if c[0] in os.environ["SOAK_ONLY"].split(",")]
 OTHER = {"MortarMayhem": {"reward_command_success": 0.25}, "MysteryPath": {"reward_fall_off": -0.5}, "SearingSpotlights": {"reward_inside_spotlight": -0.125}}
 DIV = torch.tensor(255.0, device="cuda")
+FMT = os.environ.get("SOAK_FORMAT", "f32_chw")  # formats mode: f32_chw / bf16_chw / f16_chw
 vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
 for env_id, n in CASES:
     a_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+    if mode == "streams":
+        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        seeds = torch.arange(n, dtype=torch.int64, device="cuda") + 3
+        adim = a_env.action_dim
+        n_act = 4 if adim == 1 else 3
+        g = torch.Generator(device="cuda").manual_seed(29)
+        with torch.cuda.stream(s1):
+            oa, _ = a_env.reset(seed=seeds)
+        with torch.cuda.stream(s2):
+            ob, _ = b_env.reset(seed=seeds)
+        torch.cuda.synchronize()
+        assert torch.equal(vis(oa), vis(ob))
+        for t in range(steps):
+            a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s1):
+                oa, ra, da, _, _ = a_env.step(a)
+            with torch.cuda.stream(s2):
+                ob, rb, db, _, _ = b_env.step(a)
+            torch.cuda.synchronize()
+            if not (torch.equal(vis(oa), vis(ob)) and torch.equal(ra, rb) and torch.equal(da, db)):
+                print("MISMATCH %s (streams) step %d" % (env_id, t))
+                sys.exit(1)
+        a_env.check_errors()
+        b_env.check_errors()
+        print("ok %-30s %6d instances x %d steps (streams)" % (env_id, n, steps), flush=True)
+        a_env.close()
+        b_env.close()
+        continue
     if mode in ("render", "checkpoint"):
         from memory_gym_amd import _native
         adim = a_env.action_dim
@@ -72,7 +105,7 @@ for env_id, n in CASES:
         continue
     m = 4099 if mode == "sizes" else n
     if mode == "formats":
-        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format="f32_chw")
+        b_env = memory_gym_amd.make(env_id, num_envs=n, device=0, obs_format=FMT)
     else:
         b_env = memory_gym_amd.make(env_id, num_envs=m, device=0)
     seeds = torch.arange(n, dtype=torch.int64, device="cuda") + 3
@@ -89,7 +122,8 @@ for env_id, n in CASES:
         x, y = vis(x), vis(y)
         if mode == "formats":  # [N, 84 x, 84 y, 3] uint8 -> [N, 3, 84 y, 84 x] float32 = value / 255 (the correctly rounded quotient)
             # (a DEVICE divisor: with a Python scalar torch multiplies by the rounded reciprocal, which is not the quotient for 126 bytes)
-            return torch.equal(x.permute(0, 3, 2, 1).to(torch.float32) / DIV, y)
+            q = x.permute(0, 3, 2, 1).to(torch.float32) / DIV
+            return torch.equal(q if FMT == "f32_chw" else q.to(y.dtype), y)  # (16-bit formats: the float32 quotient rounded to nearest even)
         return torch.equal(x[:m], y)
     assert same(oa, ob), env_id + ": reset frames"
     adim = a_env.action_dim
