@@ -31,6 +31,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 CASES = [("MortarMayhem-Grid-v0", 65536), ("MortarMayhem-v0", 20001), ("Endless-MortarMayhem-v0", 32768), ("MysteryPath-v0", 32768),
          ("MysteryPath-Grid-v0", 24577), ("Endless-MysteryPath-v0", 32768), ("SearingSpotlights-v0", 16385), ("Endless-SearingSpotlights-v0", 20001),
          ("Endless-SearingSpotlights-v0", 16384), ("MortarMayhemB-Grid-v0", 12289), ("MortarMayhemB-v0", 8193)]
+if os.environ.get("SOAK_CASES"):  # "id:n,id:n,...": sizes of one's own (the thresholds at which the library changes its arrangement)
+    CASES = [(c.split(":")[0], int(c.split(":")[1])) for c in os.environ["SOAK_CASES"].split(",")]
 if os.environ.get("SOAK_ONLY"):
     CASES = [c for c in CASES if c[0] in os.environ["SOAK_ONLY"].split(",")]
 OTHER = {"MortarMayhem": {"reward_command_success": 0.25}, "MysteryPath": {"reward_fall_off": -0.5}, "SearingSpotlights": {"reward_inside_spotlight": -0.125}}
