@@ -338,7 +338,7 @@ int mg_step(mg_env* env, const int32_t* actions_dev, void* obs_dev, float* rewar
         hipStream_t st = (hipStream_t)stream;
         const mg_info_buffers ib = read_info(info);
         mg::Family* f = env->fam;
-        if (autoreset && ib.final_obs_dev) {
+        if (autoreset && ib.final_obs_dev && !(mg::sparse_masked_raster() && f->keeps_final_obs(st))) {
             // terminal frames wanted: step without auto-reset (obs rows of finished instances = terminal frames), keep
             // a copy of exactly those rows, then reset the finished instances with seed=None -- the same RNG
             // consumption and frames as the fused path (tests/test_gpu_vector_api.py)

@@ -221,6 +221,10 @@ class Family {
                       const mg_info_buffers* info, int autoreset, hipStream_t s) = 0;
     // rasterise the CURRENT frame descriptors of the instances with only[i] != 0 into `obs` (others untouched)
     virtual void raster_only(void* obs, const uint8_t* only, hipStream_t s) = 0;
+    // true: step(..., autoreset = 1) with info->final_obs_dev set keeps the terminal observations ITSELF (the frame workgroup of a finishing
+    // instance draws the terminal frame into final_obs_dev, then the reset frame into obs); false: mg_step takes the generic path (a step
+    // without auto-reset, the terminal rows copied, a masked reset).  Asked once per call, on the stream of the call.
+    virtual bool keeps_final_obs(hipStream_t /*s*/) { return false; }
     // render("debug_rgb_array") before its final x4 stretch: the debug surface of every instance (the reference's
     // _build_debug_surface, e.g. mortar_mayhem_grid.py:104-135) as uint8 [num_envs][84 x][84 y][3], the observation layout
     virtual void raster_debug(void* frames, hipStream_t s) = 0;

@@ -296,13 +296,17 @@ struct MortarStepArgs {
     float* gt;
     mg_info_buffers info;
     int autoreset;
+    MortarDesc* tdesc;  // FINAL form of the one-launch step (terminal observations kept): [N] descriptors of the terminal frames
 };
 
 // CLAIM (the step workgroups of the one-launch step): the wave steps its 64 instances only if it is the first to exchange this
 // step's ticket into `claim_word` (see mortar_step_raster_kernel).  The exchange is ISSUED first and its answer awaited together
 // with the state record: as a round trip of its own in front of the loads it delayed every descriptor, i.e. the whole launch,
 // by 5-8 us (16,384 instances: 65 -> 73 us).
-template <bool FUSED, bool CLAIM = false, bool PS = false>
+// FINAL (the one-launch step of a call that keeps terminal observations, mg_info_buffers.final_obs_dev): an instance that finishes
+// publishes the descriptor of its TERMINAL frame in a.tdesc[i] before it resets, and says so in the reset frame's descriptor (ring_on, a
+// field only the debug view uses otherwise): the frame workgroup draws the terminal frame into final_obs_dev first.
+template <bool FUSED, bool CLAIM = false, bool PS = false, bool FINAL = false>
 __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a, uint32_t epoch, uint32_t* claim_word = nullptr,
                                                  uint32_t ticket = 0u) {
     uint32_t claimed_by = 0u;
@@ -520,10 +524,29 @@ __device__ __forceinline__ void mortar_step_body(int i, const MortarStepArgs& a,
     memset(&d, 0, sizeof(d));
     d.glyph_x0 = (int16_t)P.glyph_x0;
     if (done && autoreset) {
+        if constexpr (FINAL) {  // the terminal frame's descriptor (the else branch below), published like the frame descriptor's first words
+            MortarDesc td;
+            memset(&td, 0, sizeof(td));
+            td.glyph_x0 = (int16_t)P.glyph_x0;
+            const int tcx = s.disp_is_agent ? s.ax : s.disp_x, tcy = s.disp_is_agent ? s.ay : s.disp_y;
+            td.sx = (int16_t)(tcx - P.sprite_dim / 2);
+            td.sy = (int16_t)(tcy - P.sprite_dim / 2);
+            td.sprite = s.disp_sprite;
+            td.glyph = glyph;
+            td.tmpl = (uint16_t)((s.tiles_on && P.visual_feedback) ? 1 + s.tx * P.N + s.ty : 0);
+            uint32_t tw[4];
+            memcpy(tw, &td, sizeof(tw));
+            uint32_t* tdst = reinterpret_cast<uint32_t*>(&a.tdesc[i]);
+            __hip_atomic_store(tdst + 0, tw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tdst + 1, tw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tdst + 2, tw[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tdst + 3, tw[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all four in front of the wait below)
+        }
         if (!rng_loaded) g.load(io.rng, i);
         rng_loaded = true;
         rng_used = true;
         mortar_reset(P, s, g, cmds, d, (gt && P.variant == V_ENDLESS) ? gt + 2 * i : nullptr, io.vec ? io.vec + (size_t)i * VEC_DIM : nullptr);
+        if constexpr (FINAL) d.ring_on = 1;
     } else {
         int cx = s.disp_is_agent ? s.ax : s.disp_x, cy = s.disp_is_agent ? s.ay : s.disp_y;
         d.sx = (int16_t)(cx - P.sprite_dim / 2);
@@ -593,7 +616,8 @@ constexpr unsigned long long RESCUE_AFTER_TICKS = 20000;  // 200 us
 // to `done_flag` -- a word in the caller's pinned block that the host polls -- at system scope: 2.7 us less per step than a stream memory
 // operation behind the launch, 4.5 us less than hipStreamSynchronize (tools/microbench/launch_wait.hip).  Everything else the host reads
 // (reward, done, the episode record) was stored by the step's wave BEFORE it published the descriptor this workgroup waited for.
-template <bool DONE_FLAG>
+// FINAL: the call keeps terminal observations (see mortar_step_body) -- a kernel of its own, the measured one (FINAL = false) is as it was.
+template <bool DONE_FLAG, bool FINAL = false>
 __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepArgs a, int logic_wgs, int logic_base, uint32_t epoch,
                                                                     uint32_t ticket, uint32_t* claims, uint32_t* rescues,
                                                                     RasterAtlas A, void* __restrict__ obs, uint32_t* done_flag, uint32_t done_ticket) {
@@ -610,9 +634,9 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
     if (is_logic) {  // a step workgroup: wave w steps slot 4 rel + w unless a frame wave got there first
         const int q = rel * 4 + (tid >> 6), i = q * 64 + lane;
 #if defined(MG_LABV) && MG_LABV >= 1
-        if (i < n) mortar_step_body<true, false>(i, a, epoch);
+        if (i < n) mortar_step_body<true, false, false, FINAL>(i, a, epoch);
 #else
-        if (i < n) mortar_step_body<true, true>(i, a, epoch, claims + q, ticket);
+        if (i < n) mortar_step_body<true, true, false, FINAL>(i, a, epoch, claims + q, ticket);
 #endif
         return;
     }
@@ -650,7 +674,7 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
                     asm volatile("" : "+s"(ka));
                     int i = (env >> 6) * 64 + lane;
                     asm volatile("" : "+v"(i));  // (nor may what the step derives from `i` be computed at the head of every frame)
-                    if (i < n) mortar_step_body<true>(i, *(const MortarStepArgs*)ka, epoch);
+                    if (i < n) mortar_step_body<true, false, false, FINAL>(i, *(const MortarStepArgs*)ka, epoch);
                     if (lane == 0) atomicAdd(rescues, 1u);
                     continue;
                 }
@@ -663,6 +687,24 @@ __global__ __launch_bounds__(256, 7) void mortar_step_raster_kernel(MortarStepAr
         w[2] = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MortarDesc d;
         memcpy(&d, w, sizeof(d));
+        if constexpr (FINAL) {
+            if (d.ring_on) {  // the instance finished in this step: its terminal frame first, into the caller's final-observation buffer
+                // (a.tdesc[env] was published in front of the descriptor whose epoch has just been observed)
+                const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(a.tdesc + env);
+                uint32_t tw[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tw[k] = __hip_atomic_load(tsrc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                MortarDesc td;
+                memcpy(&td, tw, sizeof(td));
+                int tt = tid;
+                asm volatile("" : "+v"(tt));
+                R.tid = tt;
+                MortarComposer::compose(&td, R);
+                __syncthreads();
+                store_frame<MG_OBS_U8_XYC, false>(smem, a.info.final_obs_dev, env, tt);
+                __syncthreads();
+            }
+        }
         if (MortarComposer::skip(&d)) continue;
         // the lane's frame offsets are derived from an opaque copy of its index, i.e. inside the iteration: as loop invariants
         // they were live across the (rare) step code above, which needs every register the kernel has
@@ -908,7 +950,7 @@ class MortarFamily : public Family {
         memset(&ib, 0, sizeof(ib));
         if (info) ib = *info;
         upload_sets(s);
-        const MortarStepArgs sa{P_, n_, io(), actions, reward, done, gt_dim() ? gt : nullptr, ib, autoreset};
+        const MortarStepArgs sa{P_, n_, io(), actions, reward, done, gt_dim() ? gt : nullptr, ib, autoreset, nullptr};
         // one launch: mortar_step_raster_kernel (handles with ONE option set: the per-set step code reads its parameters from memory)
         if (obs_format == MG_OBS_U8_XYC && fuse_step() && !per_set() && !capturing(s)) {
             epoch_ = epoch_ % 255u + 1u;  // 1 .. 255: never the 0 a reset's (or the two-launch step's) descriptors carry
@@ -922,6 +964,12 @@ class MortarFamily : public Family {
                 hipLaunchKernelGGL(mortar_step_raster_kernel<true>, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, sa, logic_wgs,
                                    logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs, flag_dev_, flag_ticket_);
                 flag_armed_ = false;
+            } else if (ib.final_obs_dev && autoreset) {  // terminal observations kept by the launch itself (keeps_final_obs)
+                if (!tdesc_.p) tdesc_.alloc(n_, false);
+                MortarStepArgs fa = sa;
+                fa.tdesc = tdesc_.p;
+                hipLaunchKernelGGL((mortar_step_raster_kernel<false, true>), dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, fa, logic_wgs,
+                                   logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs, (uint32_t*)nullptr, 0u);
             } else {
                 hipLaunchKernelGGL(mortar_step_raster_kernel<false>, dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, sa, logic_wgs,
                                    logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs, (uint32_t*)nullptr, 0u);
@@ -1074,6 +1122,12 @@ class MortarFamily : public Family {
         launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s, only);
         MG_HIP(hipGetLastError());
     }
+    // (the one-launch step keeps terminal observations itself: the conditions under which step() takes that launch; lab
+    // MEMGYM_MORTAR_FINAL_FUSED=0: the generic path of mg_step)
+    bool keeps_final_obs(hipStream_t s) override {
+        static const bool wanted = lab_int("MEMGYM_MORTAR_FINAL_FUSED", 1) != 0;
+        return wanted && obs_format == MG_OBS_U8_XYC && fuse_step() && !per_set() && !capturing(s) && !(flag_armed_ && n_ == 1);
+    }
 
     void raster(void* obs, hipStream_t s) {
         launch_raster<MortarComposer>(desc_.p, atlas_->dev(), obs, obs_format, n_, s);
@@ -1111,7 +1165,7 @@ class MortarFamily : public Family {
     float* vec_ = nullptr;
     DevArray<MortarState> state_;
     DevArray<uint8_t> cmds_;
-    DevArray<MortarDesc> desc_;
+    DevArray<MortarDesc> desc_, tdesc_;  // tdesc_: terminal-frame descriptors (FINAL form of the one-launch step), allocated when first needed
     RngStore rng_;
     ErrorWord err_;
     DevArray<uint32_t> claims_, rescues_;  // one-launch step: one claim word per 64 instances; slots stepped by frame waves

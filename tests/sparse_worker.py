@@ -42,6 +42,10 @@ def upd(h, t):
     h.update(np.array([int((per_row * w2).sum()), int(per_row.sum()), int(v.sum())], dtype=np.int64).tobytes())
 
 
+if os.environ.get("MEMGYM_SPARSE_CASES") == "mortar":  # test_mortar_one_launch_keeps_terminal_observations: every mortar id, one of them at full size
+    CASES = [("MortarMayhem-Grid-v0", 65536, 70, "u8_xyc", None), ("MortarMayhem-v0", 20001, 70, "u8_xyc", None),
+             ("Endless-MortarMayhem-v0", 32768, 40, "u8_xyc", None), ("MortarMayhemB-Grid-v0", 12289, 40, "u8_xyc", None),
+             ("MortarMayhemB-v0", 8193, 60, "u8_xyc", None)]
 if os.environ.get("MEMGYM_SPARSE_CASES") == "emp_big":  # test_emp_masked_resets_...: the arrangement of launches above ~20,000 instances
     CASES = [("Endless-MysteryPath-v0", 32768, 60, "u8_xyc", None)]
 

@@ -40,3 +40,17 @@ def test_emp_masked_resets_like_the_auto_reset_step():
     assert slow[0] == fast[0] and slow[0].startswith("digest Endless-MysteryPath-v0 32768"), slow[0] + "\n" + fast[0]
     assert int(fast[0].rsplit("=", 1)[1]) > 32768  # (finished episodes: several per instance)
     assert int(slow[1].split()[1]) == 0 and int(fast[1].split()[1]) > 1000, (slow[1], fast[1])
+
+
+def test_mortar_one_launch_keeps_terminal_observations():
+    """The mortar family's one-launch step keeps terminal observations itself (round 6: the frame workgroup of a finishing instance draws the
+    terminal frame into final_obs_dev from a second descriptor, then the reset frame): everything the caller of the gymnasium vector convention
+    sees -- observations, TERMINAL observations, rewards, dones, generator words -- equal to the generic path of mg_step (step without
+    auto-reset, rows copied, masked reset; lab MEMGYM_MORTAR_FINAL_FUSED=0), all five mortar ids, MortarMayhem-Grid-v0 at 65,536 instances.
+    (Against the oracle: tests/test_gpu_vector_api.py, terminal frame by terminal frame.)"""
+    generic = digests(True, MEMGYM_SPARSE_CASES="mortar", MEMGYM_MORTAR_FINAL_FUSED="0")
+    fused = digests(True, MEMGYM_SPARSE_CASES="mortar", MEMGYM_MORTAR_FINAL_FUSED="1")
+    g = [ln for ln in generic if ln.startswith("digest ")]
+    f = [ln for ln in fused if ln.startswith("digest ")]
+    assert len(g) == 5 and g == f, "\n".join(a + "\n" + b for a, b in zip(g, f) if a != b)
+    assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in g)
