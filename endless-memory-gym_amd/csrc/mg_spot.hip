@@ -1397,8 +1397,12 @@ struct SpotServeArgs {
     // within [batch_min, batch_max] (host: 1 .. 8 up to 12,288 instances -- a step in which every instance is truncated at once
     // still takes few rounds -- and 8 beyond, where eight measured 1-2 % ahead of the adaptive choice).  profiles/r04_spot_step.md section 4.
     int batch_min, batch_max;
+    void* final_obs;  // FINAL form (terminal observations kept, mg_info_buffers.final_obs_dev), else NULL
 };
-template <bool EN, bool BORDER, bool NT>
+// FINAL (round 6): a call in the gymnasium vector convention.  The step kernel has stored a finishing instance's state and frame descriptor
+// "as after any other step" (valid = DESC_QUEUED): that descriptor IS the terminal frame's -- the service workgroup draws it into final_obs
+// before it resets the instance and draws the new episode's first frame into obs.  A kernel of its own; the measured ones are as they were.
+template <bool EN, bool BORDER, bool NT, bool FINAL = false>
 __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kernel(SpotServeArgs a) {
     typedef SpotComposerT<BORDER> Composer;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1435,6 +1439,21 @@ __global__ __launch_bounds__(256, MG_SPOT_SERVE_OCC) void spot_raster_serve_kern
             const SpotParams& P = *(const SpotParams*)&ka->P;
             const SpotIO& io = *(const SpotIO*)&ka->io;
             float* const gt = ka->gt;
+            if constexpr (FINAL) {  // the terminal frames of this round's instances, from the descriptors the step kernel left
+                // (the draw lambda's body once more with another target: as one lambda with a target argument, or one lambda calling the
+                // other, every variant of the kernel took 96-112 B of scratch and the frame loop ran three times as long)
+                void* const fin = ka->final_obs;
+                for (int k = 0; k < batch && base + k < count; ++k) {
+                    const int env = io.queue[base + k];
+                    typename Composer::Pre Pq;
+                    Composer::prefetch(cdescs + env, R, Pq);
+                    Composer::compose(cdescs + env, Pq, R);
+                    __syncthreads();
+                    Composer::recycle(R);
+                    store_frame<MG_OBS_U8_XYC, NT, true>(smem, fin, env, tid);
+                    __syncthreads();
+                }
+            }
             const int e = base + (tid >> 4), ls = tid & 15;
             if (tid < 16 * batch && e < count) {
                 const int i = io.queue[e];
@@ -1728,7 +1747,10 @@ class SpotFamily : public Family {
         upload_sets(s);
         prof.begin(0, s);
         // (resets served inside the raster launch: handles with ONE option set -- the service code takes its parameters from the launch's arguments)
-        const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && fuse_resets() && !per_set()) ? 1 : 0;
+        // (a call that keeps terminal observations: always deferred -- the service workgroup draws the terminal frame from the descriptor this
+        // launch leaves, then resets: keeps_final_obs)
+        const bool keep_final = autoreset && ib.final_obs_dev && keeps_final_obs(s);
+        const int defer = (autoreset && obs_format == MG_OBS_U8_XYC && (fuse_resets() || keep_final) && !per_set()) ? 1 : 0;
         const int sb = step_block(256);
         const SpotStepArgs sa{P_, io(), actions, reward, done, gt, ib, autoreset, defer};
         const dim3 sg((n_ * SLOTS + sb - 1) / sb);
@@ -1745,10 +1767,12 @@ class SpotFamily : public Family {
             const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + SPOT_SVC_WGS;
             const int forced_batch = lab_int("MEMGYM_SPOT_SVC_BATCH", 0);  // (lab build: exactly this many)
             const bool fb = forced_batch >= 1 && forced_batch <= SPOT_SVC_BATCH;
-            const SpotServeArgs va{desc_.p, atlas_->dev(), obs, n_, P_, io(), gt, fb ? forced_batch : (n_ <= 12288 ? 1 : SPOT_SVC_BATCH), fb ? forced_batch : SPOT_SVC_BATCH};
+            const SpotServeArgs va{desc_.p, atlas_->dev(), obs, n_, P_, io(), gt, fb ? forced_batch : (n_ <= 12288 ? 1 : SPOT_SVC_BATCH), fb ? forced_batch : SPOT_SVC_BATCH,
+                                   keep_final ? ib.final_obs_dev : nullptr};
             const bool nt = fused_nt();                // non-temporal: with plain stores the fused launch loses 5-15 us at every occupancy
             const int serve_lds = RASTER_LDS_REQUEST;  // 25 KiB: six per CU
-#define SPOT_FUSED2(EN, BO, NT) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT>), dim3(grid), dim3(256), serve_lds, s, va)
+#define SPOT_FUSED2(EN, BO, NT) do { if (keep_final) hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT, true>), dim3(grid), dim3(256), serve_lds, s, va); \
+                                     else hipLaunchKernelGGL((spot_raster_serve_kernel<EN, BO, NT>), dim3(grid), dim3(256), serve_lds, s, va); } while (0)
 #define SPOT_FUSED(EN, BO) do { if (nt) SPOT_FUSED2(EN, BO, true); else SPOT_FUSED2(EN, BO, false); } while (0)
             if (P_.endless) { if (P_.ordered_holes) SPOT_FUSED(true, true); else SPOT_FUSED(true, false); }
             else { if (P_.ordered_holes) SPOT_FUSED(false, true); else SPOT_FUSED(false, false); }
@@ -1952,6 +1976,11 @@ class SpotFamily : public Family {
     }
 
     void raster(void* obs, hipStream_t s) { raster_only(obs, nullptr, s); }
+    // (the fused raster / reset launch keeps terminal observations itself; lab MEMGYM_SPOT_FINAL_FUSED=0: the generic path of mg_step)
+    bool keeps_final_obs(hipStream_t) override {
+        static const bool wanted = lab_int("MEMGYM_SPOT_FINAL_FUSED", 1) != 0;
+        return wanted && obs_format == MG_OBS_U8_XYC && !per_set();
+    }
 
     // Resets served inside the raster launch: on for the finite variant up to FUSE_MAX instances (more instances finish per step
     // than in the endless variant and their resets place up to five objects: ~15 us for the 16 lanes of an instance, the tail of

@@ -46,6 +46,9 @@ if os.environ.get("MEMGYM_SPARSE_CASES") == "mortar":  # test_mortar_one_launch_
     CASES = [("MortarMayhem-Grid-v0", 65536, 70, "u8_xyc", None), ("MortarMayhem-v0", 20001, 70, "u8_xyc", None),
              ("Endless-MortarMayhem-v0", 32768, 40, "u8_xyc", None), ("MortarMayhemB-Grid-v0", 12289, 40, "u8_xyc", None),
              ("MortarMayhemB-v0", 8193, 60, "u8_xyc", None)]
+if os.environ.get("MEMGYM_SPARSE_CASES") == "spot":  # test_spot_fused_launch_keeps_terminal_observations
+    CASES = [("SearingSpotlights-v0", 16385, 120, "u8_xyc", None), ("Endless-SearingSpotlights-v0", 16384, 150, "u8_xyc", None),
+             ("Endless-SearingSpotlights-v0", 20001, 120, "u8_xyc", None), ("SearingSpotlights-v0", 3000, 150, "u8_xyc", {"black_background": True})]
 if os.environ.get("MEMGYM_SPARSE_CASES") == "emp_big":  # test_emp_masked_resets_...: the arrangement of launches above ~20,000 instances
     CASES = [("Endless-MysteryPath-v0", 32768, 60, "u8_xyc", None)]
 

@@ -54,3 +54,15 @@ def test_mortar_one_launch_keeps_terminal_observations():
     f = [ln for ln in fused if ln.startswith("digest ")]
     assert len(g) == 5 and g == f, "\n".join(a + "\n" + b for a, b in zip(g, f) if a != b)
     assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in g)
+
+
+def test_spot_fused_launch_keeps_terminal_observations():
+    """The spotlight family's fused raster / reset launch keeps terminal observations itself (round 6: the step kernel leaves a finishing
+    instance's descriptor "as after any other step" -- the terminal frame's -- and the service workgroup draws it into final_obs_dev before it
+    resets the instance): equal to the generic path of mg_step (lab MEMGYM_SPOT_FINAL_FUSED=0) in everything the caller sees incl. the terminal
+    observations -- both variants, below and above the size at which the endless variant takes the fused launch on its own, and the border
+    composer (black_background)."""
+    generic = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="spot", MEMGYM_SPOT_FINAL_FUSED="0") if ln.startswith("digest ")]
+    fused = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="spot", MEMGYM_SPOT_FINAL_FUSED="1") if ln.startswith("digest ")]
+    assert len(generic) == 4 and generic == fused, "\n".join(a + "\n" + b for a, b in zip(generic, fused) if a != b)
+    assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in generic)
