@@ -243,6 +243,7 @@ struct MysteryIO {
     // handle has one set.  Read by the <PS = true> forms of the reset / step / queue-server kernels only.
     const struct MysteryParams* sets;
     const int32_t* set_of;
+    MysteryDesc* tdesc;  // finite variants, FINAL forms of the step / raster kernels (terminal observations kept): [N] terminal-frame descriptors
 };
 constexpr int QC_COUNT = 0, QC_HEAD = 32, QC_LEFT = 64, QC_BG_COUNT = 96, QC_WORDS = 160;  // one 128-byte line each
 // MysteryDesc::valid: 0 = leave the frame alone (masked reset), 1 = draw, 2 = the instance has a queue entry, 3 = served (and, in
@@ -613,6 +614,20 @@ __device__ void serve_mp(const PathWS& W, const PathReq& req, Pcg& g, int* err, 
     }
 }
 
+// the frame descriptor of a finite-variant instance as its state stands
+__device__ __forceinline__ void mp_desc(const MysteryParams& P, const MysteryCore& s, MysteryDesc& d) {
+    memset(&d, 0, sizeof(d));
+    d.valid = 1;
+    d.sprite = s.rot8;
+    d.sx = (int16_t)(s.ax - P.sprite_dim / 2);
+    d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
+    d.cross_on = s.cross_on;
+    d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
+    d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
+    d.goal_on = P.show_goal ? 1 : 0; d.goal_x = s.ex; d.goal_y = s.ey;
+    d.origin_on = P.show_origin ? 1 : 0; d.origin_x = s.sx; d.origin_y = s.sy;
+}
+
 // MysteryPathEnv.step (mystery_path.py:202-276).  Returns true if the instance finished and is to be reset in this call
 // (the caller then runs mp_pre_reset / serve_mp / mp_post_reset); otherwise the frame descriptor is filled here.
 __device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, int act0, int act1, float* reward_out,
@@ -686,16 +701,7 @@ __device__ bool mp_step(const MysteryParams& P, int i, MysteryCore& s, int act0,
     done_out[i] = done ? 1 : 0;
     if (info.capacity_dev) info.capacity_dev[i] = 0;  // (the finite variants have no capacity an episode can reach)
     if (done && autoreset) return true;
-    memset(&d, 0, sizeof(d));
-    d.valid = 1;
-    d.sprite = s.rot8;
-    d.sx = (int16_t)(s.ax - P.sprite_dim / 2);
-    d.sy = (int16_t)(s.ay - P.sprite_dim / 2);
-    d.cross_on = s.cross_on;
-    d.cross_x = (int16_t)(s.cross_x - P.cross_dim / 2);
-    d.cross_y = (int16_t)(s.cross_y - P.cross_dim / 2);
-    d.goal_on = P.show_goal ? 1 : 0; d.goal_x = s.ex; d.goal_y = s.ey;
-    d.origin_on = P.show_origin ? 1 : 0; d.origin_x = s.sx; d.origin_y = s.sy;
+    mp_desc(P, s, d);
     return false;
 }
 
@@ -1427,7 +1433,10 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P0, My
 // workgroups of the raster launch that follows (mystery_raster_paths_kernel).  The launch no longer lasts as long as one noisy A* (23 us) whenever any of
 // its instances resets (MysteryPath-Grid: 0.5 % of them per step).
 constexpr int HYBRID_INLINE = 2;
-template <bool PS>
+// FINAL (round 6): a call that keeps terminal observations (mg_info_buffers.final_obs_dev).  An instance that finishes leaves the descriptor
+// of its TERMINAL frame in io.tdesc[i] and marks the reset frame's descriptor (pad8[0]); the frame workgroup of the raster launch draws
+// the terminal frame into the caller's final-observation buffer first (mystery_raster_paths_kernel<FMT, true>).
+template <bool PS, bool FINAL = false>
 __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, MysteryIO io, const int32_t* actions,
                                                            float* reward_out, uint8_t* done_out, float* gt,
                                                            mg_info_buffers info, int autoreset, int lpw, int defer) {
@@ -1459,6 +1468,13 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, Mys
     bool reset_me = false;
     {
         if (active) reset_me = mp_step(P, i, s, act0, act1, reward_out, done_out, info, autoreset, d);
+        if constexpr (FINAL) {
+            if (reset_me) {
+                MysteryDesc td;
+                mp_desc(P, s, td);
+                io.tdesc[i] = td;
+            }
+        }
         PathReq req;
         req.need = 0; req.sx = req.sy = req.ex = req.ey = 0;
         if (reset_me) req = mp_pre_reset(P, s, g);
@@ -1471,6 +1487,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, Mys
         if (!queue_mine) serve_mp(W, req, g, io.err, len, pm, io.walls, i);
         if (reset_me) {
             mp_post_reset(P, s, req, len, pm, d);  // (queued: path_mask / path_len are filled in by the raster launch's path service)
+            if constexpr (FINAL) d.pad8[0] = 1;
             if (queue_mine) queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         }
     }
@@ -1867,9 +1884,9 @@ constexpr int PATH_MASS = 2 * 4 * PATH_WGS;  // more than two entries per dedica
 // there are enough paths to fill the lanes -- 107 vs 215 us per 32,768 paths, profiles/r03_mass_resets.md): wave 0 of every
 // participating workgroup takes 64 entries, one per lane, its workspace (LW_BYTES = 19,904 B) is the workgroup's frame.
 static_assert(LW_BYTES <= RASTER_LDS, "the lane generator's workspace must fit into the raster workgroup's LDS");
-template <int FMT>
+template <int FMT, bool FINAL = false>
 __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs,
-                                                                      int n, MysteryParams P, MysteryIO io) {
+                                                                      int n, MysteryParams P, MysteryIO io, void* __restrict__ final_obs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if (blockIdx.x < PATH_WGS + PATH_HELP_MAX) {
         // (every one of these workgroups reads the count BEFORE the last participant can clear it: in the long-queue case the
@@ -1964,6 +1981,14 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
     const int tid = threadIdx.x, stride = (int)gridDim.x - PATH_WGS;
     for (int env = (int)blockIdx.x - PATH_WGS; env < n; env += stride) {
         const MysteryDesc* d = descs + env;
+        if constexpr (FINAL) {
+            if (d->pad8[0]) {  // the instance finished in this step: its terminal frame first, into the caller's final-observation buffer
+                MysteryComposer::compose(io.tdesc + env, R);
+                __syncthreads();
+                store_frame<FMT, false>(smem, final_obs, env, tid);
+                __syncthreads();
+            }
+        }
         if (MysteryComposer::skip(d)) continue;
         MysteryComposer::compose(d, R);
         __syncthreads();
@@ -2535,6 +2560,16 @@ class MysteryFamily : public Family {
             // (per-instance option sets: only this kernel has a <PS> form -- the raster launch's path service reads nothing of the options)
             const int defer = (autoreset && !big_sprites_) ? defer_mode() : 0;
             upload_sets(s);
+            if (autoreset && ib.final_obs_dev && keeps_final_obs(s)) {  // terminal observations kept by these two launches (defer != 0, one option set)
+                if (!tdesc_.p) tdesc_.alloc(n_, false);
+                hipLaunchKernelGGL((mystery_step_kernel<false, true>), dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
+                                   (float*)nullptr, ib, autoreset, lpw(), defer);
+                end_logic(s);
+                prof.begin(1, s);
+                raster_with_paths(obs, s, ib.final_obs_dev);
+                prof.end(1, s);
+                return;
+            }
             if (ps)
                 hipLaunchKernelGGL(mystery_step_kernel<true>, dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
                                    (float*)nullptr, ib, autoreset, lpw(), defer);
@@ -2647,17 +2682,26 @@ class MysteryFamily : public Family {
         }();
         return forced >= 0 && forced <= 2 ? forced : (P_.grid != 0 ? 1 : 2);
     }
-    void raster_with_paths(void* obs, hipStream_t s) {
+    void raster_with_paths(void* obs, hipStream_t s, void* final_obs = nullptr) {
         const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + PATH_WGS;
-        if (obs_format == MG_OBS_F32_CYX)
-            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+        void* const none = nullptr;
+        if (final_obs)  // (uint8 format: keeps_final_obs)
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_U8_XYC, true>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), final_obs);
+        else if (obs_format == MG_OBS_F32_CYX)
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F32_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), none);
         else if (obs_format == MG_OBS_BF16_CYX)
-            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_BF16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), none);
         else if (obs_format == MG_OBS_F16_CYX)
-            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_F16_CYX>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), none);
         else
-            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io());
+            hipLaunchKernelGGL((mystery_raster_paths_kernel<MG_OBS_U8_XYC>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_, P_, io(), none);
         MG_HIP(hipGetLastError());
+    }
+    // (the finite variants' step + raster / path-service launches keep terminal observations themselves; lab MEMGYM_MYSTERY_FINAL_FUSED=0: the
+    // generic path of mg_step.  Endless Mystery Path takes the generic path.)
+    bool keeps_final_obs(hipStream_t) override {
+        static const bool wanted = lab_int("MEMGYM_MYSTERY_FINAL_FUSED", 1) != 0;
+        return wanted && !P_.endless && obs_format == MG_OBS_U8_XYC && !big_sprites_ && !per_set() && defer_mode() != 0;
     }
     MysteryIO io() {
         MysteryIO o;
@@ -2677,6 +2721,7 @@ class MysteryFamily : public Family {
         o.stats = stats_.p;
         o.sets = per_set() ? sets_dev_.p : nullptr;
         o.set_of = per_set() ? set_of_ : nullptr;
+        o.tdesc = tdesc_.p;
         return o;
     }
 
@@ -2794,7 +2839,7 @@ class MysteryFamily : public Family {
     DevArray<MysteryCore> core_;
     DevArray<uint8_t> segs_;
     int seg_rows_ = MAX_SEG;
-    DevArray<MysteryDesc> desc_;
+    DevArray<MysteryDesc> desc_, tdesc_;  // tdesc_: terminal-frame descriptors of the FINAL kernels, allocated when first needed
     DevArray<int> queue_;  // n entries + the counters
     DevArray<int> bgq_;    // endless: background jobs (owed segments), small launches
     DevArray<uint8_t> bgflag_;  // ... larger launches: one flag per instance

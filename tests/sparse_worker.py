@@ -49,6 +49,9 @@ if os.environ.get("MEMGYM_SPARSE_CASES") == "mortar":  # test_mortar_one_launch_
 if os.environ.get("MEMGYM_SPARSE_CASES") == "spot":  # test_spot_fused_launch_keeps_terminal_observations
     CASES = [("SearingSpotlights-v0", 16385, 120, "u8_xyc", None), ("Endless-SearingSpotlights-v0", 16384, 150, "u8_xyc", None),
              ("Endless-SearingSpotlights-v0", 20001, 120, "u8_xyc", None), ("SearingSpotlights-v0", 3000, 150, "u8_xyc", {"black_background": True})]
+if os.environ.get("MEMGYM_SPARSE_CASES") == "mystery":  # test_mystery_launches_keep_terminal_observations (short episodes: max_steps)
+    CASES = [("MysteryPath-Grid-v0", 32768, 200, "u8_xyc", None), ("MysteryPath-v0", 20001, 60, "u8_xyc", {"max_steps": 24}),
+             ("MysteryPath-Grid-v0", 4097, 120, "u8_xyc", {"max_steps": 16}), ("MysteryPath-v0", 32768, 120, "u8_xyc", {"max_steps": 48})]
 if os.environ.get("MEMGYM_SPARSE_CASES") == "emp_big":  # test_emp_masked_resets_...: the arrangement of launches above ~20,000 instances
     CASES = [("Endless-MysteryPath-v0", 32768, 60, "u8_xyc", None)]
 

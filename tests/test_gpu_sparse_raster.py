@@ -66,3 +66,15 @@ def test_spot_fused_launch_keeps_terminal_observations():
     fused = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="spot", MEMGYM_SPOT_FINAL_FUSED="1") if ln.startswith("digest ")]
     assert len(generic) == 4 and generic == fused, "\n".join(a + "\n" + b for a, b in zip(generic, fused) if a != b)
     assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in generic)
+
+
+def test_mystery_launches_keep_terminal_observations():
+    """The finite Mystery Path ids keep terminal observations in the step's own two launches (round 6: mystery_step_kernel<false, true> leaves a
+    finishing instance's terminal descriptor in io.tdesc, mystery_raster_paths_kernel<u8, true> draws it into final_obs_dev before the reset
+    frame; the reset's path is generated beside the frames as in the auto-reset step): equal to the generic path of mg_step (lab
+    MEMGYM_MYSTERY_FINAL_FUSED=0) in everything the caller sees incl. the terminal observations; episodes shortened with max_steps so that
+    every instance finishes several times (a step in which ALL instances are truncated at once included)."""
+    generic = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="mystery", MEMGYM_MYSTERY_FINAL_FUSED="0") if ln.startswith("digest ")]
+    fused = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="mystery", MEMGYM_MYSTERY_FINAL_FUSED="1") if ln.startswith("digest ")]
+    assert len(generic) == 4 and generic == fused, "\n".join(a + "\n" + b for a, b in zip(generic, fused) if a != b)
+    assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in generic)
