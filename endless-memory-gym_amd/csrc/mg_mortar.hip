@@ -806,6 +806,7 @@ class MortarFamily : public Family {
         state_.alloc(n);
         cmds_.alloc((size_t)n * P_.cmd_cap);
         desc_.alloc(n);
+        tdesc_.alloc(n);  // (terminal-frame descriptors of the FINAL one-launch step: 16 B per instance; allocated here so that no step allocates)
         rng_.alloc(n);
         err_.alloc();
         claims_.alloc((size_t)((n + 255) / 256) * 4);
@@ -965,7 +966,6 @@ class MortarFamily : public Family {
                                    logic_last ? frames : 0, epoch_, ticket_, claims_.p, rescues_.p, atlas_->dev(), obs, flag_dev_, flag_ticket_);
                 flag_armed_ = false;
             } else if (ib.final_obs_dev && autoreset) {  // terminal observations kept by the launch itself (keeps_final_obs)
-                if (!tdesc_.p) tdesc_.alloc(n_, false);
                 MortarStepArgs fa = sa;
                 fa.tdesc = tdesc_.p;
                 hipLaunchKernelGGL((mortar_step_raster_kernel<false, true>), dim3(logic_wgs + frames), dim3(256), RASTER_LDS, s, fa, logic_wgs,
@@ -1165,7 +1165,7 @@ class MortarFamily : public Family {
     float* vec_ = nullptr;
     DevArray<MortarState> state_;
     DevArray<uint8_t> cmds_;
-    DevArray<MortarDesc> desc_, tdesc_;  // tdesc_: terminal-frame descriptors (FINAL form of the one-launch step), allocated when first needed
+    DevArray<MortarDesc> desc_, tdesc_;  // tdesc_: terminal-frame descriptors (FINAL form of the one-launch step)
     RngStore rng_;
     ErrorWord err_;
     DevArray<uint32_t> claims_, rescues_;  // one-launch step: one claim word per 64 instances; slots stepped by frame waves

@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(256) void mystery_reset_kernel(MysteryParams P0, My
 // its instances resets (MysteryPath-Grid: 0.5 % of them per step).
 constexpr int HYBRID_INLINE = 2;
 // FINAL (round 6): a call that keeps terminal observations (mg_info_buffers.final_obs_dev).  An instance that finishes leaves the descriptor
-// of its TERMINAL frame in io.tdesc[i] and marks the reset frame's descriptor (pad8[0]); the frame workgroup of the raster launch draws
+// of its TERMINAL frame in io.tdesc[i] and marks the reset frame's descriptor (pad8[1]; pad8[0] is the debug view's); the frame workgroup of the raster launch draws
 // the terminal frame into the caller's final-observation buffer first (mystery_raster_paths_kernel<FMT, true>).
 template <bool PS, bool FINAL = false>
 __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, MysteryIO io, const int32_t* actions,
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(256) void mystery_step_kernel(MysteryParams P0, Mys
         if (!queue_mine) serve_mp(W, req, g, io.err, len, pm, io.walls, i);
         if (reset_me) {
             mp_post_reset(P, s, req, len, pm, d);  // (queued: path_mask / path_len are filled in by the raster launch's path service)
-            if constexpr (FINAL) d.pad8[0] = 1;
+            if constexpr (FINAL) d.pad8[1] = 1;
             if (queue_mine) queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
         }
     }
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(256, 7) void mystery_raster_paths_kernel(const Myst
     for (int env = (int)blockIdx.x - PATH_WGS; env < n; env += stride) {
         const MysteryDesc* d = descs + env;
         if constexpr (FINAL) {
-            if (d->pad8[0]) {  // the instance finished in this step: its terminal frame first, into the caller's final-observation buffer
+            if (d->pad8[1]) {  // the instance finished in this step: its terminal frame first, into the caller's final-observation buffer
                 MysteryComposer::compose(io.tdesc + env, R);
                 __syncthreads();
                 store_frame<FMT, false>(smem, final_obs, env, tid);
@@ -2330,6 +2330,7 @@ class MysteryFamily : public Family {
         core_.alloc(n);
         walls_.alloc(n);
         desc_.alloc(n);
+        if (!endless) tdesc_.alloc(n);  // (terminal-frame descriptors of the FINAL kernels: 64 B per instance; allocated here so that no step allocates)
         rng_.alloc(n);
         err_.alloc();
         queue_.alloc((size_t)n + 32 + QC_WORDS);
@@ -2561,7 +2562,6 @@ class MysteryFamily : public Family {
             const int defer = (autoreset && !big_sprites_) ? defer_mode() : 0;
             upload_sets(s);
             if (autoreset && ib.final_obs_dev && keeps_final_obs(s)) {  // terminal observations kept by these two launches (defer != 0, one option set)
-                if (!tdesc_.p) tdesc_.alloc(n_, false);
                 hipLaunchKernelGGL((mystery_step_kernel<false, true>), dim3(blocks()), dim3(256), WS_BYTES, s, P_, io(), actions, reward, done,
                                    (float*)nullptr, ib, autoreset, lpw(), defer);
                 end_logic(s);
@@ -2839,7 +2839,7 @@ class MysteryFamily : public Family {
     DevArray<MysteryCore> core_;
     DevArray<uint8_t> segs_;
     int seg_rows_ = MAX_SEG;
-    DevArray<MysteryDesc> desc_, tdesc_;  // tdesc_: terminal-frame descriptors of the FINAL kernels, allocated when first needed
+    DevArray<MysteryDesc> desc_, tdesc_;  // tdesc_: terminal-frame descriptors of the FINAL kernels (finite variants)
     DevArray<int> queue_;  // n entries + the counters
     DevArray<int> bgq_;    // endless: background jobs (owed segments), small launches
     DevArray<uint8_t> bgflag_;  // ... larger launches: one flag per instance
