@@ -55,7 +55,10 @@ if os.environ.get("MEMGYM_SPARSE_CASES") == "mystery":  # test_mystery_launches_
 if os.environ.get("MEMGYM_SPARSE_CASES") == "emp_big":  # test_emp_masked_resets_...: the arrangement of launches above ~20,000 instances
     CASES = [("Endless-MysteryPath-v0", 32768, 60, "u8_xyc", None)]
 
+STEPS_X = int(os.environ.get("MEMGYM_SPARSE_STEPS_X", "1"))  # one-off long runs of the same comparison
+
 for env_id, n, steps, fmt, options in CASES:
+    steps *= STEPS_X
     h = hashlib.sha256()
     vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
     # (1) the gymnasium vector convention: terminal observations + same-call resets
