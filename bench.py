@@ -947,6 +947,13 @@ def main():
 
     from datetime import timedelta
 
+    # The observation buffer's placement search (include/memgym.h: mg_obs_alloc_for) is bounded at 1.5 s by default -- a trainer's start-up
+    # should not hang on it -- and on a box whose memory earlier processes have dirtied (the driver wipes what it hands out, ~27 ms per GiB)
+    # that bound can end the walk inside the first zone: the buffer is then a plain allocation, 0-20 % slower depending on where it lands
+    # (round 6, eight processes in a row on one box: 282-289 M with two zones, 286.6 and 231.5 M on the two one-zone fallbacks).  A benchmark
+    # run can afford the walk (setup, not timed): 8 s unless the caller has set a bound.  `obs_placement` in the line says what was found.
+    os.environ.setdefault("MEMGYM_OBS_SEARCH_MS", "8000")
+
     import torch
     import torch.distributed as dist
 

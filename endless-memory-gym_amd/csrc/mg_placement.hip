@@ -675,10 +675,13 @@ int mg_obs_alloc_for(int device, size_t bytes, size_t frame_bytes, size_t search
                 walked += PIECE;
                 // good enough (a quarter from another zone)?  Six more pieces of alternating kind first, without fillers: a
                 // second piece of the minority zone is often one request away (3 : 2 measures 0.785-0.79, 4 : 1 0.767-0.77)
+                // (round 6: ... and while less than a quarter of the time bound is spent, the walk goes on WITH fillers until the split is
+                // even: 4 : 1 was the outcome of two or three processes in eight on some boxes, 282 against 289-291 M env-steps/s)
                 const bool good_enough = groups.size() >= 2 && usable(loose_cap) >= k;
-                if (good_enough && ++tries_after_good > 6) break;
+                const bool early = elapsed_ms() < 0.25 * max_ms;
+                if (good_enough && ++tries_after_good > 6 && !early) break;
                 exportable = !exportable;
-                if (!exportable && !good_enough) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed.
+                if (!exportable && (!good_enough || early)) {  // every second time: step the ordinary allocator further -- or give up when that is not allowed.
                     // With piece-sized handles of the ordinary kind, 32 at a time (9.5 GiB): the driver serves requests of
                     // different sizes from different lists (big spacers -- 96 GiB, then 16 GiB at a time, the first version --
                     // moved the pieces' list on some boxes and not at all on others: 158 GiB walked, every piece from one zone),
