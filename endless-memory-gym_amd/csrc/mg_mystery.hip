@@ -1119,7 +1119,10 @@ static __device__ unsigned long long g_lab_step_clock[12 * 4096];
 // fall-off list) -- is requested in ONE batch: the kernel is a chain of dependent memory round trips on 512 waves (~2 us each on a
 // memory system the observation stream has just swept; rounds 3-4: records, then the fall-off list, then the stamina flags'
 // records, then the queue's counter), not a matter of bytes (profiles/r03_emp.md section 7, r05_emp.md).
-template <bool OWN_RESET, bool WHOLE_DESC = false>
+// FINAL (mg_step with mg_info_buffers.final_obs_dev, round 6): the frame descriptor of a finished instance's TERMINAL state goes to
+// io.tdesc[i] before anybody resets it (drawn into final_obs_dev by a sparse raster launch behind the fused one); the tail runs twice for
+// such an instance -- one copy of emp_fill_desc either way, and for FINAL = false the code of rounds 3-5 (a loop of exactly one pass).
+template <bool OWN_RESET, bool WHOLE_DESC = false, bool FINAL = false>
 __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, MysteryCore& s, int nx, int ny, float* reward_out,
                            uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc& d, bool cap = false) {
     typedef uint32_t q4 __attribute__((ext_vector_type(4)));
@@ -1288,8 +1291,7 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
     if (info.capacity_dev) info.capacity_dev[i] = cap ? 1 : 0;
     LAB_STEP_CLOCK(9);
     bool fresh = false;
-    if (done && autoreset) {
-        if (!(OWN_RESET && P.lazy && EMP_PRE(s) && EMP_OWED(s) == 0)) return true;
+    auto own_reset = [&]() {
         // EndlessMysteryPathEnv.reset (endless_mystery_path.py:195-280) with the first segment taken from the record that was
         // generated ahead of time; the stream continues behind that segment's draws, the other two segments are owed
         emp_pre_reset(s);
@@ -1314,8 +1316,28 @@ __device__ bool emp_step_b(const MysteryParams& P, const MysteryIO& io, int i, M
         emp_post_reset_state(P, io, i, s, gt, R);
         nx = s.ax / P.tile;
         fresh = true;
+    };
+    if (!FINAL) {  // (rounds 3-5, as it was)
+        if (done && autoreset) {
+            if (!(OWN_RESET && P.lazy && EMP_PRE(s) && EMP_OWED(s) == 0)) return true;
+            own_reset();
+        }
+        emp_fill_desc<WHOLE_DESC>(P, io, i, s, d, nx, R, Rprev);
+    } else {
+        const bool fin = done && autoreset;
+#pragma nounroll
+        for (int pass = fin ? 0 : 1; pass < 2; ++pass) {  // a finished instance: the terminal descriptor first
+            if (fin && pass == 1) {
+                if (!(OWN_RESET && P.lazy && EMP_PRE(s) && EMP_OWED(s) == 0)) return true;
+                own_reset();
+            }
+            emp_fill_desc<WHOLE_DESC>(P, io, i, s, d, nx, R, Rprev);
+            if (pass == 0) {
+                io.tdesc[i] = d;
+                if (LAB_BUILD && !OWN_RESET && io.stats) atomicAdd(io.stats + 4, 1ull);  // mg_debug_counter "emp_final_served" (lab build: tests)
+            }
+        }
     }
-    emp_fill_desc<WHOLE_DESC>(P, io, i, s, d, nx, R, Rprev);
     if (fresh) {
         d.cross_on = 0;
         if (P.show_stamina) d.stamina_red = 0;
@@ -1510,7 +1532,7 @@ constexpr int EMP_Q_SEGMENT = 1 << 30;
 constexpr int EMP_Q_OWED = 1 << 29;  // "generate one of the segments this instance is owed" (a background job served like an entry: bg_coop)
 constexpr int EMP_Q_INST = EMP_Q_OWED - 1;
 
-template <bool PS>
+template <bool PS, bool FINAL = false>
 __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, MysteryIO io, const int32_t* actions, float* reward_out,
                                                        uint8_t* done_out, float* gt, mg_info_buffers info, int autoreset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1531,7 +1553,7 @@ __global__ __launch_bounds__(256) void emp_step_kernel(MysteryParams P0, Mystery
     if (due) {  // the agent entered the last-but-one segment: the rest of its step needs the new one
         queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i | EMP_Q_SEGMENT, io.err);
     } else {
-        q = emp_step_b<!PS, true>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d, (ra & EMP_CAP) != 0);
+        q = emp_step_b<!PS, true, FINAL>(P, io, i, s, nx, ny, reward_out, done_out, gt ? gt + 3 * i : nullptr, info, autoreset, d, (ra & EMP_CAP) != 0);
         LAB_STEP_CLOCK(2);
         if (q) {
             queue_push(io.queue, &io.qctr[QC_COUNT], P.n, i, io.err);
@@ -1620,6 +1642,7 @@ __global__ __launch_bounds__(256) void emp_masked_reset_kernel(MysteryParams P, 
 
 // One queue entry, served by one converged wave whose lane 0 plays the instance's lane: "append a segment, finish the step"
 // and / or "reset" (three segments), state, stream and frame descriptor written back.
+template <bool FINAL = false>
 __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, const PathWS& W, int entry, const int64_t* seeds, float* reward_out,
                                 uint8_t* done_out, float* gt, const mg_info_buffers& info, int autoreset, MysteryDesc* d_out = nullptr) {
     const bool me = (threadIdx.x & 63) == 0;
@@ -1662,7 +1685,7 @@ __device__ void emp_serve_entry(const MysteryParams& P, const MysteryIO& io, con
             return;
         }
         if (me)
-            reset_me = emp_step_b<false>(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
+            reset_me = emp_step_b<false, false, FINAL>(P, io, i, s, floordiv_pos(s.ax, P.tile), floordiv_pos(s.ay, P.tile), reward_out, done_out,
                                          gti, info, autoreset, d, cap) ? 1 : 0;
         reset_me = bcast(reset_me, 0);
     }
@@ -2163,7 +2186,7 @@ static_assert(LW_BYTES <= v1::RASTER_LDS, "the lane generator's workspace must f
 // struct form that helped the spotlight family's fused kernel (service loop reading them through an opaque pointer where it uses
 // them): scratch 672 -> 624 B only -- the path generator wants ~200 VGPRs whatever the scalar side does -- and the launch got
 // SLOWER, 149-151 -> 156-164 us.)
-template <int FMT, bool EMP_NT>
+template <int FMT, bool EMP_NT, bool FINAL = false>
 __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(const MysteryDesc* __restrict__ descs, RasterAtlas A, void* __restrict__ obs, int n,
                                                                   MysteryParams P, MysteryIO io, float* reward_out, uint8_t* done_out,
                                                                   float* gt, mg_info_buffers info, int autoreset, int svc, int bgw, int turn) {
@@ -2198,7 +2221,7 @@ __global__ __launch_bounds__(256, MG_LAB_EMP_LB) void emp_raster_serve_kernel(co
             if (idx < count + bg) {
                 const int entry = idx < count ? bcast(io.queue[idx], 0) : (bcast(io.bgq[idx - count], 0) | EMP_Q_OWED);
 #ifndef MG_LAB_EMP_NOSVC  // (measurement builds: what the launch costs without the cooperative generator's registers; entries are dropped)
-                emp_serve_entry(P, io, W, entry, nullptr, reward_out, done_out, gt, info, autoreset, &sdesc[wv]);
+                emp_serve_entry<FINAL>(P, io, W, entry, nullptr, reward_out, done_out, gt, info, autoreset, &sdesc[wv]);
 #endif
                 if (!(entry & EMP_Q_OWED)) inst = entry & EMP_Q_INST;
                 if (me) idx = waves + atomicAdd(&io.qctr[QC_HEAD], 1);
@@ -2330,7 +2353,7 @@ class MysteryFamily : public Family {
         core_.alloc(n);
         walls_.alloc(n);
         desc_.alloc(n);
-        if (!endless) tdesc_.alloc(n);  // (terminal-frame descriptors of the FINAL kernels: 64 B per instance; allocated here so that no step allocates)
+        tdesc_.alloc(n);  // (terminal-frame descriptors of the FINAL kernels: 64 B per instance; allocated here so that no step allocates)
         rng_.alloc(n);
         err_.alloc();
         queue_.alloc((size_t)n + 32 + QC_WORDS);
@@ -2347,7 +2370,7 @@ class MysteryFamily : public Family {
                 jt[2 * k + 1] = make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(q >> 64), (uint32_t)(q >> 96));
             }
             jump_.upload(jt);
-            stats_.alloc(4);
+            stats_.alloc(8);
         }
         if (endless) {
             seg_rows_ = MAX_SEG;
@@ -2518,7 +2541,11 @@ class MysteryFamily : public Family {
             if (P_.lazy) owed_possible_ = true;
             upload_sets(s);
             const int sb = step_block(256);
+            // terminal observations (mg_step, mg_info_buffers.final_obs_dev): the FINAL forms of the two launches leave the terminal frame
+            // descriptors in tdesc_, a sparse raster launch behind them draws those frames (round 6; keeps_final_obs)
+            const bool keep_final = autoreset && ib.final_obs_dev && fused && keeps_final_obs(s);
             if (ps) hipLaunchKernelGGL(emp_step_kernel<true>, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
+            else if (keep_final) hipLaunchKernelGGL((emp_step_kernel<false, true>), dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
             else hipLaunchKernelGGL(emp_step_kernel<false>, dim3((n_ + sb - 1) / sb), dim3(sb), 0, s, P_, io(), actions, reward, done, gt, ib, autoreset);
             if (fused) {  // the queue is served inside the raster launch
                 end_logic(s);
@@ -2534,13 +2561,21 @@ class MysteryFamily : public Family {
                 const int bgw_later = bg_separate ? bgw : 0;
                 if (bg_separate) bgw = 0;
                 const int grid = (n_ < raster_grid(n_) ? n_ : raster_grid(n_)) + svc + bgw;  // (service, background, frames)
-                if (nt)
+                if (keep_final && nt)
+                    hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, true, true>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                       P_, io(), reward, done, gt, ib, autoreset, svc, bgw, turn_);
+                else if (keep_final)
+                    hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, false, true>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
+                                       P_, io(), reward, done, gt, ib, autoreset, svc, bgw, turn_);
+                else if (nt)
                     hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, true>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
                                        P_, io(), reward, done, gt, ib, autoreset, svc, bgw, turn_);
                 else
                     hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, false>), dim3(grid), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
                                        P_, io(), reward, done, gt, ib, autoreset, svc, bgw, turn_);
                 MG_HIP(hipGetLastError());
+                if (keep_final)  // every finished instance's flag is in `done` by now (the service workgroups wrote the last of them)
+                    launch_raster_sparse<MysteryComposer>(tdesc_.p, atlas_->dev(), ib.final_obs_dev, MG_OBS_U8_XYC, n_, s, done);
                 prof.end(1, s);
                 if (bgw_later)  // (grid = service + background workgroups only: no frames; the queue is empty by now)
                     hipLaunchKernelGGL((emp_raster_serve_kernel<MG_OBS_U8_XYC, false>), dim3(svc + bgw_later), dim3(256), RASTER_LDS, s, desc_.p, atlas_->dev(), obs, n_,
@@ -2622,7 +2657,7 @@ class MysteryFamily : public Family {
             *out = name == "emp_segments_sum" ? sum : (name == "emp_segments_max" ? mx : fmx);
             return true;
         }
-        const int k = name == "path_gen_ticks" ? 0 : (name == "path_gen_paths" ? 1 : (name == "emp_own_resets" ? 2 : (name == "emp_ahead_records" ? 3 : -1)));
+        const int k = name == "path_gen_ticks" ? 0 : (name == "path_gen_paths" ? 1 : (name == "emp_own_resets" ? 2 : (name == "emp_ahead_records" ? 3 : (name == "emp_final_served" ? 4 : -1))));
         if (k < 0 || !stats_.p) return false;
         unsigned long long v = 0;
         MG_HIP(hipMemcpy(&v, stats_.p + k, sizeof v, hipMemcpyDeviceToHost));
@@ -2698,10 +2733,12 @@ class MysteryFamily : public Family {
         MG_HIP(hipGetLastError());
     }
     // (the finite variants' step + raster / path-service launches keep terminal observations themselves; lab MEMGYM_MYSTERY_FINAL_FUSED=0: the
-    // generic path of mg_step.  Endless Mystery Path takes the generic path.)
+    // generic path of mg_step.  Endless Mystery Path: its step kernel and the service waves of its fused launch leave the terminal frame
+    // DESCRIPTORS behind, one sparse raster launch draws them -- lab MEMGYM_EMP_FINAL_FUSED=0: the generic path.)
     bool keeps_final_obs(hipStream_t) override {
-        static const bool wanted = lab_int("MEMGYM_MYSTERY_FINAL_FUSED", 1) != 0;
-        return wanted && !P_.endless && obs_format == MG_OBS_U8_XYC && !big_sprites_ && !per_set() && defer_mode() != 0;
+        static const bool wanted = lab_int("MEMGYM_MYSTERY_FINAL_FUSED", 1) != 0, emp_wanted = lab_int("MEMGYM_EMP_FINAL_FUSED", 1) != 0;
+        if (P_.endless) return emp_wanted && fuse_serve() && obs_format == MG_OBS_U8_XYC && !big_sprites_ && !per_set();
+        return wanted && obs_format == MG_OBS_U8_XYC && !big_sprites_ && !per_set() && defer_mode() != 0;
     }
     MysteryIO io() {
         MysteryIO o;

@@ -55,6 +55,14 @@ if os.environ.get("MEMGYM_SPARSE_CASES") == "mystery":  # test_mystery_launches_
 if os.environ.get("MEMGYM_SPARSE_CASES") == "emp_big":  # test_emp_masked_resets_...: the arrangement of launches above ~20,000 instances
     CASES = [("Endless-MysteryPath-v0", 32768, 60, "u8_xyc", None)]
 
+if os.environ.get("MEMGYM_SPARSE_CASES") == "emp":  # test_emp_launches_keep_terminal_observations: random agents and followers (a trailing
+    # "follow": the agent follows info["ground_truth"], 10 % random moves; max_steps: many instances truncated in one step, some of them in the
+    # very step in which they enter a new segment -- the one case in which the fused launch's SERVICE waves meet a terminal state), above and
+    # below the ~20,000 instances at which the arrangement of launches changes
+    # (a follower needs ~60 steps per segment: max_steps beyond the step in which the first segments are appended)
+    CASES = [("Endless-MysteryPath-v0", 32768, 120, "u8_xyc", None), ("Endless-MysteryPath-v0", 32768, 330, "u8_xyc", {"max_steps": 150, "follow": 1}),
+             ("Endless-MysteryPath-v0", 20001, 300, "u8_xyc", {"max_steps": 131, "follow": 1}), ("Endless-MysteryPath-v0", 4097, 300, "u8_xyc", {"max_steps": 140, "follow": 1})]
+
 STEPS_X = int(os.environ.get("MEMGYM_SPARSE_STEPS_X", "1"))  # one-off long runs of the same comparison
 
 for env_id, n, steps, fmt, options in CASES:
@@ -62,6 +70,9 @@ for env_id, n, steps, fmt, options in CASES:
     h = hashlib.sha256()
     vis = (lambda o: o["visual_observation"] if isinstance(o, dict) else o)
     # (1) the gymnasium vector convention: terminal observations + same-call resets
+    follow = bool(options and options.get("follow"))
+    if options and "follow" in options:
+        options = {k: v for k, v in options.items() if k != "follow"} or None
     envs = memory_gym_amd.GymnasiumVectorEnv(env_id, n, device=0, obs_format=fmt)
     adim = envs.env.action_dim
     n_act = 4 if adim == 1 else 3
@@ -71,6 +82,9 @@ for env_id, n, steps, fmt, options in CASES:
     finished = 0
     for t in range(steps):
         a = torch.randint(0, n_act, (n,) if adim == 1 else (n, adim), device="cuda", generator=g, dtype=torch.int32)
+        if follow:  # (ground truth of the previous step: one-hot right / up / down = actions 1 / 2 / 3... the library's own action codes)
+            gt = envs.env.gt
+            a = torch.where(torch.rand(n, device="cuda", generator=g) < 0.1, a, gt.argmax(1).to(torch.int32) + 1)
         obs, rew, term, trunc, infos = envs.step(a)
         upd(h, vis(obs)); upd(h, rew); upd(h, term)
         d = infos["_final_observation"]
@@ -78,6 +92,8 @@ for env_id, n, steps, fmt, options in CASES:
         if d.any():
             upd(h, vis(infos["final_observation"])[d])
     own = envs.env.debug_counter("emp_own_resets") if env_id == "Endless-MysteryPath-v0" else 0
+    if env_id == "Endless-MysteryPath-v0" and os.environ.get("MEMGYM_SPARSE_CASES") == "emp":
+        print("final_served %d" % envs.env.debug_counter("emp_final_served"), flush=True)
     for i in (0, n // 2, n - 1):
         h.update(np.asarray(envs.env.rng_words(i)).tobytes())
     envs.close()

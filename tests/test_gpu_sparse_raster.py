@@ -20,7 +20,7 @@ def digests(sparse, **more):
     r = subprocess.run([sys.executable, os.path.join(HERE, "sparse_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok: all cases" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     if more:
-        return [ln for ln in r.stdout.splitlines() if ln.startswith(("digest ", "own_resets "))]
+        return [ln for ln in r.stdout.splitlines() if ln.startswith(("digest ", "own_resets ", "final_served "))]
     return [ln for ln in r.stdout.splitlines() if ln.startswith("digest ")]
 
 
@@ -35,8 +35,9 @@ def test_emp_masked_resets_like_the_auto_reset_step():
     record generated ahead of time, like the auto-reset step (emp_masked_reset_kernel), or queues it for ONE lazily served segment --
     everything the caller sees (observations, terminal observations, rewards, dones, RNG words) equal to the run in which every masked
     instance is three cooperative paths of the queue server (lab MEMGYM_EMP_MASKED_FAST=0), and the fast path did reset instances itself."""
-    slow = digests(True, MEMGYM_SPARSE_CASES="emp_big", MEMGYM_EMP_MASKED_FAST="0")
-    fast = digests(True, MEMGYM_SPARSE_CASES="emp_big", MEMGYM_EMP_MASKED_FAST="1")
+    # (MEMGYM_EMP_FINAL_FUSED=0: the vector convention through the generic path of mg_step, whose resets are masked resets)
+    slow = digests(True, MEMGYM_SPARSE_CASES="emp_big", MEMGYM_EMP_MASKED_FAST="0", MEMGYM_EMP_FINAL_FUSED="0")
+    fast = digests(True, MEMGYM_SPARSE_CASES="emp_big", MEMGYM_EMP_MASKED_FAST="1", MEMGYM_EMP_FINAL_FUSED="0")
     assert slow[0] == fast[0] and slow[0].startswith("digest Endless-MysteryPath-v0 32768"), slow[0] + "\n" + fast[0]
     assert int(fast[0].rsplit("=", 1)[1]) > 32768  # (finished episodes: several per instance)
     assert int(slow[1].split()[1]) == 0 and int(fast[1].split()[1]) > 1000, (slow[1], fast[1])
@@ -78,3 +79,21 @@ def test_mystery_launches_keep_terminal_observations():
     fused = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="mystery", MEMGYM_MYSTERY_FINAL_FUSED="1") if ln.startswith("digest ")]
     assert len(generic) == 4 and generic == fused, "\n".join(a + "\n" + b for a, b in zip(generic, fused) if a != b)
     assert all(int(ln.rsplit("=", 1)[1]) > 0 for ln in generic)
+
+
+def test_emp_launches_keep_terminal_observations():
+    """Endless-MysteryPath-v0 keeps terminal observations with the auto-reset step's own launches (round 6: emp_step_kernel<false, true> and the
+    service waves of emp_raster_serve_kernel<u8, *, true> leave a finishing instance's terminal frame DESCRIPTOR in io.tdesc before anybody resets
+    it; one sparse raster launch behind them draws those frames into final_obs_dev): equal to the generic path of mg_step (lab
+    MEMGYM_EMP_FINAL_FUSED=0) in everything the caller sees incl. the terminal observations -- random agents and path followers, truncation of
+    many instances in one step, both arrangements of launches."""
+    generic = [ln for ln in digests(True, MEMGYM_SPARSE_CASES="emp", MEMGYM_EMP_FINAL_FUSED="0") if ln.startswith("digest ")]
+    assert len(generic) == 4 and all(int(ln.rsplit("=", 1)[1]) > 0 for ln in generic)
+    # (appended segments lazily -- the default: no step waits for a path, the service waves see resets only -- and, lab
+    # MEMGYM_EMP_LAZY_APPEND=0, by the service waves within the step that needs them: those finish the instance's step and can meet its end)
+    for lazy_append in ("1", "0"):
+        out = digests(True, MEMGYM_SPARSE_CASES="emp", MEMGYM_EMP_FINAL_FUSED="1", MEMGYM_EMP_LAZY_APPEND=lazy_append)
+        fused = [ln for ln in out if ln.startswith("digest ")]
+        assert generic == fused, "\n".join(a + "\n" + b for a, b in zip(generic, fused) if a != b)
+        served = [int(ln.split()[1]) for ln in out if ln.startswith("final_served ")]
+        assert len(served) == 4 and (sum(served[1:]) > 0) == (lazy_append == "0"), served
