@@ -482,6 +482,7 @@ def other_workloads(primary, dev, settle):
     plan.append(("Endless-MysteryPath-v0", "u8_xyc", "follower:0.02"))
     plan += [("MortarMayhem-Grid-v0", "f32_chw", None), ("MortarMayhem-Grid-v0", "bf16_chw", None)]
     plan.append(("MortarMayhem-Grid-v0", "u8_xyc", "vector_api"))  # (round 6) the same handle behind GymnasiumVectorEnv.step
+    plan.append(("Endless-MysteryPath-v0", "u8_xyc", "vector_api"))  # ... and the id the convention costs most (a sparse raster launch of terminal frames)
     for env_id, fmt, policy in plan:
         r = run_workload(env_id, DEFAULT_ENVS[env_id], 200, 30, settle, 1, 0, dev, obs_format=fmt, policy=policy)
         algo = FRAME * OBS_ELEM[fmt] + DESC_BYTES[env_id]  # algorithmic bytes of the dominant launch per instance-step (frame + descriptor)
@@ -502,9 +503,10 @@ def other_workloads(primary, dev, settle):
             e["policy"] = "uniform random"
             e["api"] = "memory_gym_amd.vector.GymnasiumVectorEnv.step"
             e["workload"] += ", gymnasium vector convention"
-            e["api_note"] = ("terminal observations kept in infos['final_observation'] (copied out of the observation buffer), finished instances "
-                             "reset in the same call (masked reset, frames drawn by the mask); the dominant launch is the step's, the rest of "
-                             "ms_per_step is what the convention adds")
+            e["api_note"] = ("terminal observations kept in infos['final_observation'], finished instances reset in the same call: mg_step with "
+                             "mg_info_buffers.final_obs_dev -- the step's own launches draw a finishing instance's terminal frame as well as its "
+                             "reset frame (Endless-MysteryPath: the terminal frames by one sparse raster launch behind them); the dominant launch "
+                             "is the step's, the rest of ms_per_step is what the convention adds")
         elif policy:
             e["policy_note"] = ("actions from the previous step's info['ground_truth'] (one-hot right / up / down), a random one with probability %s; "
                                 "the policy's three small torch kernels per step run on the launch stream inside the timed region" % policy.split(":")[1])
