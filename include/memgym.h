@@ -43,7 +43,10 @@ typedef struct mg_info_buffers {
     /* Optional (gymnasium 0.29 VectorEnv convention, info["final_observation"]): with autoreset != 0 and this pointer
      * set, mg_step also writes the TERMINAL observation of every instance that finished in this call to row i of this
      * buffer (same format and shape as obs_dev; rows of other instances are left untouched) while obs_dev row i holds
-     * the first observation of the new episode.  Costs one masked reset launch and two masked raster launches. */
+     * the first observation of the new episode.  uint8 observations, one option set: the step's own launches draw both frames (round 6;
+     * Endless-MysteryPath: the terminal frames by one sparse raster launch behind them) -- 0-4 % of a step for eight env ids, 11-12 % for
+     * SearingSpotlights-v0 and Endless-MysteryPath-v0.  Otherwise (float formats, per-instance option sets, the mortar family under graph
+     * capture): a step without auto-reset, the terminal rows copied, a masked reset whose frames a sparse raster launch draws. */
     void* final_obs_dev;
     /* Optional: the step reward of every instance as the reference computes it -- a Python float, i.e. a double
      * (e.g. mortar_mayhem_grid.py:288-352) -- next to reward_dev's float32 rounding of it; [num_envs]. */
